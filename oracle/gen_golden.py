@@ -1,0 +1,359 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures for the replay / parameter-server / worker hot path.
+
+TEST INFRASTRUCTURE ONLY.  Runs ONLY in the build container, where the reference
+checkout is mounted read-only at /root/reference.  It imports the reference's own
+Python modules (example/dsac.py, algos/sac1/sac1.py, algos/dqn/train.py) with stub
+modules standing in for the third-party packages that are absent from this image
+(ray, tensorflow, gym, spinup), drives the *reference's own* classes/functions
+(ReplayBuffer, ParameterServer, worker_rollout, worker_train) and records their
+inputs/outputs as small data fixtures under tests/golden/.
+
+No reference source (or bytecode) is copied; only input/output vectors are written.
+Nothing at test/bench run time reads /root/reference.
+
+Usage:  python oracle/gen_golden.py            # rewrites tests/golden/*.npz|*.json
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+import zlib
+from unittest import mock
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# --------------------------------------------------------------------------------------
+# stub third-party modules so that the reference's modules import
+# --------------------------------------------------------------------------------------
+def _install_stubs():
+    ray = types.ModuleType("ray")
+
+    def remote(*args, **kwargs):
+        # handles both @ray.remote and @ray.remote(num_gpus=1, max_calls=1)
+        if len(args) == 1 and not kwargs and (callable(args[0]) or isinstance(args[0], type)):
+            return args[0]
+        return lambda obj: obj
+
+    ray.remote = remote
+    ray.get = lambda x: x
+    ray.wait = lambda x, **k: (x, [])
+    ray.init = lambda *a, **k: None
+    ray.experimental = types.ModuleType("ray.experimental")
+    ray.experimental.tf_utils = mock.MagicMock()
+    sys.modules["ray"] = ray
+    sys.modules["ray.experimental"] = ray.experimental
+    sys.modules["ray.experimental.tf_utils"] = ray.experimental.tf_utils
+    for name in ("ray.rllib", "ray.rllib.utils", "ray.rllib.utils.compression"):
+        sys.modules[name] = mock.MagicMock()
+    for name in ("tensorflow", "gym", "gym.spaces", "spinup", "spinup.algos", "spinup.algos.sac",
+                 "spinup.algos.sac.core", "spinup.utils", "spinup.utils.logx",
+                 "spinup.utils.run_utils", "pandas"):
+        sys.modules[name] = mock.MagicMock()
+
+
+def _load(path, name, extra_path):
+    if extra_path not in sys.path:
+        sys.path.insert(0, extra_path)
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _mt_fingerprint():
+    st = np.random.get_state()
+    key = np.asarray(st[1], dtype=np.uint32)
+    return {"pos": int(st[2]), "key_crc32": int(zlib.crc32(key.tobytes())), "key_head": [int(v) for v in key[:4]]}
+
+
+def _transitions(n, obs_dim, act_dim, act_1d=False):
+    """Deterministic transitions in the dtypes a gym loop hands to store():
+    float64 observations, float32 actions, python-float reward, python bool done."""
+    out = []
+    for i in range(n):
+        obs = (np.arange(obs_dim, dtype=np.float64) * 0.25 + i * 1.000000123 + 1.0 / 3.0)
+        obs2 = obs + 0.1 + 1e-9 * i
+        if act_1d:
+            act = float(i % 5)
+        else:
+            act = (np.arange(act_dim, dtype=np.float32) - 0.5) * np.float32(0.3) + np.float32(i) * np.float32(0.01)
+        rew = float(i) * 0.7 - 3.3333333333333335
+        done = bool(i % 4 == 3)
+        out.append((obs, act, rew, obs2, done))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+def gen_index_streams(dsac):
+    """(1) index streams of ReplayBuffer.sample_batch  (example/dsac.py:39-45)."""
+    seeds = [0, 1, 12345, 2 ** 32 - 1]
+    sizes = [1, 2, 3, 100, 256, 257, 1000, 65536, 10 ** 6, 4 * 10 ** 6]
+    cap = max(sizes)
+    buf = dsac.ReplayBuffer(1, 1, cap)
+    buf.rews_buf[:] = np.arange(cap, dtype=np.float32)  # row value == row index (exact < 2**24)
+    rec = {}
+    meta = []
+    for s in seeds:
+        for n in sizes:
+            buf.size = n
+            np.random.seed(s)
+            a = buf.sample_batch(256)["rews"].astype(np.int64)
+            fp1 = _mt_fingerprint()
+            b = buf.sample_batch(100)["rews"].astype(np.int64)
+            fp2 = _mt_fingerprint()
+            tag = "s%d_n%d" % (s, n)
+            rec[tag + "_a"] = a.astype(np.int32)
+            rec[tag + "_b"] = b.astype(np.int32)
+            meta.append({"seed": s, "size": n, "after_256": fp1, "after_100": fp2})
+    np.savez_compressed(os.path.join(OUT, "index_streams.npz"), **rec)
+    with open(os.path.join(OUT, "index_streams.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
+def gen_ring_and_gather(dsac, sac1, dqn):
+    """(2)+(3) ring states after n stores and gathers out of them; (8) counts order."""
+    rec = {}
+    meta = []
+    obs_dim, act_dim = 8, 2
+    for cap in (7, 256):
+        for n in (cap - 1, cap, cap + 1, 3 * cap + 2):
+            for flavour, cls in (("dsac", dsac.ReplayBuffer), ("sac1", sac1.ReplayBuffer)):
+                buf = cls(obs_dim, act_dim, cap)
+                for tr in _transitions(n, obs_dim, act_dim):
+                    buf.store(*tr)
+                tag = "%s_c%d_n%d" % (flavour, cap, n)
+                for k in ("obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf"):
+                    rec[tag + "_" + k] = getattr(buf, k).copy()
+                entry = {"flavour": flavour, "cap": cap, "n": n, "ptr": int(buf.ptr), "size": int(buf.size),
+                         "counts_before": _jsonable(buf.get_counts()), "batches": []}
+                np.random.seed(7)
+                for B in (1, 32, 256):
+                    d = buf.sample_batch(B)
+                    for k, v in d.items():
+                        assert v.dtype == np.float32
+                        rec["%s_B%d_%s" % (tag, B, k)] = v
+                    entry["batches"].append({"B": B, "mt": _mt_fingerprint()})
+                entry["counts_after"] = _jsonable(buf.get_counts())
+                meta.append(entry)
+
+    # dqn-shaped buffer (algos/dqn/train.py:43-76): acts 1-D, extra worker_index arg, counts order
+    class Opt:
+        pass
+    opt = Opt()
+    opt.buffer_size, opt.obs_dim, opt.batch_size = 9, 12, 5
+    buf = dqn.ReplayBuffer(opt, 0)
+    for tr in _transitions(13, 12, 1, act_1d=True):
+        buf.store(*tr, 3)
+    tag = "dqn_c9_n13"
+    for k in ("obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf"):
+        rec[tag + "_" + k] = getattr(buf, k).copy()
+    np.random.seed(11)
+    d = buf.sample_batch()
+    for k, v in d.items():
+        rec[tag + "_B5_" + k] = v
+    meta.append({"flavour": "dqn", "cap": 9, "n": 13, "ptr": int(buf.ptr), "size": int(buf.size),
+                 "obs_dim": 12, "B": 5, "seed": 11, "counts_after": _jsonable(buf.get_counts()),
+                 "mt": _mt_fingerprint()})
+
+    # (4) empty buffer
+    buf = dsac.ReplayBuffer(obs_dim, act_dim, 5)
+    try:
+        buf.sample_batch(4)
+        err = None
+    except Exception as e:  # noqa
+        err = {"type": type(e).__name__, "msg": str(e)}
+    meta.append({"flavour": "empty", "error": err})
+
+    np.savez_compressed(os.path.join(OUT, "ring_gather.npz"), **rec)
+    with open(os.path.join(OUT, "ring_gather.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
+def _jsonable(x):
+    if isinstance(x, tuple):
+        return [int(v) for v in x]
+    return int(x)
+
+
+def gen_ps(dsac):
+    """(5) ParameterServer snapshot semantics (example/dsac.py:51-73)."""
+    keys = ["main/pi/dense/kernel", "main/pi/dense/bias", "main/q1/dense/kernel"]
+    vals = [np.arange(6, dtype=np.float32).reshape(2, 3), np.ones(3, np.float32), np.full((2, 2), 7, np.float32)]
+    ps = dsac.ParameterServer(keys, vals)
+    log = []
+    vals[0][0, 0] = 99.0  # mutate the source after construction: PS must not see it
+    log.append({"op": "pull_after_src_mutation", "keys": keys[:1], "out": [v.tolist() for v in ps.pull(keys[:1])]})
+    new = [np.full(3, 5, np.float32)]
+    ps.push(keys[1:2], new)
+    new[0][1] = -1.0  # mutate after push
+    log.append({"op": "pull_after_push", "keys": [keys[1], keys[0]],
+                "out": [v.tolist() for v in ps.pull([keys[1], keys[0]])]})
+    ps.push(["extra/key"], [np.zeros(1, np.float32)])  # push of an unknown key adds it
+    log.append({"op": "get_weights_keys", "out": list(ps.get_weights().keys())})
+    log.append({"op": "pull_order", "keys": [keys[2], "extra/key", keys[1]],
+                "out": [v.tolist() for v in ps.pull([keys[2], "extra/key", keys[1]])]})
+    with open(os.path.join(OUT, "ps_trace.json"), "w") as f:
+        json.dump(log, f, indent=0)
+
+
+class _Stop(Exception):
+    pass
+
+
+def gen_worker_traces(dsac, sac1):
+    """(6) worker_rollout event order, (7) worker_train push cadence, (8) sac1 throttle."""
+    ev = []
+
+    class FakeSpace:
+        def sample(self):
+            ev.append(["sample_random"])
+            return np.array([0.5, -0.5], np.float32)
+
+    class FakeEnv:
+        # scripted episode lengths: terminal after 3 steps, then time-limit (max_ep_len=5), then 2
+        lens = [3, 99, 2, 99]
+
+        def __init__(self):
+            self.action_space = FakeSpace()
+            self.ep = -1
+            self.k = 0
+
+        def reset(self):
+            self.ep += 1
+            self.k = 0
+            ev.append(["reset"])
+            return np.full(8, float(self.ep), np.float64)
+
+        def step(self, a):
+            self.k += 1
+            d = self.k >= self.lens[self.ep % len(self.lens)]
+            ev.append(["env_step", [float(x) for x in np.asarray(a).ravel()]])
+            return np.full(8, self.ep + 0.01 * self.k, np.float64), 1.5 * self.k, d, {}
+
+    class FakeAgent:
+        def __init__(self, *a, **k):
+            pass
+
+        def get_weights(self):
+            return ["main/pi/w"], [np.zeros(1, np.float32)]
+
+        def set_weights(self, keys, w):
+            ev.append(["set_weights", list(keys)])
+
+        def get_action(self, o, deterministic=False):
+            ev.append(["get_action", float(np.asarray(o).ravel()[0])])
+            return np.array([0.1, 0.2], np.float32)
+
+        n_train = 0
+
+        def train(self, *a):
+            FakeAgent.n_train += 1
+            if FakeAgent.n_train > 601:
+                raise _Stop()
+
+    class Remote:
+        def __init__(self, fn):
+            self.remote = fn
+
+    class FakePS:
+        def __init__(self):
+            self.pull = Remote(lambda keys: (ev.append(["pull", list(keys)]), [np.zeros(1, np.float32)])[1])
+            self.push = Remote(lambda keys, vals: ev.append(["push", FakeAgent.n_train]))
+
+    class FakeRB:
+        def __init__(self, counts=None):
+            self.counts = counts
+            self.store = Remote(lambda o, a, r, o2, d: ev.append(
+                ["store", float(np.asarray(o).ravel()[0]), [float(x) for x in np.asarray(a).ravel()],
+                 float(r), float(np.asarray(o2).ravel()[0]), bool(d)]))
+            self.get_counts = Remote(self._counts)
+
+        def _counts(self):
+            c = self.counts.pop(0) if len(self.counts) > 1 else self.counts[0]
+            ev.append(["get_counts", list(c)])
+            return tuple(c)
+
+    class Args:
+        pass
+
+    out = {}
+    # ---- example/dsac.py worker_rollout (dsac.py:76-130)
+    args = Args()
+    args.env, args.steps_per_epoch, args.epochs, args.start_steps, args.max_ep_len = "fake", 14, 1, 4, 5
+    dsac.gym.make = lambda name: FakeEnv()
+    dsac.Model = FakeAgent
+    dsac.worker_rollout(FakePS(), FakeRB(), args)
+    out["dsac_rollout"] = {"args": {"total_steps": 14, "start_steps": 4, "max_ep_len": 5,
+                                    "episode_lens": FakeEnv.lens}, "events": list(ev)}
+
+    # ---- example/dsac.py worker_train (dsac.py:133-150): 601 iterations -> pushes at 300, 600
+    ev.clear()
+    FakeAgent.n_train = 0
+    try:
+        dsac.worker_train(FakePS(), FakeRB(), args)
+    except _Stop:
+        pass
+    out["dsac_train"] = {"iterations": 601, "events": [e for e in ev if e[0] in ("push", "pull", "set_weights")]}
+
+    # ---- algos/sac1/sac1.py worker_rollout (sac1.py:157-213): throttle on a_l_ratio
+    ev.clear()
+    opt = Args()
+    opt.env_name, opt.obs_noise, opt.act_noise, opt.reward_scale = "fake", 0, 0, 1
+    opt.steps_per_epoch, opt.total_epochs, opt.start_steps, opt.max_ep_len, opt.a_l_ratio = 5, 1, 2, 5, 2
+    sac1.Wrapper = lambda env, *a: env
+    sac1.gym.make = lambda name: FakeEnv()
+    sac1.Actor = FakeAgent
+    sac1.time.sleep = lambda s: ev.append(["sleep", s])
+    # counts fed to the throttle: (sample_times, steps, size). 1st episode end: 0 samples -> no spin;
+    # 2nd: steps/sample_times = 3 > 2 -> spin twice until ratio 2.0; afterwards raise to stop
+    counts = [[0, 3, 3], [2, 6, 6], [2, 6, 6], [3, 6, 6], [1, 1, 1]]
+
+    class StopRB(FakeRB):
+        def _counts(self):
+            if len(self.counts) == 1:
+                raise _Stop()
+            return super()._counts()
+    try:
+        sac1.worker_rollout(FakePS(), StopRB(counts), opt, 0)
+    except _Stop:
+        pass
+    out["sac1_rollout"] = {"args": {"start_steps": 2, "max_ep_len": 5, "a_l_ratio": 2,
+                                    "episode_lens": FakeEnv.lens,
+                                    "counts_script": [[0, 3, 3], [2, 6, 6], [2, 6, 6], [3, 6, 6]]},
+                           "events": list(ev)}
+    with open(os.path.join(OUT, "worker_traces.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference checkout not present; fixtures can only be regenerated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    _install_stubs()
+    dsac = _load(os.path.join(REF, "example", "dsac.py"), "ref_dsac", os.path.join(REF, "example"))
+    sys.path.remove(os.path.join(REF, "example"))
+    for m in ("core", "model"):
+        sys.modules.pop(m, None)
+    sac1 = _load(os.path.join(REF, "algos", "sac1", "sac1.py"), "ref_sac1", os.path.join(REF, "algos", "sac1"))
+    sys.path.remove(os.path.join(REF, "algos", "sac1"))
+    for m in ("core", "hyperparams", "actor_learner"):
+        sys.modules.pop(m, None)
+    sys.path.insert(0, os.path.join(REF, "algos"))
+    dqn = _load(os.path.join(REF, "algos", "dqn", "train.py"), "ref_dqn", os.path.join(REF, "algos", "dqn"))
+    gen_index_streams(dsac)
+    gen_ring_and_gather(dsac, sac1, dqn)
+    gen_ps(dsac)
+    gen_worker_traces(dsac, sac1)
+    print("golden fixtures written to", OUT)
+    for fn in sorted(os.listdir(OUT)):
+        print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(OUT, fn))))
+
+
+if __name__ == "__main__":
+    main()
