@@ -1,0 +1,500 @@
+// Replay ring buffer on HBM: store (ring append with wrap), bit-exact NumPy-compatible MT19937
+// uniform index sampler, row gather.  Replaces class ReplayBuffer of the reference
+// (example/dsac.py:14-48, algos/sac1/sac1.py:28-63, algos/dqn/train.py:37-76).
+//
+// Data layout: the reference's own struct-of-arrays — obs1[N,obs] obs2[N,obs] acts[N,act] (or
+// [N]) rews[N] done[N], float32, row-major — so the rings are byte-compatible with the .npy
+// checkpoint of algos/dqn/train.py:82-90.  Cursor/counters and the MT19937 state live in a
+// device-side RingState so that store/sample kernels can be captured in a hipGraph and replayed
+// without host-side argument patching.
+#include "ddrl_common.h"
+
+namespace {
+
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+constexpr int SAMPLE_THREADS = 256;
+constexpr int MAX_FUSED_BATCH = 4096;          // idx staged in LDS for the fused sample+gather
+constexpr long long MAX_FUSED_BYTES = 1 << 18;  // fuse the gather when the whole batch is <= 256 KiB
+
+struct RingState {
+    long long ptr, size, steps, sample_times;
+    unsigned int done_counter;  // last-block-done ticket for the store kernel
+    int error;                  // sticky device-side error (sample from empty ring)
+    int mt_pos;
+    int pad;
+    uint32_t mt_key[MT_N];
+};
+
+struct RingPtrs {
+    float *obs1, *obs2, *acts, *rews, *done;
+    long long capacity;
+    int obs_dim, act_dim;  // act_dim == row width of acts (1 for the 1-D dqn shape)
+};
+
+struct BatchPtrs {
+    float *obs1, *obs2, *acts, *rews, *done;
+};
+
+// ------------------------------------------------------------------------------------------
+// store: n sequential ReplayBuffer.store() calls (example/dsac.py:29-37)
+// grid = (blocks, 5 arrays).  Rows i < n - capacity would be overwritten later in the same
+// batch, so they are skipped; every remaining destination row is unique.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, const float *obs, const float *act,
+                                               const float *rew, const float *obs2, const float *done,
+                                               long long n) {
+    __shared__ long long s_ptr;
+    if (threadIdx.x == 0) s_ptr = st->ptr;
+    __syncthreads();
+    const long long ptr = s_ptr, cap = ring.capacity;
+    const long long skip = n > cap ? n - cap : 0;
+    const int which = blockIdx.y;
+    const float *src;
+    float *dst;
+    int width;
+    switch (which) {
+        case 0: src = obs; dst = ring.obs1; width = ring.obs_dim; break;
+        case 1: src = obs2; dst = ring.obs2; width = ring.obs_dim; break;
+        case 2: src = act; dst = ring.acts; width = ring.act_dim; break;
+        case 3: src = rew; dst = ring.rews; width = 1; break;
+        default: src = done; dst = ring.done; width = 1; break;
+    }
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((width & 3) == 0) {
+        const int w4 = width >> 2;
+        const long long total = (n - skip) * w4;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (long long e = t0; e < total; e += stride) {
+            const long long i = skip + e / w4;
+            const int c = (int)(e % w4);
+            const long long row = (ptr + i) % cap;
+            d4[row * w4 + c] = s4[i * w4 + c];
+        }
+    } else {
+        const long long total = (n - skip) * width;
+        for (long long e = t0; e < total; e += stride) {
+            const long long i = skip + e / width;
+            const int c = (int)(e % width);
+            const long long row = (ptr + i) % cap;
+            dst[row * width + c] = src[i * width + c];
+        }
+    }
+    // last block to finish advances the cursor (every block has read st->ptr before its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total_blocks = gridDim.x * gridDim.y;
+        const unsigned ticket = atomicAdd(&st->done_counter, 1u);
+        if (ticket == total_blocks - 1) {
+            st->ptr = (ptr + n) % cap;
+            const long long sz = st->size + n;
+            st->size = sz > cap ? cap : sz;
+            st->steps += n;
+            st->done_counter = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MT19937 (NumPy legacy RandomState): seed == init_genrand
+// ------------------------------------------------------------------------------------------
+__global__ void k_mt_seed(RingState *st, uint32_t seed) {
+    // sequential recurrence; 624 steps on one lane (a few microseconds, off the hot path)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t x = seed;
+        st->mt_key[0] = x;
+        for (int i = 1; i < MT_N; ++i) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+            st->mt_key[i] = x;
+        }
+        st->mt_pos = MT_N;
+    }
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Regenerate all 624 words in LDS.  The recurrence mt[k] <- f(mt[k], mt[k+1], mt[(k+397)%624])
+// has lag 397, so it splits into three segments whose inputs are all available in parallel:
+// [0,227) reads only old words; [227,454) reads new words of segment 1; [454,624) reads new
+// words of segment 2 (and new mt[0] for k = 623).
+__device__ __forceinline__ void mt_twist_lds(uint32_t *mt, int tid) {
+    uint32_t v = 0;
+    if (tid < MT_N - MT_M) v = mt_mix(mt[tid], mt[tid + 1], mt[tid + MT_M]);
+    __syncthreads();
+    if (tid < MT_N - MT_M) mt[tid] = v;
+    __syncthreads();
+    const int k2 = (MT_N - MT_M) + tid;  // 227..453
+    if (tid < MT_N - MT_M) v = mt_mix(mt[k2], mt[k2 + 1], mt[k2 - (MT_N - MT_M)]);
+    __syncthreads();
+    if (tid < MT_N - MT_M) mt[k2] = v;
+    __syncthreads();
+    const int k3 = 2 * (MT_N - MT_M) + tid;  // 454..623
+    if (k3 < MT_N) v = mt_mix(mt[k3], mt[k3 == MT_N - 1 ? 0 : k3 + 1], mt[k3 - (MT_N - MT_M)]);
+    __syncthreads();
+    if (k3 < MT_N) mt[k3] = v;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void gather_rows(const float *__restrict__ ring, float *__restrict__ out,
+                                            const unsigned *s_idx, int B, int width, int tid, int nthreads) {
+    if ((width & 3) == 0) {
+        const int w4 = width >> 2;
+        const float4 *r4 = reinterpret_cast<const float4 *>(ring);
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (int e = tid; e < B * w4; e += nthreads) {
+            const int b = e / w4, c = e - b * w4;
+            o4[e] = r4[(long long)s_idx[b] * w4 + c];
+        }
+    } else {
+        for (int e = tid; e < B * width; e += nthreads) {
+            const int b = e / width, c = e - b * width;
+            out[e] = ring[(long long)s_idx[b] * width + c];
+        }
+    }
+}
+
+// idxs = np.random.randint(0, size, B) (masked rejection on 32-bit draws), optionally fused with
+// the five gathers when the batch is small (the SAC1 shape: 256 x 80 B).  One workgroup: the
+// accept/reject compaction is a wave ballot + prefix count, the stream position advances by
+// exactly the number of words NumPy would have consumed.
+__global__ void __launch_bounds__(SAMPLE_THREADS) k_sample(RingState *st, RingPtrs ring, BatchPtrs out, int B,
+                                                           long long *idx_out, int fuse_gather) {
+    __shared__ uint32_t mt[MT_N];
+    __shared__ int s_wave_tot[SAMPLE_THREADS / 64];
+    __shared__ int s_consumed;
+    __shared__ unsigned s_idx[MAX_FUSED_BATCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long size = st->size;
+    if (size <= 0) {  // reference: ValueError("high <= 0"); the host wrapper reports it
+        if (tid == 0) st->error = DDRL_ERR_EMPTY_BUFFER;
+        return;
+    }
+    const uint32_t rng = (uint32_t)(size - 1);
+    if (rng == 0) {
+        // NumPy fills with `low` and consumes no draw
+        for (int i = tid; i < B; i += SAMPLE_THREADS) {
+            if (idx_out) idx_out[i] = 0;
+            if (fuse_gather) s_idx[i] = 0;
+        }
+    } else {
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        for (int i = tid; i < MT_N; i += SAMPLE_THREADS) mt[i] = st->mt_key[i];
+        int pos = st->mt_pos;
+        bool dirty = false;
+        int produced = 0;
+        __syncthreads();
+        while (produced < B) {
+            if (pos >= MT_N) {
+                mt_twist_lds(mt, tid);
+                pos = 0;
+                dirty = true;
+            }
+            const int w = pos + tid;
+            const bool valid = w < MT_N;
+            const uint32_t v = valid ? (mt_temper(mt[w]) & mask) : 0xffffffffu;
+            const bool acc = valid && v <= rng;
+            const unsigned long long bal = __ballot(acc);
+            const int rank_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave_tot[wave] = __popcll(bal);
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < SAMPLE_THREADS / 64; ++i) {
+                const int t = s_wave_tot[i];
+                if (i < wave) off += t;
+                tot += t;
+            }
+            const int rank = off + rank_in_wave;
+            const int need = B - produced;
+            if (acc && rank < need) {
+                if (idx_out) idx_out[produced + rank] = (long long)v;
+                if (fuse_gather) s_idx[produced + rank] = v;
+                if (rank == need - 1) s_consumed = tid + 1;  // words consumed up to the last accepted draw
+            }
+            __syncthreads();
+            if (tot >= need) {
+                pos += s_consumed;
+                produced = B;
+            } else {
+                pos += (MT_N - pos < SAMPLE_THREADS) ? (MT_N - pos) : SAMPLE_THREADS;
+                produced += tot;
+            }
+            __syncthreads();
+        }
+        if (dirty)
+            for (int i = tid; i < MT_N; i += SAMPLE_THREADS) st->mt_key[i] = mt[i];
+        if (tid == 0) st->mt_pos = pos;
+    }
+    if (tid == 0) st->sample_times += 1;
+    if (fuse_gather) {
+        __syncthreads();
+        gather_rows(ring.obs1, out.obs1, s_idx, B, ring.obs_dim, tid, SAMPLE_THREADS);
+        gather_rows(ring.obs2, out.obs2, s_idx, B, ring.obs_dim, tid, SAMPLE_THREADS);
+        gather_rows(ring.acts, out.acts, s_idx, B, ring.act_dim, tid, SAMPLE_THREADS);
+        gather_rows(ring.rews, out.rews, s_idx, B, 1, tid, SAMPLE_THREADS);
+        gather_rows(ring.done, out.done, s_idx, B, 1, tid, SAMPLE_THREADS);
+    }
+}
+
+// Stand-alone gather for large rows (the dqn pixel shape: 2 x 112 896 B per index): one
+// workgroup per (row, array-slot) so that >= B*3 workgroups fill the chip; each lane keeps four
+// independent 16-B loads in flight (HBM-bound random-row gather).
+__global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, const long long *__restrict__ idx,
+                                                int B) {
+    const int b = blockIdx.x;
+    const long long row = idx[b];
+    const int tid = threadIdx.x;
+    if (blockIdx.y < 2) {
+        const float *src = (blockIdx.y == 0 ? ring.obs1 : ring.obs2) + row * ring.obs_dim;
+        float *dst = (blockIdx.y == 0 ? out.obs1 : out.obs2) + (long long)b * ring.obs_dim;
+        const int width = ring.obs_dim;
+        if ((width & 3) == 0) {
+            const int w4 = width >> 2;
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            int e = tid;
+            for (; e + 3 * 256 < w4; e += 4 * 256) {
+                const float4 a0 = s4[e], a1 = s4[e + 256], a2 = s4[e + 512], a3 = s4[e + 768];
+                d4[e] = a0; d4[e + 256] = a1; d4[e + 512] = a2; d4[e + 768] = a3;
+            }
+            for (; e < w4; e += 256) d4[e] = s4[e];
+        } else {
+            for (int e = tid; e < width; e += 256) dst[e] = src[e];
+        }
+    } else {
+        for (int e = tid; e < ring.act_dim; e += 256)
+            out.acts[(long long)b * ring.act_dim + e] = ring.acts[row * ring.act_dim + e];
+        if (tid == 0) {
+            out.rews[b] = ring.rews[row];
+            out.done[b] = ring.done[row];
+        }
+    }
+}
+
+__global__ void k_set_counts(RingState *st, long long ptr, long long size, long long steps, long long samples) {
+    st->ptr = ptr; st->size = size; st->steps = steps; st->sample_times = samples;
+    st->done_counter = 0; st->error = 0;
+}
+
+}  // namespace
+
+struct ddrl_replay {
+    int device;
+    RingPtrs ring;
+    RingState *state;    // device
+    long long *idx_buf;  // device scratch for indices when the caller passes none
+    long long idx_cap;
+    // host mirror of the counters: exact while every store/sample goes through this API
+    // eagerly; refreshed from the device by ddrl_replay_counts (graph replays run ahead of it)
+    long long h_ptr, h_size, h_steps, h_samples;
+    uint32_t flags;
+};
+
+static int refresh_counts(ddrl_replay *h, hipStream_t s) {
+    RingState tmp;
+    DDRL_HIP_CHECK(hipMemcpyAsync(&tmp, h->state, offsetof(RingState, mt_key), hipMemcpyDeviceToHost, s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    h->h_ptr = tmp.ptr; h->h_size = tmp.size; h->h_steps = tmp.steps; h->h_samples = tmp.sample_times;
+    return DDRL_OK;
+}
+
+extern "C" {
+
+int ddrl_replay_create(ddrl_replay_t **out, int device, int64_t capacity, int obs_dim, int act_dim,
+                       uint32_t flags) {
+    DDRL_REQUIRE(out != nullptr, "out is NULL");
+    DDRL_REQUIRE(capacity > 0 && capacity <= 0xFFFFFFFFll, "capacity must be in [1, 2^32-1]");
+    DDRL_REQUIRE(obs_dim > 0 && act_dim > 0, "obs_dim/act_dim must be positive");
+    DDRL_REQUIRE(!(flags & DDRL_REPLAY_ACTS_1D) || act_dim == 1, "ACTS_1D needs act_dim == 1");
+    ddrl::DeviceGuard g(device);
+    if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
+    ddrl_replay *h = new ddrl_replay();
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->flags = flags;
+    h->ring.capacity = capacity;
+    h->ring.obs_dim = obs_dim;
+    h->ring.act_dim = act_dim;
+    const size_t no = (size_t)capacity * obs_dim * sizeof(float), na = (size_t)capacity * act_dim * sizeof(float),
+                 n1 = (size_t)capacity * sizeof(float);
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&h->ring.obs1, no);
+    if (e == hipSuccess) e = hipMalloc(&h->ring.obs2, no);
+    if (e == hipSuccess) e = hipMalloc(&h->ring.acts, na);
+    if (e == hipSuccess) e = hipMalloc(&h->ring.rews, n1);
+    if (e == hipSuccess) e = hipMalloc(&h->ring.done, n1);
+    if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(RingState));
+    h->idx_cap = 1 << 16;
+    if (e == hipSuccess) e = hipMalloc(&h->idx_buf, h->idx_cap * sizeof(long long));
+    if (e != hipSuccess) {
+        ddrl::set_error("hipMalloc failed for replay of %lld x (%d,%d): %s", (long long)capacity, obs_dim, act_dim,
+                        hipGetErrorString(e));
+        ddrl_replay_destroy(h);
+        return DDRL_ERR_NOMEM;
+    }
+    // np.zeros for the five rings (example/dsac.py:21-25)
+    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.obs1, 0, no, nullptr));
+    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.obs2, 0, no, nullptr));
+    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.acts, 0, na, nullptr));
+    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.rews, 0, n1, nullptr));
+    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.done, 0, n1, nullptr));
+    DDRL_HIP_CHECK(hipMemsetAsync(h->state, 0, sizeof(RingState), nullptr));
+    k_mt_seed<<<1, 64, 0, nullptr>>>(h->state, 0u);
+    DDRL_LAUNCH_CHECK();
+    DDRL_HIP_CHECK(hipStreamSynchronize(nullptr));
+    *out = h;
+    return DDRL_OK;
+}
+
+int ddrl_replay_destroy(ddrl_replay_t *h) {
+    if (!h) return DDRL_OK;
+    ddrl::DeviceGuard g(h->device);
+    (void)hipFree(h->ring.obs1); (void)hipFree(h->ring.obs2); (void)hipFree(h->ring.acts);
+    (void)hipFree(h->ring.rews); (void)hipFree(h->ring.done); (void)hipFree(h->state); (void)hipFree(h->idx_buf);
+    delete h;
+    return DDRL_OK;
+}
+
+int ddrl_replay_seed(ddrl_replay_t *h, uint32_t seed, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    k_mt_seed<<<1, 64, 0, ddrl::as_stream(stream)>>>(h->state, seed);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_replay_store(ddrl_replay_t *h, const float *obs_d, const float *act_d, const float *rew_d,
+                      const float *obs2_d, const float *done_d, int64_t n, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(n >= 0, "n must be >= 0");
+    if (n == 0) return DDRL_OK;
+    DDRL_REQUIRE(obs_d && act_d && rew_d && obs2_d && done_d, "NULL transition pointer");
+    ddrl::DeviceGuard g(h->device);
+    const long long rows = n > h->ring.capacity ? h->ring.capacity : n;
+    const long long widest = rows * ((h->ring.obs_dim & 3) == 0 ? h->ring.obs_dim / 4 : h->ring.obs_dim);
+    long long blocks = (widest + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    k_store<<<dim3((unsigned)blocks, 5), 256, 0, ddrl::as_stream(stream)>>>(h->state, h->ring, obs_d, act_d, rew_d,
+                                                                            obs2_d, done_d, n);
+    DDRL_LAUNCH_CHECK();
+    h->h_ptr = (h->h_ptr + n) % h->ring.capacity;
+    h->h_size = (h->h_size + n > h->ring.capacity) ? h->ring.capacity : h->h_size + n;
+    h->h_steps += n;
+    return DDRL_OK;
+}
+
+static int launch_gather(ddrl_replay *h, const long long *idx, int64_t B, BatchPtrs out, hipStream_t s) {
+    k_gather<<<dim3((unsigned)B, 3), 256, 0, s>>>(h->ring, out, idx, (int)B);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *obs2_d, float *acts_d,
+                       float *rews_d, float *done_d, int64_t *idx_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(batch > 0 && batch <= (1 << 24), "batch must be in [1, 2^24]");
+    DDRL_REQUIRE(obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL output pointer");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    if (h->h_size <= 0) {
+        // the mirror may lag behind graph replays: ask the device before reporting empty
+        int rc = refresh_counts(h, s);
+        if (rc != DDRL_OK) return rc;
+        if (h->h_size <= 0) {
+            ddrl::set_error("high <= 0");  // message of the reference's ValueError
+            return DDRL_ERR_EMPTY_BUFFER;
+        }
+    }
+    BatchPtrs out{obs1_d, obs2_d, acts_d, rews_d, done_d};
+    const long long bytes = batch * (2ll * h->ring.obs_dim + h->ring.act_dim + 2) * (long long)sizeof(float);
+    const int fuse = (batch <= MAX_FUSED_BATCH && bytes <= MAX_FUSED_BYTES) ? 1 : 0;
+    long long *idx = reinterpret_cast<long long *>(idx_d);
+    if (!fuse && !idx) {
+        if (batch > h->idx_cap) {
+            DDRL_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(h->idx_buf);
+            h->idx_cap = batch;
+            DDRL_HIP_CHECK(hipMalloc(&h->idx_buf, h->idx_cap * sizeof(long long)));
+        }
+        idx = h->idx_buf;
+    }
+    k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, out, (int)batch, idx, fuse);
+    DDRL_LAUNCH_CHECK();
+    h->h_samples += 1;
+    if (!fuse) return launch_gather(h, idx, batch, out, s);
+    return DDRL_OK;
+}
+
+int ddrl_replay_gather(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *obs1_d, float *obs2_d,
+                       float *acts_d, float *rews_d, float *done_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && idx_d != nullptr, "NULL handle or index pointer");
+    DDRL_REQUIRE(batch > 0 && batch <= (1 << 24), "batch must be in [1, 2^24]");
+    DDRL_REQUIRE(obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL output pointer");
+    ddrl::DeviceGuard g(h->device);
+    BatchPtrs out{obs1_d, obs2_d, acts_d, rews_d, done_d};
+    return launch_gather(h, reinterpret_cast<const long long *>(idx_d), batch, out, ddrl::as_stream(stream));
+}
+
+int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_t *steps_h,
+                       int64_t *sample_times_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    int rc = refresh_counts(h, ddrl::as_stream(stream));
+    if (rc != DDRL_OK) return rc;
+    if (ptr_h) *ptr_h = h->h_ptr;
+    if (size_h) *size_h = h->h_size;
+    if (steps_h) *steps_h = h->h_steps;
+    if (sample_times_h) *sample_times_h = h->h_samples;
+    return DDRL_OK;
+}
+
+int ddrl_replay_buffers(ddrl_replay_t *h, float **obs1_d, float **obs2_d, float **acts_d, float **rews_d,
+                        float **done_d) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    if (obs1_d) *obs1_d = h->ring.obs1;
+    if (obs2_d) *obs2_d = h->ring.obs2;
+    if (acts_d) *acts_d = h->ring.acts;
+    if (rews_d) *rews_d = h->ring.rews;
+    if (done_d) *done_d = h->ring.done;
+    return DDRL_OK;
+}
+
+int ddrl_replay_set_counts(ddrl_replay_t *h, int64_t ptr, int64_t size, int64_t steps, int64_t sample_times,
+                           void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(ptr >= 0 && ptr < h->ring.capacity && size >= 0 && size <= h->ring.capacity, "ptr/size out of range");
+    ddrl::DeviceGuard g(h->device);
+    k_set_counts<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->state, ptr, size, steps, sample_times);
+    DDRL_LAUNCH_CHECK();
+    h->h_ptr = ptr; h->h_size = size; h->h_steps = steps; h->h_samples = sample_times;
+    return DDRL_OK;
+}
+
+int ddrl_replay_mt_state(ddrl_replay_t *h, uint32_t *key_h, int32_t *pos_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr && key_h != nullptr && pos_h != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    RingState tmp;
+    hipStream_t s = ddrl::as_stream(stream);
+    DDRL_HIP_CHECK(hipMemcpyAsync(&tmp, h->state, sizeof(RingState), hipMemcpyDeviceToHost, s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(key_h, tmp.mt_key, sizeof(tmp.mt_key));
+    *pos_h = tmp.mt_pos;
+    return DDRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""ReplayBuffer with the reference's surface, backed by the HBM ring of libddrl_hip.so.
+
+Mirrors (same names, argument meaning, error behaviour):
+  example/dsac.py:14-48        class ReplayBuffer            -> ReplayBuffer
+  algos/sac1/sac1.py:28-63     class ReplayBuffer (counters) -> ReplayBufferSAC1
+  algos/dqn/train.py:37-108    class ReplayBuffer(opt, idx)  -> ReplayBufferDQN (+ save/load .npy)
+
+`store` / `sample_batch` keep the reference's host-side types (NumPy in, dict of fresh float32
+NumPy arrays out).  The vectorised device path adds `store_batch` / `sample_batch_device`
+(torch CUDA tensors in/out, no host round trip); both run the same kernels.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class ReplayBuffer:
+    """A simple FIFO experience replay buffer for SAC agents (example/dsac.py:14-48)."""
+
+    _default_batch = 32
+    _acts_1d = False
+
+    def __init__(self, obs_dim, act_dim, size, device=None, seed=None):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self.obs_dim, self.act_dim, self.max_size = int(obs_dim), int(act_dim), int(size)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        h = ctypes.c_void_p()
+        flags = _lib.DDRL_REPLAY_ACTS_1D if self._acts_1d else 0
+        _lib.check(self._lib.ddrl_replay_create(ctypes.byref(h), self.device.index, self.max_size, self.obs_dim,
+                                                self.act_dim, flags))
+        self._h = h
+        self._out = {}
+        if seed is not None:
+            self.seed(seed)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_replay_destroy(h)
+
+    # -- np.random.seed(s) of the reference's buffer process ---------------------------------
+    def seed(self, s):
+        _lib.check(self._lib.ddrl_replay_seed(self._h, int(s) & 0xFFFFFFFF, _lib.stream_ptr()))
+
+    # -- reference surface ---------------------------------------------------------------------
+    def store(self, obs, act, rew, next_obs, done, worker_index=None):
+        """One transition (example/dsac.py:29-37).  Values are cast to float32 exactly as the
+        NumPy row assignment does (float64 -> f32 round-to-nearest, bool -> 0.0/1.0)."""
+        o = torch.from_numpy(np.asarray(obs, dtype=np.float32).reshape(1, self.obs_dim))
+        o2 = torch.from_numpy(np.asarray(next_obs, dtype=np.float32).reshape(1, self.obs_dim))
+        a = torch.from_numpy(np.asarray(act, dtype=np.float32).reshape(1, self.act_dim))
+        r = torch.from_numpy(np.asarray(rew, dtype=np.float32).reshape(1))
+        d = torch.from_numpy(np.asarray(done, dtype=np.float32).reshape(1))
+        self.store_batch(*(t.to(self.device) for t in (o, a, r, o2, d)))
+
+    def store_batch(self, obs, act, rew, next_obs, done):
+        """n sequential store() calls in row order (device tensors, float32)."""
+        n = int(rew.shape[0])
+        obs, act, rew, next_obs, done = (self._f32(t) for t in (obs, act, rew, next_obs, done))
+        assert obs.numel() == n * self.obs_dim and next_obs.numel() == n * self.obs_dim
+        assert act.numel() == n * self.act_dim and done.numel() == n
+        _lib.check(self._lib.ddrl_replay_store(self._h, _lib.dptr(obs), _lib.dptr(act), _lib.dptr(rew),
+                                               _lib.dptr(next_obs), _lib.dptr(done), n, _lib.stream_ptr()))
+
+    def sample_batch(self, batch_size=None):
+        """dict(obs1, obs2, acts, rews, done) of fresh float32 NumPy arrays (example/dsac.py:39-45).
+        Raises ValueError("high <= 0") on an empty buffer like the reference."""
+        d = self.sample_batch_device(batch_size, fresh=True)
+        return {k: v.cpu().numpy() for k, v in d.items()}
+
+    def sample_batch_device(self, batch_size=None, fresh=False, with_indices=False):
+        B = int(self._default_batch if batch_size is None else batch_size)
+        out = self._buffers(B, fresh)
+        idx = None
+        if with_indices:
+            idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        _lib.check(self._lib.ddrl_replay_sample(self._h, B, _lib.dptr(out["obs1"]), _lib.dptr(out["obs2"]),
+                                                _lib.dptr(out["acts"]), _lib.dptr(out["rews"]),
+                                                _lib.dptr(out["done"]), _lib.dptr(idx), _lib.stream_ptr()))
+        if with_indices:
+            out = dict(out, idxs=idx)
+        return out
+
+    def gather_device(self, idx, fresh=True):
+        """The five fancy-index gathers for caller-supplied int64 device indices."""
+        B = int(idx.numel())
+        out = self._buffers(B, fresh)
+        idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
+        _lib.check(self._lib.ddrl_replay_gather(self._h, _lib.dptr(idx), B, _lib.dptr(out["obs1"]),
+                                                _lib.dptr(out["obs2"]), _lib.dptr(out["acts"]),
+                                                _lib.dptr(out["rews"]), _lib.dptr(out["done"]), _lib.stream_ptr()))
+        return out
+
+    def get_counts(self):
+        """example/dsac.py:47-48: number of store() calls so far."""
+        return self._counts()[2]
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _f32(self, t):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(np.asarray(t, dtype=np.float32))
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _buffers(self, B, fresh):
+        if not fresh and B in self._out:
+            return self._out[B]
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        out = dict(obs1=e(B, self.obs_dim), obs2=e(B, self.obs_dim),
+                   acts=e(B) if self._acts_1d else e(B, self.act_dim), rews=e(B), done=e(B))
+        if not fresh:
+            self._out[B] = out
+        return out
+
+    def _counts(self):
+        c = [ctypes.c_int64() for _ in range(4)]
+        _lib.check(self._lib.ddrl_replay_counts(self._h, *[ctypes.byref(x) for x in c], _lib.stream_ptr()))
+        return tuple(int(x.value) for x in c)  # (ptr, size, steps, sample_times)
+
+    @property
+    def ptr(self):
+        return self._counts()[0]
+
+    @property
+    def size(self):
+        return self._counts()[1]
+
+    def rings(self):
+        """Views of the five rings as torch tensors (device memory owned by the handle)."""
+        p = [ctypes.c_void_p() for _ in range(5)]
+        _lib.check(self._lib.ddrl_replay_buffers(self._h, *[ctypes.byref(x) for x in p]))
+        N = self.max_size
+        shapes = [(N, self.obs_dim), (N, self.obs_dim), (N,) if self._acts_1d else (N, self.act_dim), (N,), (N,)]
+        names = ["obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf"]
+        return {n: _view(ptr.value, s, self.device) for n, ptr, s in zip(names, p, shapes)}
+
+    def mt_state(self):
+        key = np.empty(624, dtype=np.uint32)
+        pos = ctypes.c_int32()
+        _lib.check(self._lib.ddrl_replay_mt_state(self._h, ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos),
+                                                  _lib.stream_ptr()))
+        return key, int(pos.value)
+
+
+class ReplayBufferSAC1(ReplayBuffer):
+    """algos/sac1/sac1.py:28-63: default batch 128, get_counts -> (sample_times, steps, size)."""
+    _default_batch = 128
+
+    def get_counts(self):
+        _, size, steps, samples = self._counts()
+        return samples, steps, size
+
+
+class ReplayBufferDQN(ReplayBuffer):
+    """algos/dqn/train.py:37-108: ReplayBuffer(opt, buffer_index), 1-D acts_buf, batch size from
+    opt, get_counts -> (learner_steps, actor_steps, size), save/load of the .npy checkpoint."""
+    _acts_1d = True
+
+    def __init__(self, opt, buffer_index, device=None, seed=None):
+        self.opt, self.buffer_index = opt, buffer_index
+        super().__init__(opt.obs_dim, 1, opt.buffer_size, device=device, seed=seed)
+
+    def store(self, obs, act, rew, next_obs, done, worker_index=None):
+        super().store(obs, act, rew, next_obs, done)
+
+    def sample_batch(self, batch_size=None):
+        return super().sample_batch(self.opt.batch_size if batch_size is None else batch_size)
+
+    def get_counts(self):
+        _, size, steps, samples = self._counts()
+        return samples, steps, size
+
+    def _ckpt(self, checkpoint_path=None):
+        return checkpoint_path if checkpoint_path else os.path.join(self.opt.save_dir, "checkpoint")
+
+    def save(self, checkpoint_path=None):
+        """Five .npy arrays + buffer_infos (ptr, size, max_size, actor_steps, learner_steps)
+        — the on-disk format of algos/dqn/train.py:82-90."""
+        path = self._ckpt(checkpoint_path)
+        os.makedirs(path, exist_ok=True)
+        for name, t in self.rings().items():
+            np.save(os.path.join(path, "%s-%s" % (name, self.buffer_index)), t.cpu().numpy())
+        ptr, size, steps, samples = self._counts()
+        np.save(os.path.join(path, "buffer_infos-%s" % self.buffer_index),
+                np.array((ptr, size, self.max_size, steps, samples)))
+
+    def load(self, checkpoint_path=None):
+        """algos/dqn/train.py:92-108."""
+        path = self._ckpt(checkpoint_path)
+        rings = self.rings()
+        for name, t in rings.items():
+            arr = np.load(os.path.join(path, "%s-%s.npy" % (name, self.buffer_index)))
+            t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).reshape(t.shape))
+        infos = np.load(os.path.join(path, "buffer_infos-%s.npy" % self.buffer_index))
+        _lib.check(self._lib.ddrl_replay_set_counts(self._h, int(infos[0]), int(infos[1]), int(infos[3]),
+                                                    int(infos[4]), _lib.stream_ptr()))
+
+
+def _view(ptr, shape, device):
+    """Wrap raw device memory owned by a handle as a float32 torch tensor (no copy)."""
+    n = int(np.prod(shape))
+
+    class _Holder:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Holder(), device=device).view(*shape)

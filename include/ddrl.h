@@ -1,0 +1,254 @@
+/*
+ * ddrl.h — C-ABI of libddrl_hip.so: the MI355X-native (gfx950) actor–learner hot path of
+ * createamind/Distributed-DRL (replay ring store + uniform-sample gather, SAC1 learner update,
+ * batched policy forward, batched env.step, parameter-server buffer).
+ *
+ * The reference has no FFI on this path: its boundary is Ray's remote-callable surface
+ * (`Class.remote(...)`, `handle.method.remote(...)`, `ray.get`) over plain-Python/NumPy classes.
+ * Each entry point below cites the reference interface it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add; `distributed-drl_amd/` holds that binding plus the Python classes with the
+ * reference's names and signatures.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_d / documented "device" is a device pointer
+ *     (HBM) to float32 unless stated otherwise; host pointers are named *_h / documented "host".
+ *   - every function returns 0 (DDRL_OK) or a negative ddrl_status; no exception or abort
+ *     crosses the boundary; `ddrl_last_error()` returns a thread-local message.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All device work is
+ *     enqueued on it; no call synchronises the device except where documented (counts /
+ *     *_to_host helpers).  Inputs are borrowed until the stream reaches the enqueued work;
+ *     outputs are caller-allocated; handles own all persistent device memory.
+ *   - handles are not thread-safe (the reference's actors execute methods serially,
+ *     algos/sac1/sac_ray.py:316-317); the Python actor shim serialises calls per handle.
+ */
+#ifndef DDRL_H
+#define DDRL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDRL_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    DDRL_OK = 0,
+    DDRL_ERR_BAD_ARG = -1,
+    DDRL_ERR_EMPTY_BUFFER = -2, /* sample from an empty ring: reference raises ValueError("high <= 0") */
+    DDRL_ERR_HIP = -3,
+    DDRL_ERR_NOMEM = -4,
+    DDRL_ERR_UNSUPPORTED = -5
+} ddrl_status;
+
+int ddrl_version(void);
+const char *ddrl_last_error(void);
+/* Name of the device the library sees as `device` ("gfx950…"), for fail-loud checks. host buf. */
+int ddrl_device_arch(int device, char *buf_h, int buflen);
+
+/* ===================================================================================== */
+/* Replay ring buffer — replaces class ReplayBuffer                                       */
+/*   example/dsac.py:14-48, algos/sac1/sac1.py:28-63, algos/dqn/train.py:37-76            */
+/* ===================================================================================== */
+typedef struct ddrl_replay ddrl_replay_t;
+
+#define DDRL_REPLAY_ACTS_1D 1u /* algos/dqn/train.py:48: acts_buf is [N] (act_dim must be 1) */
+
+/* ReplayBuffer.__init__(obs_dim, act_dim, size)  (example/dsac.py:20-27): five zero-filled
+ * float32 struct-of-arrays rings obs1[N,obs] obs2[N,obs] acts[N,act] rews[N] done[N];
+ * ptr = size = 0; counters steps / sample_times = 0; MT19937 stream seeded with 0. */
+int ddrl_replay_create(ddrl_replay_t **out, int device, int64_t capacity, int obs_dim, int act_dim,
+                       uint32_t flags);
+int ddrl_replay_destroy(ddrl_replay_t *h);
+
+/* np.random.seed(seed) in the reference's ReplayBuffer process (legacy global MT19937,
+ * init_genrand).  Enqueued on `stream`. */
+int ddrl_replay_seed(ddrl_replay_t *h, uint32_t seed, void *stream);
+
+/* ReplayBuffer.store(obs, act, rew, next_obs, done) x n  (example/dsac.py:29-37): exactly n
+ * sequential store() calls in row order, including wrap-around inside the batch
+ * (ptr=(ptr+1)%N, size=min(size+1,N), steps+=1 per row).  Device float32 inputs:
+ * obs_d[n,obs_dim] act_d[n,act_dim] rew_d[n] obs2_d[n,obs_dim] done_d[n] (done as 0.0/1.0). */
+int ddrl_replay_store(ddrl_replay_t *h, const float *obs_d, const float *act_d, const float *rew_d,
+                      const float *obs2_d, const float *done_d, int64_t n, void *stream);
+
+/* ReplayBuffer.sample_batch(batch_size)  (example/dsac.py:39-45; algos/sac1/sac1.py:53-60 also
+ * bumps sample_times): idxs = np.random.randint(0, size, batch_size) on the ring's MT19937
+ * stream (bit-exact, the stream position advances by exactly the words NumPy would consume),
+ * then the five fancy-index gathers into caller buffers obs1_d[B,obs] obs2_d[B,obs]
+ * acts_d[B,act] rews_d[B] done_d[B].  idx_d (device int64[B]) may be NULL.
+ * Returns DDRL_ERR_EMPTY_BUFFER when size == 0 (reference: ValueError "high <= 0"). */
+int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *obs2_d, float *acts_d,
+                       float *rews_d, float *done_d, int64_t *idx_d, void *stream);
+
+/* Same gather for caller-provided indices (device int64[B]); does not touch the MT stream or
+ * sample_times.  Used by the sharded sampler and by size-independent property tests. */
+int ddrl_replay_gather(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *obs1_d,
+                       float *obs2_d, float *acts_d, float *rews_d, float *done_d, void *stream);
+
+/* ReplayBuffer.get_counts()  (example/dsac.py:47-48 -> steps; algos/sac1/sac1.py:62-63 ->
+ * (sample_times, steps, size)).  Synchronises `stream` (the only sync on the replay path).
+ * Any out pointer may be NULL.  Host outputs. */
+int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_t *steps_h,
+                       int64_t *sample_times_h, void *stream);
+
+/* Raw ring pointers (device) for checkpointing / inspection (algos/dqn/train.py:82-90 saves
+ * exactly these five arrays + (ptr,size,max_size,steps,sample_times)). */
+int ddrl_replay_buffers(ddrl_replay_t *h, float **obs1_d, float **obs2_d, float **acts_d,
+                        float **rews_d, float **done_d);
+/* Restore counters after loading the arrays (algos/dqn/train.py:92-108). */
+int ddrl_replay_set_counts(ddrl_replay_t *h, int64_t ptr, int64_t size, int64_t steps,
+                           int64_t sample_times, void *stream);
+/* Copy the MT19937 state (624 words + position) to the host; synchronises `stream`. */
+int ddrl_replay_mt_state(ddrl_replay_t *h, uint32_t *key_h, int32_t *pos_h, void *stream);
+
+/* ===================================================================================== */
+/* Parameter server — replaces class ParameterServer (example/dsac.py:51-73)              */
+/*   one flat float32 device buffer; the name -> (offset, shape) table lives in Python    */
+/* ===================================================================================== */
+typedef struct ddrl_ps ddrl_ps_t;
+
+int ddrl_ps_create(ddrl_ps_t **out, int device, int64_t count);
+int ddrl_ps_destroy(ddrl_ps_t *h);
+/* push: snapshot-by-copy of src_d[count] into the server at `offset` (dsac.py:59-62);
+ * bumps the version.  pull: copy out (dsac.py:64-65). Device<->device, on `stream`. */
+int ddrl_ps_push(ddrl_ps_t *h, const float *src_d, int64_t offset, int64_t count, void *stream);
+int ddrl_ps_pull(ddrl_ps_t *h, float *dst_d, int64_t offset, int64_t count, void *stream);
+int ddrl_ps_buffer(ddrl_ps_t *h, float **buf_d, int64_t *count);
+int64_t ddrl_ps_version(ddrl_ps_t *h);
+
+/* ===================================================================================== */
+/* SAC1 learner — replaces class Learner (algos/sac1/actor_learner.py:19-148) with the    */
+/* network of algos/sac1/core.py:91-121                                                   */
+/* ===================================================================================== */
+typedef struct ddrl_sac1 ddrl_sac1_t;
+
+typedef struct {
+    int32_t obs_dim;   /* 8  LunarLanderContinuous-v2 */
+    int32_t act_dim;   /* 2 */
+    int32_t hidden1;   /* 400  core.py:91 hidden_sizes=(400,300) */
+    int32_t hidden2;   /* 300 */
+    int32_t batch;     /* 256  hyperparams.py:82 */
+    float alpha;       /* 0.1    hyperparams.py:60 (fixed, not 'auto') */
+    float gamma;       /* 0.997  hyperparams.py:67 */
+    float lr;          /* 5e-5   hyperparams.py:78 */
+    float polyak;      /* 0.995  hyperparams.py:79 */
+    float beta1;       /* 0.9    tf.train.AdamOptimizer defaults */
+    float beta2;       /* 0.999 */
+    float adam_eps;    /* 1e-8 */
+    float act_scale;   /* action_space.high[0] = 1.0  core.py:104-106 */
+} ddrl_sac1_config_t;
+
+/* Parameter layout (flat float32, TF variable creation order, kernels [in,out] row-major):
+ *   pi : dense/kernel[obs,h1] dense/bias[h1] dense_1/kernel[h1,h2] dense_1/bias[h2]
+ *        dense_2/kernel[h2,act] dense_2/bias[act] (mu)  dense_3/kernel[h2,act] dense_3/bias[act] (log_std)
+ *   q1 : dense/kernel[obs+act,h1] dense/bias[h1] dense_1/kernel[h1,h2] dense_1/bias[h2]
+ *        dense_2/kernel[h2,1] dense_2/bias[1]
+ *   q2 : as q1
+ * flat = [pi | q1 | q2]; n_pi = 125104, n_q = 125001 at the default sizes. */
+int ddrl_sac1_param_counts(const ddrl_sac1_config_t *cfg, int64_t *n_pi, int64_t *n_q);
+
+int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cfg);
+int ddrl_sac1_destroy(ddrl_sac1_t *h);
+
+/* Learner.set_weights (actor_learner.py:125-127): copy flat main weights in, then target_init
+ * (target <- main).  Does not touch Adam state.  flat_main_d: device float32[n_pi+2*n_q]. */
+int ddrl_sac1_set_weights(ddrl_sac1_t *h, const float *flat_main_d, void *stream);
+/* Learner.get_weights (actor_learner.py:129-133): the "main" variables. */
+int ddrl_sac1_get_weights(ddrl_sac1_t *h, float *flat_main_d, void *stream);
+/* Raw state pointers (device) for tests/checkpoint: main, target, adam m, adam v (each
+ * n_pi+2*n_q floats) and the two Adam step counters (host). */
+int ddrl_sac1_state(ddrl_sac1_t *h, float **main_d, float **target_d, float **adam_m_d,
+                    float **adam_v_d, int64_t *t_pi_h, int64_t *t_q_h);
+
+/* Learner.train(batch) == sess.run(step_ops) (actor_learner.py:58-101,135-142): forward of main
+ * and target nets, pi_loss / q1_loss / q2_loss from the PRE-update parameters, Adam(pi) then
+ * Adam(q1,q2) (TF1 formula, epsilon outside the sqrt, lr_t = lr*sqrt(1-b2^t)/(1-b1^t)), then
+ * polyak target update with the post-update main.  tf.random_normal (core.py:77) is replaced by
+ * explicit noise inputs eps_x_d (main policy at x), eps_x2_d (main policy at x2), eps_t_d
+ * (target policy at x2), each device float32[B,act].  losses_d: device float32[3]
+ * = (pi_loss, q1_loss, q2_loss) (step_ops[0:3], actor_learner.py:97).  Optional per-row outputs
+ * (may be NULL): q1_d[B], q2_d[B], logp_pi_d[B]  (step_ops[3:6]). */
+int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d,
+                   const float *rews_d, const float *done_d, const float *eps_x_d,
+                   const float *eps_x2_d, const float *eps_t_d, float *losses_d, float *q1_d,
+                   float *q2_d, float *logp_pi_d, void *stream);
+
+/* Gradients of the last step (device, flat layout as the parameters) — for parity tests and for
+ * the multi-learner all-reduce.  Valid until the next step. */
+int ddrl_sac1_grads(ddrl_sac1_t *h, float **grad_d, int64_t *count);
+/* Two-phase form of ddrl_sac1_step for data-parallel learners: (1) forward+backward only,
+ * gradients left in the grad buffer; (2) Adam(pi), Adam(q), polyak using the (possibly
+ * all-reduced) grad buffer.  step == grads followed by apply. */
+int ddrl_sac1_compute_grads(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d,
+                            const float *acts_d, const float *rews_d, const float *done_d,
+                            const float *eps_x_d, const float *eps_x2_d, const float *eps_t_d,
+                            float *losses_d, float *q1_d, float *q2_d, float *logp_pi_d,
+                            void *stream);
+int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream);
+
+/* ===================================================================================== */
+/* Batched policy forward — replaces Actor.get_action (actor_learner.py:195-197) called    */
+/* once per env step in worker_rollout (example/dsac.py:96-97)                             */
+/* ===================================================================================== */
+typedef struct ddrl_actor ddrl_actor_t;
+
+int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *cfg, int64_t max_rows);
+int ddrl_actor_destroy(ddrl_actor_t *h);
+/* Actor.set_weights (actor_learner.py:186-187): the n_pi floats of the main/pi variables (device). */
+int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream);
+int ddrl_actor_params(ddrl_actor_t *h, float **flat_pi_d, int64_t *n_pi);
+/* get_action for n observations: act = tanh(mu + eps*exp(log_std))*act_scale, or
+ * tanh(mu)*act_scale when deterministic (core.py:49-87,104-106).  obs_d[n,obs], eps_d[n,act]
+ * (ignored when deterministic; may be NULL then), act_d[n,act].  n <= max_rows. */
+int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int64_t n,
+                   int deterministic, float *act_d, void *stream);
+
+/* ===================================================================================== */
+/* Batched lander environment — stands where gym's LunarLanderContinuous-v2 env.step /     */
+/* env.reset are called (example/dsac.py:78-79,102,127).  gym/Box2D are third-party and    */
+/* absent; the dynamics are this build's own Box2D-style rigid-body model, */
+/* validated against oracle/env_oracle.py, not against Box2D ("parity unpinned").          */
+/* ===================================================================================== */
+typedef struct ddrl_env ddrl_env_t;
+
+int ddrl_env_create(ddrl_env_t **out, int device, int64_t n_envs, uint32_t seed, int32_t max_ep_len);
+int ddrl_env_destroy(ddrl_env_t *h);
+/* env.reset() for every env (mask_d == NULL) or for envs with mask_d[i] != 0 (device uint8[n]).
+ * obs_d[n,8] receives the current observation of every env. */
+int ddrl_env_reset(ddrl_env_t *h, const uint8_t *mask_d, float *obs_d, void *stream);
+/* One env.step(a) per env followed by the reference's episode bookkeeping
+ * (example/dsac.py:102-127): outputs the transition as it is stored —
+ *   obs2_d[n,8]  next observation o2,
+ *   rew_d[n]     reward,
+ *   done_d[n]    d with the time-limit override "d = False if ep_len == max_ep_len" (dsac.py:109),
+ * then resets every env whose episode ended (d or ep_len == max_ep_len) and writes
+ *   next_obs_d[n,8]  the observation to act on next (o2, or the reset observation),
+ *   ended_d[n]       (uint8, may be NULL) 1 where an episode ended this step.
+ * act_d[n,2] device float32. */
+int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d, float *done_d,
+                  float *next_obs_d, uint8_t *ended_d, void *stream);
+/* Episode statistics accumulated on device since the last call: number of finished episodes,
+ * sum of their returns and lengths.  Synchronises `stream`; resets the accumulators. Host outs. */
+int ddrl_env_stats(ddrl_env_t *h, int64_t *episodes_h, double *ret_sum_h, int64_t *len_sum_h,
+                   void *stream);
+/* Raw state access for parity tests: copies the [DDRL_ENV_STATE_FIELDS, n] float32 state block
+ * to / from a device buffer. */
+#define DDRL_ENV_STATE_FIELDS 32
+int ddrl_env_get_state(ddrl_env_t *h, float *state_d, void *stream);
+int ddrl_env_set_state(ddrl_env_t *h, const float *state_d, void *stream);
+
+/* ===================================================================================== */
+/* Counter-based noise (stands in for tf.random_normal, core.py:77, and                    */
+/* env.action_space.sample(), example/dsac.py:99) — same generator as oracle/noise_oracle  */
+/* ===================================================================================== */
+/* out_d[i] = N(0,1) (Box–Muller over hash(seed, counter+i)); uniform: lo + (hi-lo)*U[0,1). */
+int ddrl_normal_fill(float *out_d, int64_t n, uint32_t seed, uint64_t counter, void *stream);
+int ddrl_uniform_fill(float *out_d, int64_t n, float lo, float hi, uint32_t seed, uint64_t counter,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDRL_H */
