@@ -17,18 +17,19 @@ DDRL_ERR_NOMEM = -4
 DDRL_ERR_UNSUPPORTED = -5
 DDRL_REPLAY_ACTS_1D = 1
 DDRL_ENV_STATE_FIELDS = 32
+SAC1_MAIN, SAC1_TARGET, SAC1_ADAM_M, SAC1_ADAM_V, SAC1_GRAD = range(5)
 
 
 class Sac1Config(ctypes.Structure):
     """ddrl_sac1_config_t; defaults = algos/sac1/hyperparams.py + core.py:91 at LunarLander dims."""
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("hidden1", c_int32), ("hidden2", c_int32),
-                ("batch", c_int32), ("alpha", c_float), ("gamma", c_float), ("lr", c_float),
-                ("polyak", c_float), ("beta1", c_float), ("beta2", c_float), ("adam_eps", c_float),
-                ("act_scale", c_float)]
+                ("batch", c_int32), ("reserved", c_int32), ("alpha", c_double), ("gamma", c_double),
+                ("lr", c_double), ("polyak", c_double), ("beta1", c_double), ("beta2", c_double),
+                ("adam_eps", c_double), ("act_scale", c_double)]
 
     def __init__(self, obs_dim=8, act_dim=2, hidden1=400, hidden2=300, batch=256, alpha=0.1, gamma=0.997,
                  lr=5e-5, polyak=0.995, beta1=0.9, beta2=0.999, adam_eps=1e-8, act_scale=1.0):
-        super().__init__(obs_dim, act_dim, hidden1, hidden2, batch, alpha, gamma, lr, polyak, beta1, beta2,
+        super().__init__(obs_dim, act_dim, hidden1, hidden2, batch, 0, alpha, gamma, lr, polyak, beta1, beta2,
                          adam_eps, act_scale)
 
 
@@ -61,16 +62,16 @@ SIGNATURES = {
     "ddrl_sac1_destroy": (c_int, [_P]),
     "ddrl_sac1_set_weights": (c_int, [_P, _P, _P]),
     "ddrl_sac1_get_weights": (c_int, [_P, _P, _P]),
-    "ddrl_sac1_state": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_int64),
-                                POINTER(c_int64)]),
+    "ddrl_sac1_export": (c_int, [_P, c_int, _P, _P]),
+    "ddrl_sac1_import": (c_int, [_P, c_int, _P, _P]),
+    "ddrl_sac1_opt_steps": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), _P]),
     "ddrl_sac1_step": (c_int, [_P] + [_P] * 12 + [_P]),
-    "ddrl_sac1_grads": (c_int, [_P, POINTER(_P), POINTER(c_int64)]),
     "ddrl_sac1_compute_grads": (c_int, [_P] + [_P] * 12 + [_P]),
     "ddrl_sac1_apply_grads": (c_int, [_P, _P]),
     "ddrl_actor_create": (c_int, [POINTER(_P), c_int, POINTER(Sac1Config), c_int64]),
     "ddrl_actor_destroy": (c_int, [_P]),
     "ddrl_actor_set_weights": (c_int, [_P, _P, _P]),
-    "ddrl_actor_params": (c_int, [_P, POINTER(_P), POINTER(c_int64)]),
+    "ddrl_actor_get_weights": (c_int, [_P, _P, _P]),
     "ddrl_actor_act": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P]),
     "ddrl_env_create": (c_int, [POINTER(_P), c_int, c_int64, c_uint32, c_int32]),
     "ddrl_env_destroy": (c_int, [_P]),

@@ -1,0 +1,279 @@
+"""SAC1 agent classes with the reference's surface, backed by the HIP learner/actor kernels.
+
+Mirrors (same names, argument meaning):
+  algos/sac1/actor_learner.py:19-148   class Learner(opt, job): set_weights / get_weights / train
+  algos/sac1/actor_learner.py:151-229  class Actor(opt, job):   set_weights / get_weights / get_action / test
+  algos/sac1/hyperparams.py:10-104     class HyperParameters    (values; scalar obs_dim / act_dim,
+                                        SURVEY §2.4 decision: alpha fixed at 0.1, action scale = high[0])
+
+`get_weights()` returns `(keys, values)` restricted to names containing "main", keys being the TF1
+variable names of the reference graph; `set_weights(keys, values)` accepts any subset.
+tf.random_normal (core.py:77) is replaced by explicit noise: `train(batch, eps=...)` /
+`get_action(o, eps=...)`; when omitted it is drawn on the device from the counter-based generator
+(`ddrl_normal_fill`) seeded with `opt.seed`.
+"""
+import ctypes
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def param_specs(obs_dim, act_dim, hidden1, hidden2, nets=("pi", "q1", "q2")):
+    """(name, shape) in TF variable-creation order (core.py:91-121)."""
+    o, a, h1, h2 = obs_dim, act_dim, hidden1, hidden2
+    specs = []
+    if "pi" in nets:
+        specs += [("main/pi/dense/kernel", (o, h1)), ("main/pi/dense/bias", (h1,)),
+                  ("main/pi/dense_1/kernel", (h1, h2)), ("main/pi/dense_1/bias", (h2,)),
+                  ("main/pi/dense_2/kernel", (h2, a)), ("main/pi/dense_2/bias", (a,)),
+                  ("main/pi/dense_3/kernel", (h2, a)), ("main/pi/dense_3/bias", (a,))]
+    for q in ("q1", "q2"):
+        if q in nets:
+            specs += [("main/%s/dense/kernel" % q, (o + a, h1)), ("main/%s/dense/bias" % q, (h1,)),
+                      ("main/%s/dense_1/kernel" % q, (h1, h2)), ("main/%s/dense_1/bias" % q, (h2,)),
+                      ("main/%s/dense_2/kernel" % q, (h2, 1)), ("main/%s/dense_2/bias" % q, (1,))]
+    return specs
+
+
+def glorot_init(specs, seed):
+    """tf.layers.dense defaults: glorot-uniform kernels, zero biases; one flat float32 vector."""
+    rs = np.random.RandomState(seed)
+    parts = []
+    for name, shape in specs:
+        if name.endswith("kernel"):
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+            parts.append(rs.uniform(-lim, lim, size=shape).astype(np.float32).reshape(-1))
+        else:
+            parts.append(np.zeros(int(np.prod(shape)), np.float32))
+    return np.concatenate(parts)
+
+
+class HyperParameters:
+    """Value bag of algos/sac1/hyperparams.py:10-104 (the entries the hot path reads)."""
+
+    def __init__(self, env_name="LunarLanderContinuous-v2", exp_name="sac1", num_workers=1, a_l_ratio=2,
+                 weights_file="", obs_dim=8, act_dim=2, act_scale=1.0):
+        self.exp_name, self.env_name = exp_name, env_name
+        self.a_l_ratio = a_l_ratio
+        self.weights_file = weights_file
+        self.start_steps = int(5e4) if not weights_file else int(10e6)
+        self.obs_dim, self.act_dim, self.act_scale = obs_dim, act_dim, act_scale
+        self.hidden_sizes = (400, 300)  # core.py:91
+        self.num_workers, self.num_learners = num_workers, 1
+        self.alpha = 0.1
+        self.gamma = 0.997
+        self.num_buffers = self.num_workers // 25 + 1
+        self.buffer_size = int(3e6) // self.num_buffers
+        self.lr = 5e-5
+        self.polyak = 0.995
+        self.steps_per_epoch = 5000
+        self.batch_size = 256
+        self.max_ep_len = 2900
+        self.seed = 0
+        self.push_freq = 300  # sac1.py:149
+        self.num_envs = 1     # vectorised rollouts: envs stepped together by one worker
+
+    def config(self, batch=None):
+        return _lib.Sac1Config(obs_dim=self.obs_dim, act_dim=self.act_dim, hidden1=self.hidden_sizes[0],
+                               hidden2=self.hidden_sizes[1], batch=self.batch_size if batch is None else batch,
+                               alpha=self.alpha, gamma=self.gamma, lr=self.lr, polyak=self.polyak,
+                               act_scale=self.act_scale)
+
+
+class _Net:
+    def _setup(self, opt, nets):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self.opt = opt
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.specs = param_specs(opt.obs_dim, opt.act_dim, opt.hidden_sizes[0], opt.hidden_sizes[1], nets)
+        self.keys = [n for n, _ in self.specs]
+        off = 0
+        self.table = {}
+        for n, s in self.specs:
+            cnt = int(np.prod(s))
+            self.table[n] = (off, cnt, s)
+            off += cnt
+        self.n_params = off
+        self._noise_seed = int(getattr(opt, "seed", 0)) & 0xFFFFFFFF
+        self._noise_ctr = 0
+
+    def _flat_get(self):
+        raise NotImplementedError
+
+    def _flat_set(self, flat):
+        raise NotImplementedError
+
+    def get_weights_flat(self):
+        """The whole "main" vector as ONE device tensor (what ps.push_flat / RCCL broadcast move)."""
+        return self._flat_get()
+
+    def set_weights_flat(self, flat):
+        self._flat_set(flat.to(device=self.device, dtype=torch.float32).contiguous())
+
+    def get_weights(self):
+        flat = self._flat_get().cpu().numpy()
+        values = [flat[o:o + n].reshape(s).copy() for (o, n, s) in (self.table[k] for k in self.keys)]
+        return list(self.keys), values
+
+    def set_weights(self, variable_names, weights):
+        if list(variable_names) == self.keys:
+            flat = np.concatenate([np.asarray(w, np.float32).reshape(-1) if not torch.is_tensor(w)
+                                   else w.detach().float().cpu().numpy().reshape(-1) for w in weights])
+            self._flat_set(torch.from_numpy(flat).to(self.device))
+            return
+        flat = self._flat_get()
+        for k, w in zip(variable_names, weights):
+            if k not in self.table:
+                continue  # the reference's TensorFlowVariables ignores names it does not hold
+            o, n, _ = self.table[k]
+            w = w if torch.is_tensor(w) else torch.from_numpy(np.asarray(w, np.float32))
+            flat[o:o + n] = w.to(self.device).reshape(-1)
+        self._flat_set(flat)
+
+    def _normal(self, n):
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_normal_fill(_lib.dptr(out), n, self._noise_seed, self._noise_ctr, _lib.stream_ptr()))
+        self._noise_ctr += n
+        return out
+
+    def _dev(self, x, shape=None):
+        t = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        return t if shape is None else t.reshape(shape)
+
+
+class Learner(_Net):
+    """algos/sac1/actor_learner.py:19-148."""
+
+    def __init__(self, opt, job="learner"):
+        self._setup(opt, ("pi", "q1", "q2"))
+        self.cfg = opt.config()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ddrl_sac1_create(ctypes.byref(h), self.device.index, ctypes.byref(self.cfg)))
+        self._h = h
+        self.losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        # tf.global_variables_initializer with tf.set_random_seed(opt.seed): glorot / zeros
+        self._flat_set(torch.from_numpy(glorot_init(self.specs, opt.seed)).to(self.device))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_sac1_destroy(h)
+
+    def _flat_get(self):
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_sac1_get_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
+        return flat
+
+    def _flat_set(self, flat):
+        # set_weights + target_init (actor_learner.py:125-127)
+        _lib.check(self._lib.ddrl_sac1_set_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
+
+    def export(self, which):
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_sac1_export(self._h, which, _lib.dptr(flat), _lib.stream_ptr()))
+        return flat
+
+    def import_(self, which, flat):
+        flat = flat.to(device=self.device, dtype=torch.float32).contiguous()
+        _lib.check(self._lib.ddrl_sac1_import(self._h, which, _lib.dptr(flat), _lib.stream_ptr()))
+
+    def opt_steps(self):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._lib.ddrl_sac1_opt_steps(self._h, ctypes.byref(a), ctypes.byref(b), _lib.stream_ptr()))
+        return int(a.value), int(b.value)
+
+    def _args(self, batch, eps, outs):
+        B, a = self.cfg.batch, self.cfg.act_dim
+        x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))
+        ac, r, d = self._dev(batch["acts"], (B, a)), self._dev(batch["rews"], (B,)), self._dev(batch["done"], (B,))
+        if eps is None:
+            e = self._normal(3 * B * a).view(3, B, a)
+            eps = (e[0], e[1], e[2])
+        eps = [self._dev(e, (B, a)) for e in eps]
+        keep = (x, x2, ac, r, d, *eps)
+        q1 = q2 = lp = None
+        if outs:
+            q1, q2, lp = (torch.empty(B, dtype=torch.float32, device=self.device) for _ in range(3))
+        ptrs = [_lib.dptr(t) for t in keep] + [_lib.dptr(self.losses), _lib.dptr(q1), _lib.dptr(q2), _lib.dptr(lp)]
+        return keep, ptrs, (q1, q2, lp)
+
+    def train(self, batch, eps=None, return_outputs=False):
+        """One sess.run(step_ops) (actor_learner.py:135-142).  `batch` holds obs1/obs2/acts/rews/done
+        as NumPy arrays (the reference's feed) or device tensors (no host round trip)."""
+        keep, ptrs, outs = self._args(batch, eps, return_outputs)
+        _lib.check(self._lib.ddrl_sac1_step(self._h, *ptrs, _lib.stream_ptr()))
+        if return_outputs:
+            return self.losses, outs
+        return None  # the reference drops the fetched values (actor_learner.py:142)
+
+    def compute_gradients(self, batch, eps=None):
+        """Forward + backward only (the stubbed compute_gradients of actor_learner.py:144-145)."""
+        keep, ptrs, _ = self._args(batch, eps, False)
+        _lib.check(self._lib.ddrl_sac1_compute_grads(self._h, *ptrs, _lib.stream_ptr()))
+        return self.export(_lib.SAC1_GRAD)
+
+    def apply_gradients(self, gradients=None):
+        """Adam(pi), Adam(q), polyak with `gradients` (flat) or the buffer of the last compute."""
+        if gradients is not None:
+            self.import_(_lib.SAC1_GRAD, gradients)
+        _lib.check(self._lib.ddrl_sac1_apply_grads(self._h, _lib.stream_ptr()))
+
+
+class Actor(_Net):
+    """algos/sac1/actor_learner.py:151-229 (policy-only graph)."""
+
+    def __init__(self, opt, job="worker", max_rows=None):
+        self._setup(opt, ("pi",))
+        self.cfg = opt.config()
+        self.max_rows = int(max_rows if max_rows is not None else max(1, getattr(opt, "num_envs", 1)))
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ddrl_actor_create(ctypes.byref(h), self.device.index, ctypes.byref(self.cfg), self.max_rows))
+        self._h = h
+        self.job = job
+        self._flat_set(torch.from_numpy(glorot_init(self.specs, opt.seed)).to(self.device))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_actor_destroy(h)
+
+    def _flat_get(self):
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_actor_get_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
+        return flat
+
+    def _flat_set(self, flat):
+        _lib.check(self._lib.ddrl_actor_set_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
+
+    def get_actions(self, obs, deterministic=False, eps=None, out=None):
+        """Batched get_action on device tensors: obs[n, obs_dim] -> act[n, act_dim]."""
+        obs = self._dev(obs, (-1, self.cfg.obs_dim))
+        n, a = obs.shape[0], self.cfg.act_dim
+        if not deterministic:
+            eps = self._normal(n * a).view(n, a) if eps is None else self._dev(eps, (n, a))
+        act = out if out is not None else torch.empty(n, a, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_actor_act(self._h, _lib.dptr(obs), _lib.dptr(eps if not deterministic else None), n,
+                                            1 if deterministic else 0, _lib.dptr(act), _lib.stream_ptr()))
+        return act
+
+    def get_action(self, o, deterministic=False, eps=None):
+        """actor_learner.py:195-197: one observation in, one action (NumPy) out."""
+        return self.get_actions(np.asarray(o, np.float32).reshape(1, -1), deterministic, eps)[0].cpu().numpy()
+
+    def test(self, test_env, replay_buffer=None, n=25):
+        """Deterministic evaluation episodes (actor_learner.py:199-218); returns the mean return."""
+        rew = []
+        for _ in range(n):
+            o, r, d, ep_ret, ep_len = test_env.reset(), 0, False, 0, 0
+            while not (d or (ep_len == self.opt.max_ep_len)):
+                o, r, d, _ = test_env.step(self.get_action(o, True))
+                ep_ret += r
+                ep_len += 1
+            rew.append(ep_ret)
+        return sum(rew) / n

@@ -1,0 +1,1078 @@
+// SAC1 learner update and batched policy forward on gfx950.
+// Replaces Learner / Actor of algos/sac1/actor_learner.py:19-229 with the network of
+// algos/sac1/core.py:91-121 (policy 8->400->300->(2,2), twin Q 10->400->300->1, ReLU).
+//
+// One update = 8 network evaluations (policy main@x, main@x2, target@x2; Q1,Q2 main@(x,a);
+// Q1 main@(x,pi); Q1,Q2 target@(x2,pi_targ)), backward of pi_loss through Q1 and of value_loss,
+// two TF1-Adam steps and the polyak update.  The dense fc work (hidden1 x hidden2 layers,
+// forward / dgrad / wgrad) runs on the f32-input MFMA v_mfma_f32_32x32x2_f32, which is bit-exact
+// f32 FMA arithmetic (no bf16: the 1e-5 loss parity forbids it); everything else is row-local
+// VALU work with wavefront-shuffle reductions.  All stages of one update are launched
+// back-to-back on one stream with no host synchronisation and no host-side state, so a whole
+// update (or many) can be captured in a hipGraph.
+//
+// Numerics kept from the reference formulae (fp contraction is OFF for this file; FMAs are
+// explicit): the only re-arrangement is z = eps*std/(std+EPS) for (pi-mu)/(std+EPS)
+// (core.py:31 with pi = mu + eps*std, core.py:76-77) — algebraically identical, but free of the
+// catastrophic cancellation that makes the literal float32 form noisy at the 1e-5 level
+// (DESIGN.md §numerics).
+#include "ddrl_common.h"
+
+#include <vector>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int MAXA = 8;        // act_dim supported by the row kernels
+constexpr int NEVAL = 8;       // network evaluations per update
+constexpr int SW_MAXK = 12;    // max "scale" columns of a small-wgrad job (obs+act+1 <= 12 at LunarLander dims)
+constexpr float LOG2PI = 1.8378770664093453f;  // float32(np.log(2*np.pi))
+constexpr float STD_EPS = 1e-8f;               // core.py:5 EPS
+
+// ------------------------------------------------------------------------------------------
+// job descriptors
+// ------------------------------------------------------------------------------------------
+struct GemmJob {
+    const float *A, *B;
+    float *C;
+    const float *bias;  // forward: C = relu(A*B + bias)
+    const float *mask;  // dgrad:   C = (A*B) where mask > 0 else 0   (mask laid out like C)
+    int M, N, K, lda, ldb, ldc;
+    int a_kc;  // 1: A(i,k) = A[i*lda + k]   0: A(i,k) = A[k*lda + i]
+    int b_kc;  // 1: B(k,j) = B[j*ldb + k]   0: B(k,j) = B[k*ldb + j]
+    int relu;
+    int tiles_n, tile_start, ntiles;
+};
+constexpr int MAX_GEMM_JOBS = 8;
+struct GemmJobs {
+    int njobs, total_tiles;
+    GemmJob job[MAX_GEMM_JOBS];
+};
+
+struct L1Job {  // H1 = relu([in0 | in1] * W1 + b1)
+    const float *in0, *in1, *W, *b;
+    float *out;
+    int d0, d1, rows, h1;
+};
+constexpr int MAX_L1_JOBS = 5;
+struct L1Jobs {
+    int njobs;
+    L1Job job[MAX_L1_JOBS];
+};
+
+struct SwJob {  // out_k[j*ostride_k] = sum_r S_k[r] * M[r*ldm + j];   S_k == nullptr means ones
+    const float *M;
+    int ldm, ncols, rows, nk;
+    const float *sptr[SW_MAXK];
+    int sstride[SW_MAXK];
+    float *optr[SW_MAXK];
+    int ostride[SW_MAXK];
+    int block_start, nblocks;
+};
+
+struct Seg {  // one tensor: dense external offset <-> padded internal offset
+    long long ext, in, n;
+};
+
+struct OptState {  // device-resident Adam bookkeeping (running beta powers like TF's beta*_power)
+    float b1p_pi, b2p_pi, b1p_q, b2p_q;
+    long long t_pi, t_q;
+    unsigned int ticket_adam, pad;
+};
+
+// ------------------------------------------------------------------------------------------
+// K: layer 1 (K = obs_dim or obs_dim+act_dim: tiny) — VALU, threads along the output feature
+// ------------------------------------------------------------------------------------------
+constexpr int L1_ROWS = 16;
+__global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
+    const L1Job &jb = jobs.job[blockIdx.z];
+    __shared__ float s_in[L1_ROWS][40];
+    const int din = jb.d0 + jb.d1;
+    const int r0 = blockIdx.y * L1_ROWS;
+    if (r0 >= jb.rows) return;
+    for (int e = threadIdx.x; e < L1_ROWS * din; e += 256) {
+        const int rr = e / din, k = e - rr * din;
+        const int r = r0 + rr;
+        float v = 0.f;
+        if (r < jb.rows) v = (k < jb.d0) ? jb.in0[(long long)r * jb.d0 + k] : jb.in1[(long long)r * jb.d1 + (k - jb.d0)];
+        s_in[rr][k] = v;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= jb.h1) return;
+    float acc[L1_ROWS];
+    const float bj = jb.b[j];
+#pragma unroll
+    for (int rr = 0; rr < L1_ROWS; ++rr) acc[rr] = 0.f;
+    for (int k = 0; k < din; ++k) {
+        const float w = jb.W[(long long)k * jb.h1 + j];
+#pragma unroll
+        for (int rr = 0; rr < L1_ROWS; ++rr) acc[rr] = fmaf(s_in[rr][k], w, acc[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < L1_ROWS; ++rr) {
+        const int r = r0 + rr;
+        if (r < jb.rows) jb.out[(long long)r * jb.h1 + j] = fmaxf(acc[rr] + bj, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K: batched small GEMM on v_mfma_f32_32x32x2_f32.
+// One workgroup = one 32x32 output tile; its 4 waves split K four ways (in-workgroup split-K:
+// at M = batch = 256 a stage has only ~80-130 tiles per network, so K is what fills the 1024
+// SIMDs), each wave streams its operands straight from L2 into registers (nothing is shared
+// between waves, so LDS staging would only add a round trip), and the four partial tiles are
+// combined through LDS in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------
+constexpr int G_IT = 26;  // 4 k per iteration and lane-half -> up to 104 k per wave pass
+
+__device__ __forceinline__ void ld_pair(const float *__restrict__ base, int kc, int idx, int nidx, int ld, int k, int kend,
+                                        float &x, float &y) {
+    x = 0.f; y = 0.f;
+    if (idx < nidx && k < kend) {
+        if (kc) {
+            const float *p = base + (long long)idx * ld + k;
+            if (k + 1 < kend) {
+                if ((((uintptr_t)p) & 7) == 0) { const float2 v = *reinterpret_cast<const float2 *>(p); x = v.x; y = v.y; }
+                else { x = p[0]; y = p[1]; }
+            } else x = p[0];
+        } else {
+            x = base[(long long)k * ld + idx];
+            if (k + 1 < kend) y = base[(long long)(k + 1) * ld + idx];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
+    __shared__ float red[4][32][33];
+    int t = blockIdx.x, ji = 0;
+#pragma unroll 1
+    while (ji + 1 < jobs.njobs && t >= jobs.job[ji + 1].tile_start) ++ji;
+    const GemmJob &jb = jobs.job[ji];
+    t -= jb.tile_start;
+    const int m0 = (t / jb.tiles_n) * 32, n0 = (t % jb.tiles_n) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int K = jb.K;
+    const int chunk = ((K + 15) >> 4) << 2;
+    const int k0 = w * chunk;
+    const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ai = m0 + l31, bj = n0 + l31;
+    for (int kb = k0; kb < k1; kb += 4 * G_IT) {
+        float ax[G_IT], ay[G_IT], bx[G_IT], by[G_IT];
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            const int k = kb + 4 * it + 2 * h;
+            ld_pair(jb.A, jb.a_kc, ai, jb.M, jb.lda, k, k1, ax[it], ay[it]);
+            ld_pair(jb.B, jb.b_kc, bj, jb.N, jb.ldb, k, k1, bx[it], by[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            if (kb + 4 * it < k1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[it], bx[it], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[it], by[it], acc, 0, 0, 0);
+            }
+        }
+    }
+    // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int row = o >> 5, col = o & 31;
+        const int gi = m0 + row, gj = n0 + col;
+        if (gi < jb.M && gj < jb.N) {
+            float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+            if (jb.bias) v += jb.bias[gj];
+            if (jb.relu) v = fmaxf(v, 0.f);
+            if (jb.mask) v = (jb.mask[(long long)gi * jb.ldc + gj] > 0.f) ? v : 0.f;
+            jb.C[(long long)gi * jb.ldc + gj] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct NetPi { const float *W1, *b1, *W2, *b2, *Wmu, *bmu, *Wls, *bls; };
+struct NetQ { const float *W1, *b1, *W2, *b2, *W3, *b3; };
+
+struct Consts {
+    float alpha, gamma, scale, inv_b;
+};
+
+// One policy head for one row held by one wave: returns (valid in lanes c < act) the per-dim
+// quantities; all lanes get logp.  core.py:49-87,104-106.
+struct HeadOut { float act, a, std, t, logp; };
+__device__ __forceinline__ HeadOut policy_head(const float *__restrict__ h2row, int h2, int act, const NetPi &p,
+                                               const float *__restrict__ eps_row, float scale, int lane, bool deterministic) {
+    float part[2 * MAXA];
+#pragma unroll
+    for (int c = 0; c < 2 * MAXA; ++c) part[c] = 0.f;
+    for (int j = lane; j < h2; j += 64) {
+        const float hv = h2row[j];
+#pragma unroll
+        for (int c = 0; c < MAXA; ++c)
+            if (c < act) {
+                part[c] = fmaf(hv, p.Wmu[j * act + c], part[c]);
+                part[MAXA + c] = fmaf(hv, p.Wls[j * act + c], part[MAXA + c]);
+            }
+    }
+    float mu = 0.f, lsr = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXA; ++c)
+        if (c < act) {
+            const float s0 = wave_sum(part[c]), s1 = wave_sum(part[MAXA + c]);
+            if (lane == c) { mu = s0 + p.bmu[c]; lsr = s1 + p.bls[c]; }
+        }
+    HeadOut o;
+    o.act = 0.f; o.a = 0.f; o.std = 0.f; o.t = 0.f;
+    float pre = 0.f, corr = 0.f;
+    if (lane < act) {
+        const float t = tanhf(lsr);
+        const float log_std = -20.0f + 11.0f * (t + 1.0f);  // LOG_STD_MIN + 0.5*(MAX-MIN)*(ls+1), core.py:73-74
+        const float std = expf(log_std);
+        const float e = deterministic ? 0.f : eps_row[lane];
+        const float u = mu + e * std;                          // core.py:76-77
+        const float z = (e * std) / (std + STD_EPS);           // == (pi - mu)/(std + EPS), core.py:31
+        pre = -0.5f * ((z * z + 2.0f * log_std) + LOG2PI);
+        const float a = tanhf(u);                              // core.py:83-84
+        const float om = 1.0f - a * a;
+        const float cl = fminf(fmaxf(om, 0.f), 1.f);           // clip_but_pass_gradient value, core.py:35-38,86
+        corr = logf(cl + 1e-6f);
+        o.act = a * scale; o.a = a; o.std = std; o.t = t;
+    }
+    float sp = 0.f, sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXA; ++c)
+        if (c < act) { sp += __shfl(pre, c); sc += __shfl(corr, c); }
+    o.logp = sp - sc;
+    return o;
+}
+
+__device__ __forceinline__ float row_dot(const float *__restrict__ a, const float *__restrict__ b, int n, int lane) {
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s = fmaf(a[j], b[j], s);
+    return wave_sum(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// K: heads, stage A — one wave per (row, eval in {pi@x, pi@x2, piT@x2, q1(x,a), q2(x,a)})
+// ------------------------------------------------------------------------------------------
+struct RowsA {
+    const float *H2;  // [NEVAL][B][h2]
+    NetPi pi_main, pi_targ;
+    NetQ q1, q2;
+    const float *e0, *e1, *e2;
+    float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o;
+    int B, h2, act;
+    float scale;
+};
+__global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= a.B * 5) return;
+    const int e = wid / a.B, r = wid - e * a.B;
+    const float *hrow = a.H2 + ((long long)e * a.B + r) * a.h2;
+    if (e < 3) {
+        const NetPi &p = (e == 2) ? a.pi_targ : a.pi_main;
+        const float *eps = (e == 0 ? a.e0 : (e == 1 ? a.e1 : a.e2)) + (long long)r * a.act;
+        const HeadOut o = policy_head(hrow, a.h2, a.act, p, eps, a.scale, lane, false);
+        if (e == 0) {
+            if (lane < a.act) {
+                a.act0[r * a.act + lane] = o.act;
+                float *s = a.save0 + ((long long)r * a.act + lane) * 4;
+                s[0] = o.a; s[1] = o.std; s[2] = o.t; s[3] = 0.f;
+            }
+            if (lane == 0) a.logp0[r] = o.logp;
+        } else if (e == 1) {
+            if (lane == 0) a.logp1[r] = o.logp;
+        } else if (lane < a.act) {
+            a.act2[r * a.act + lane] = o.act;
+        }
+    } else {
+        const NetQ &q = (e == 3) ? a.q1 : a.q2;
+        const float v = row_dot(hrow, q.W3, a.h2, lane) + q.b3[0];
+        if (lane == 0) (e == 3 ? a.q1o : a.q2o)[r] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K: heads, stage B — Q(x,pi), target Qs, backup, losses, dq and dZ2 of the three Q paths.
+// actor_learner.py:58-69.  One wave per row; deterministic block partials + last-block sum.
+// ------------------------------------------------------------------------------------------
+struct RowsB {
+    const float *H2;
+    NetQ q1, q2, q1t, q2t;
+    const float *rew, *done, *logp0, *logp1, *q1o, *q2o;
+    float *dZ2;  // [4][B][h2]  slots: 0 = q1(x,a), 1 = q2(x,a), 2 = q1(x,pi), 3 = pi
+    float *dq;   // [2][B]
+    float *loss_part;
+    int B, h2;
+    float alpha, gamma;
+};
+__global__ void __launch_bounds__(256) k_rows_b(RowsB a) {
+    __shared__ float s_part[4][3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    float lpi = 0.f, l1 = 0.f, l2 = 0.f;
+    if (r < a.B) {
+        const long long BH = (long long)a.B * a.h2;
+        const float *h3 = a.H2 + 3 * BH + (long long)r * a.h2, *h4 = a.H2 + 4 * BH + (long long)r * a.h2;
+        const float *h5 = a.H2 + 5 * BH + (long long)r * a.h2, *h6 = a.H2 + 6 * BH + (long long)r * a.h2;
+        const float *h7 = a.H2 + 7 * BH + (long long)r * a.h2;
+        const float q1pi = row_dot(h5, a.q1.W3, a.h2, lane) + a.q1.b3[0];
+        const float q1t = row_dot(h6, a.q1t.W3, a.h2, lane) + a.q1t.b3[0];
+        const float q2t = row_dot(h7, a.q2t.W3, a.h2, lane) + a.q2t.b3[0];
+        const float minq = fminf(q1t, q2t);                                   // actor_learner.py:59
+        const float vb = minq - a.alpha * a.logp1[r];                         // :62
+        const float backup = a.rew[r] + (a.gamma * (1.0f - a.done[r])) * vb;  // :63
+        const float e1 = backup - a.q1o[r], e2 = backup - a.q2o[r];
+        lpi = a.alpha * a.logp0[r] - q1pi;                                    // :66
+        l1 = e1 * e1; l2 = e2 * e2;                                           // :67-68
+        const float inv_b = 1.0f / (float)a.B;
+        const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b, dqp = -inv_b;
+        if (lane == 0) { a.dq[r] = dq1; a.dq[a.B + r] = dq2; }
+        float *z0 = a.dZ2 + (long long)r * a.h2, *z1 = z0 + BH, *z2 = z1 + BH;
+        for (int j = lane; j < a.h2; j += 64) {
+            const float w1 = a.q1.W3[j], w2 = a.q2.W3[j];
+            z0[j] = h3[j] > 0.f ? dq1 * w1 : 0.f;
+            z1[j] = h4[j] > 0.f ? dq2 * w2 : 0.f;
+            z2[j] = h5[j] > 0.f ? dqp * w1 : 0.f;
+        }
+    }
+    if (lane == 0) { s_part[wv][0] = lpi; s_part[wv][1] = l1; s_part[wv][2] = l2; }
+    __syncthreads();
+    // fixed-order block partials; the final sum over blocks is done by the next row kernel
+    // (k_rows_c), after the kernel boundary has made them visible — no in-kernel fence needed
+    if (threadIdx.x < 3)
+        a.loss_part[blockIdx.x * 3 + threadIdx.x] =
+            ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------
+// K: policy-head backward — d pi_loss / d (mu_raw, log_std_raw) and dZ2 of the policy trunk
+// ------------------------------------------------------------------------------------------
+struct RowsC {
+    const float *H2;    // eval 0 rows
+    const float *dZ1q;  // dZ1 of the q1(x,pi) path: [B][h1]
+    const float *W1q1;  // main q1 layer-1 kernel [(obs+act)][h1]
+    NetPi pi;
+    const float *e0, *save0;
+    float *dhead;  // [B][2*act]
+    float *dZ2pi;  // [B][h2]
+    const float *loss_part;  // [loss_blocks][3] from k_rows_b
+    float *losses;           // [3] pi_loss, q1_loss, q2_loss (actor_learner.py:66-68)
+    int B, h1, h2, obs, act, loss_blocks;
+    float alpha, scale;
+};
+__global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < 3) {  // reduce_mean over the batch, fixed order
+        float s = 0.f;
+        for (int b = 0; b < a.loss_blocks; ++b) s += a.loss_part[b * 3 + threadIdx.x];
+        const float mean = s / (float)a.B;
+        a.losses[threadIdx.x] = threadIdx.x == 0 ? mean : 0.5f * mean;
+    }
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.B) return;
+    const float *dz = a.dZ1q + (long long)r * a.h1;
+    float ga = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXA; ++c)
+        if (c < a.act) {
+            const float s = row_dot(dz, a.W1q1 + (long long)(a.obs + c) * a.h1, a.h1, lane);
+            if (lane == c) ga = s;
+        }
+    float dmu = 0.f, dls = 0.f;
+    if (lane < a.act) {
+        const float *s = a.save0 + ((long long)r * a.act + lane) * 4;
+        const float av = s[0], std = s[1], t = s[2];
+        const float e = a.e0[(long long)r * a.act + lane];
+        const float glp = a.alpha / (float)a.B;  // d pi_loss / d logp_pi
+        const float om = 1.0f - av * av;
+        const float cl = fminf(fmaxf(om, 0.f), 1.f);
+        const float du = (ga * a.scale) * om + glp * ((2.0f * av * om) / (cl + 1e-6f));
+        const float sd = std + STD_EPS;
+        const float z = (e * std) / sd;
+        const float dzdl = ((e * std) * STD_EPS) / (sd * sd);
+        const float dl = du * (e * std) + glp * (-(z * dzdl) - 1.0f);
+        dmu = du;
+        dls = dl * (11.0f * (1.0f - t * t));
+        a.dhead[(long long)r * 2 * a.act + lane] = dmu;
+        a.dhead[(long long)r * 2 * a.act + a.act + lane] = dls;
+    }
+    float gm[MAXA], gl[MAXA];
+#pragma unroll
+    for (int c = 0; c < MAXA; ++c) { gm[c] = __shfl(dmu, c); gl[c] = __shfl(dls, c); }
+    const float *hrow = a.H2 + (long long)r * a.h2;
+    float *out = a.dZ2pi + (long long)r * a.h2;
+    for (int j = lane; j < a.h2; j += 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXA; ++c)
+            if (c < a.act) {
+                v = fmaf(gm[c], a.pi.Wmu[j * a.act + c], v);
+                v = fmaf(gl[c], a.pi.Wls[j * a.act + c], v);
+            }
+        out[j] = hrow[j] > 0.f ? v : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K: small weight gradients (layer-1 kernels, all biases, head / W3 kernels): column sums
+//     out_k[j] = sum_r S_k[r] * M[r][j]
+// 64 columns x 4 row groups per workgroup, fixed-order LDS combine (deterministic).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_small_wgrad(const SwJob *__restrict__ jobs, int njobs) {
+    __shared__ float s_red[4][SW_MAXK][64];
+    int ji = 0;
+    while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block_start) ++ji;
+    const SwJob &jb = jobs[ji];
+    const int cb = blockIdx.x - jb.block_start;
+    const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = cb * 64 + cj;
+    const int per = (jb.rows + 3) >> 2;
+    const int ra = rg * per, rb = (ra + per < jb.rows) ? ra + per : jb.rows;
+    float acc[SW_MAXK];
+#pragma unroll
+    for (int k = 0; k < SW_MAXK; ++k) acc[k] = 0.f;
+    if (j < jb.ncols) {
+        for (int r = ra; r < rb; ++r) {
+            const float mv = jb.M[(long long)r * jb.ldm + j];
+#pragma unroll
+            for (int k = 0; k < SW_MAXK; ++k)
+                if (k < jb.nk) {
+                    const float sv = jb.sptr[k] ? jb.sptr[k][(long long)r * jb.sstride[k]] : 1.0f;
+                    acc[k] = fmaf(sv, mv, acc[k]);
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SW_MAXK; ++k) s_red[rg][k][cj] = acc[k];
+    __syncthreads();
+    if (rg == 0 && j < jb.ncols) {
+#pragma unroll
+        for (int k = 0; k < SW_MAXK; ++k)
+            if (k < jb.nk)
+                jb.optr[k][(long long)j * jb.ostride[k]] =
+                    ((s_red[0][k][cj] + s_red[1][k][cj]) + s_red[2][k][cj]) + s_red[3][k][cj];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K: Adam(pi) + Adam(q1,q2) + polyak, fused over the flat (padded) parameter buffer.
+// tf.train.AdamOptimizer's ApplyAdam update form; actor_learner.py:73-87.
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float *p, *t, *m, *v;
+    const float *g;
+    OptState *opt;
+    long long n, n_pi;
+    float lr, b1, b2, eps, pk, pk1;
+};
+__global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
+    const float one = 1.0f;
+    const float al_pi = a.lr * sqrtf(one - a.opt->b2p_pi) / (one - a.opt->b1p_pi);
+    const float al_q = a.lr * sqrtf(one - a.opt->b2p_q) / (one - a.opt->b1p_q);
+    const float omb1 = one - a.b1, omb2 = one - a.b2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const float g = a.g[i];
+        float m = a.m[i], v = a.v[i], p = a.p[i];
+        m = m + (g - m) * omb1;
+        v = v + (g * g - v) * omb2;
+        const float al = i < a.n_pi ? al_pi : al_q;
+        p = p - (m * al) / (sqrtf(v) + a.eps);
+        a.m[i] = m; a.v[i] = v; a.p[i] = p;
+        a.t[i] = a.pk * a.t[i] + a.pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = atomicAdd(&a.opt->ticket_adam, 1u);
+        if (tk == gridDim.x - 1) {  // every block has read the powers before taking its ticket
+            a.opt->b1p_pi *= a.b1; a.opt->b2p_pi *= a.b2; a.opt->b1p_q *= a.b1; a.opt->b2p_q *= a.b2;
+            a.opt->t_pi += 1; a.opt->t_q += 1;
+            a.opt->ticket_adam = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K: dense external layout <-> padded internal layout; staging of the caller's batch
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack(const Seg *__restrict__ segs, const float *__restrict__ src, float *__restrict__ dst,
+                                              float *__restrict__ dst2, int to_internal) {
+    const Seg s = segs[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.n; i += (long long)gridDim.x * 256) {
+        if (to_internal) {
+            const float v = src[s.ext + i];
+            dst[s.in + i] = v;
+            if (dst2) dst2[s.in + i] = v;
+        } else {
+            dst[s.ext + i] = src[s.in + i];
+        }
+    }
+}
+
+struct StageArgs {
+    const float *src[8];
+    float *dst[8];
+    int n[8];
+};
+__global__ void __launch_bounds__(256) k_stage(StageArgs a) {
+    const int w = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[w]; i += gridDim.x * 256) a.dst[w][i] = a.src[w][i];
+}
+
+__global__ void k_copy3(const float *a, const float *b, const float *c, float *oa, float *ob, float *oc, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        if (oa) oa[i] = a[i];
+        if (ob) ob[i] = b[i];
+        if (oc) oc[i] = c[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K: batched get_action — one wave per observation row (Actor.get_action, actor_learner.py:195-197)
+// ------------------------------------------------------------------------------------------
+struct ActArgs {
+    const float *H2;
+    NetPi pi;
+    const float *eps;
+    float *act_out;
+    int rows, h2, act, deterministic;
+    float scale;
+};
+__global__ void __launch_bounds__(256) k_rows_act(ActArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.rows) return;
+    const HeadOut o = policy_head(a.H2 + r * a.h2, a.h2, a.act, a.pi, a.eps ? a.eps + r * a.act : nullptr, a.scale, lane,
+                                  a.deterministic != 0);
+    if (lane < a.act) a.act_out[r * a.act + lane] = o.act;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: layout
+// ------------------------------------------------------------------------------------------
+static inline long long pad4(long long n) { return (n + 3) & ~3ll; }
+
+struct Layout {
+    // internal (padded) offsets
+    long long pi_W1, pi_b1, pi_W2, pi_b2, pi_Wmu, pi_bmu, pi_Wls, pi_bls;
+    long long q_W1[2], q_b1[2], q_W2[2], q_b2[2], q_W3[2], q_b3[2];
+    long long n_pi_int, total_int;
+    long long n_pi, n_q, total_ext;
+    std::vector<Seg> segs;  // 20 tensors in external order
+};
+
+static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only) {
+    Layout L;
+    const long long o = c.obs_dim, a = c.act_dim, h1 = c.hidden1, h2 = c.hidden2;
+    long long in = 0, ext = 0;
+    auto add = [&](long long &slot, long long n) {
+        slot = in;
+        L.segs.push_back(Seg{ext, in, n});
+        in += pad4(n);
+        ext += n;
+    };
+    add(L.pi_W1, o * h1); add(L.pi_b1, h1); add(L.pi_W2, h1 * h2); add(L.pi_b2, h2);
+    add(L.pi_Wmu, h2 * a); add(L.pi_bmu, a); add(L.pi_Wls, h2 * a); add(L.pi_bls, a);
+    L.n_pi_int = in;
+    L.n_pi = ext;
+    for (int q = 0; q < 2 && !pi_only; ++q) {
+        add(L.q_W1[q], (o + a) * h1); add(L.q_b1[q], h1); add(L.q_W2[q], h1 * h2); add(L.q_b2[q], h2);
+        add(L.q_W3[q], h2); add(L.q_b3[q], 1);
+    }
+    L.total_int = in;
+    L.total_ext = ext;
+    L.n_q = pi_only ? 0 : (ext - L.n_pi) / 2;
+    return L;
+}
+
+static NetPi net_pi(const float *base, const Layout &L) {
+    return NetPi{base + L.pi_W1, base + L.pi_b1, base + L.pi_W2, base + L.pi_b2,
+                 base + L.pi_Wmu, base + L.pi_bmu, base + L.pi_Wls, base + L.pi_bls};
+}
+static NetQ net_q(const float *base, const Layout &L, int q) {
+    return NetQ{base + L.q_W1[q], base + L.q_b1[q], base + L.q_W2[q], base + L.q_b2[q], base + L.q_W3[q], base + L.q_b3[q]};
+}
+
+static void gemm_add(GemmJobs &js, GemmJob j) {
+    j.tiles_n = (j.N + 31) / 32;
+    j.ntiles = ((j.M + 31) / 32) * j.tiles_n;
+    j.tile_start = js.total_tiles;
+    js.total_tiles += j.ntiles;
+    js.job[js.njobs++] = j;
+}
+static GemmJob gemm_fwd(const float *H1, const float *W2, const float *b2, float *H2, int rows, int h1, int h2) {
+    GemmJob j{};
+    j.A = H1; j.B = W2; j.C = H2; j.bias = b2; j.mask = nullptr;
+    j.M = rows; j.N = h2; j.K = h1; j.lda = h1; j.ldb = h2; j.ldc = h2; j.a_kc = 1; j.b_kc = 0; j.relu = 1;
+    return j;
+}
+static GemmJob gemm_dgrad(const float *dZ2, const float *W2, const float *H1mask, float *dZ1, int rows, int h1, int h2) {
+    GemmJob j{};  // dZ1 = (dZ2 * W2^T) .* (H1 > 0)
+    j.A = dZ2; j.B = W2; j.C = dZ1; j.bias = nullptr; j.mask = H1mask;
+    j.M = rows; j.N = h1; j.K = h2; j.lda = h2; j.ldb = h2; j.ldc = h1; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
+    return j;
+}
+static GemmJob gemm_wgrad(const float *H1, const float *dZ2, float *dW2, int rows, int h1, int h2) {
+    GemmJob j{};  // dW2 = H1^T * dZ2
+    j.A = H1; j.B = dZ2; j.C = dW2; j.bias = nullptr; j.mask = nullptr;
+    j.M = h1; j.N = h2; j.K = rows; j.lda = h1; j.ldb = h2; j.ldc = h2; j.a_kc = 0; j.b_kc = 0; j.relu = 0;
+    return j;
+}
+
+template <typename T>
+static hipError_t dev_alloc(T **p, size_t count) {
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T));
+    return e;
+}
+
+static int check_cfg(const ddrl_sac1_config_t *c) {
+    DDRL_REQUIRE(c != nullptr, "config is NULL");
+    DDRL_REQUIRE(c->obs_dim > 0 && c->act_dim > 0 && c->hidden1 > 0 && c->hidden2 > 0 && c->batch > 0, "dims must be positive");
+    DDRL_REQUIRE(c->act_dim <= MAXA, "act_dim > 8 unsupported");
+    DDRL_REQUIRE(c->obs_dim + c->act_dim + 1 <= SW_MAXK && c->obs_dim + c->act_dim <= 40, "obs_dim + act_dim too large for the layer-1 kernels (<= 11)");
+    return DDRL_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+struct ddrl_sac1 {
+    int device;
+    ddrl_sac1_config_t cfg;
+    Layout L;
+    float *main_p, *target_p, *m, *v, *grad;
+    float *x, *x2, *a, *r, *d, *e0, *e1, *e2;
+    float *H1, *H2, *dZ2, *dZ1;
+    float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o, *dq, *dhead, *loss_part, *losses;
+    OptState *opt;
+    Seg *segs_d;
+    SwJob *sw_d;
+    int sw_njobs, sw_blocks;
+    L1Jobs l1a, l1b;
+    GemmJobs g_fa, g_fb, g_bq, g_bpi;
+    RowsA ra;
+    RowsB rb;
+    RowsC rc;
+    AdamArgs ad;
+    int rows_b_blocks;
+};
+
+static int sac1_free(ddrl_sac1 *h) {
+    float **ps[] = {&h->main_p, &h->target_p, &h->m, &h->v, &h->grad, &h->x, &h->x2, &h->a, &h->r, &h->d,
+                    &h->e0, &h->e1, &h->e2, &h->H1, &h->H2, &h->dZ2, &h->dZ1, &h->act0, &h->act2, &h->logp0, &h->logp1,
+                    &h->save0, &h->q1o, &h->q2o, &h->dq, &h->dhead, &h->loss_part, &h->losses};
+    for (auto p : ps) (void)hipFree(*p);
+    (void)hipFree(h->opt); (void)hipFree(h->segs_d); (void)hipFree(h->sw_d);
+    delete h;
+    return DDRL_OK;
+}
+
+static int reset_opt(ddrl_sac1 *h, hipStream_t s) {
+    OptState o{};
+    o.b1p_pi = o.b1p_q = (float)h->cfg.beta1;
+    o.b2p_pi = o.b2p_q = (float)h->cfg.beta2;
+    DDRL_HIP_CHECK(hipMemcpyAsync(h->opt, &o, sizeof(o), hipMemcpyHostToDevice, s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    return DDRL_OK;
+}
+
+extern "C" {
+
+int ddrl_sac1_param_counts(const ddrl_sac1_config_t *cfg, int64_t *n_pi, int64_t *n_q) {
+    int rc = check_cfg(cfg);
+    if (rc != DDRL_OK) return rc;
+    Layout L = make_layout(*cfg, false);
+    if (n_pi) *n_pi = L.n_pi;
+    if (n_q) *n_q = L.n_q;
+    return DDRL_OK;
+}
+
+int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cfg) {
+    DDRL_REQUIRE(out != nullptr, "out is NULL");
+    int rc = check_cfg(cfg);
+    if (rc != DDRL_OK) return rc;
+    ddrl::DeviceGuard g(device);
+    if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
+    ddrl_sac1 *h = new ddrl_sac1();  // value-initialised: every pointer/job table starts zeroed
+    h->device = device;
+    h->cfg = *cfg;
+    h->L = make_layout(*cfg, false);
+    const Layout &L = h->L;
+    const int B = cfg->batch, o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
+    const size_t NT = (size_t)L.total_int;
+    hipError_t e = hipSuccess;
+#define ALLOC(ptr, cnt) if (e == hipSuccess) e = dev_alloc(&h->ptr, (size_t)(cnt))
+    ALLOC(main_p, NT); ALLOC(target_p, NT); ALLOC(m, NT); ALLOC(v, NT); ALLOC(grad, NT);
+    ALLOC(x, B * o); ALLOC(x2, B * o); ALLOC(a, B * a); ALLOC(r, B); ALLOC(d, B);
+    ALLOC(e0, B * a); ALLOC(e1, B * a); ALLOC(e2, B * a);
+    ALLOC(H1, (size_t)NEVAL * B * h1); ALLOC(H2, (size_t)NEVAL * B * h2);
+    ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1);
+    ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
+    ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(dq, 2 * B); ALLOC(dhead, (size_t)B * 2 * a);
+    h->rows_b_blocks = (B + 3) / 4;
+    ALLOC(loss_part, (size_t)h->rows_b_blocks * 3); ALLOC(losses, 4);
+    if (e == hipSuccess) e = dev_alloc(&h->opt, 1);
+    if (e == hipSuccess) e = dev_alloc(&h->segs_d, L.segs.size());
+#undef ALLOC
+    if (e != hipSuccess) {
+        ddrl::set_error("hipMalloc failed in ddrl_sac1_create: %s", hipGetErrorString(e));
+        sac1_free(h);
+        return DDRL_ERR_NOMEM;
+    }
+    DDRL_HIP_CHECK(hipMemcpy(h->segs_d, L.segs.data(), L.segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    rc = reset_opt(h, nullptr);
+    if (rc != DDRL_OK) { sac1_free(h); return rc; }
+
+    const float *Pm = h->main_p, *Pt = h->target_p;
+    const long long BH1 = (long long)B * h1, BH2 = (long long)B * h2;
+    // ---- layer-1 jobs.  evals: 0 pi(x) 1 pi(x2) 2 piT(x2) 3 q1(x,a) 4 q2(x,a) | 5 q1(x,pi) 6 q1T(x2,piT) 7 q2T(x2,piT)
+    auto l1 = [&](const float *in0, int d0, const float *in1, int d1, const float *W, const float *b, int ev) {
+        return L1Job{in0, in1, W, b, h->H1 + ev * BH1, d0, d1, B, h1};
+    };
+    h->l1a.njobs = 5;
+    h->l1a.job[0] = l1(h->x, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 0);
+    h->l1a.job[1] = l1(h->x2, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 1);
+    h->l1a.job[2] = l1(h->x2, o, nullptr, 0, Pt + L.pi_W1, Pt + L.pi_b1, 2);
+    h->l1a.job[3] = l1(h->x, o, h->a, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 3);
+    h->l1a.job[4] = l1(h->x, o, h->a, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 4);
+    h->l1b.njobs = 3;
+    h->l1b.job[0] = l1(h->x, o, h->act0, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 5);
+    h->l1b.job[1] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[0], Pt + L.q_b1[0], 6);
+    h->l1b.job[2] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[1], Pt + L.q_b1[1], 7);
+    // ---- forward layer-2 GEMMs
+    auto fwd = [&](const float *P, long long W2, long long b2, int ev) {
+        return gemm_fwd(h->H1 + ev * BH1, P + W2, P + b2, h->H2 + ev * BH2, B, h1, h2);
+    };
+    gemm_add(h->g_fa, fwd(Pm, L.pi_W2, L.pi_b2, 0));
+    gemm_add(h->g_fa, fwd(Pm, L.pi_W2, L.pi_b2, 1));
+    gemm_add(h->g_fa, fwd(Pt, L.pi_W2, L.pi_b2, 2));
+    gemm_add(h->g_fa, fwd(Pm, L.q_W2[0], L.q_b2[0], 3));
+    gemm_add(h->g_fa, fwd(Pm, L.q_W2[1], L.q_b2[1], 4));
+    gemm_add(h->g_fb, fwd(Pm, L.q_W2[0], L.q_b2[0], 5));
+    gemm_add(h->g_fb, fwd(Pt, L.q_W2[0], L.q_b2[0], 6));
+    gemm_add(h->g_fb, fwd(Pt, L.q_W2[1], L.q_b2[1], 7));
+    // ---- backward layer-2 GEMMs, Q paths: dZ2 slots 0 q1(x,a) 1 q2(x,a) 2 q1(x,pi); dZ1 same slots
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 2 * BH2, Pm + L.q_W2[0], h->H1 + 5 * BH1, h->dZ1 + 2 * BH1, B, h1, h2));  // first: pi waits on it
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 0 * BH2, Pm + L.q_W2[0], h->H1 + 3 * BH1, h->dZ1 + 0 * BH1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 1 * BH2, Pm + L.q_W2[1], h->H1 + 4 * BH1, h->dZ1 + 1 * BH1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_wgrad(h->H1 + 3 * BH1, h->dZ2 + 0 * BH2, h->grad + L.q_W2[0], B, h1, h2));
+    gemm_add(h->g_bq, gemm_wgrad(h->H1 + 4 * BH1, h->dZ2 + 1 * BH2, h->grad + L.q_W2[1], B, h1, h2));
+    // ---- policy trunk backward (slot 3)
+    gemm_add(h->g_bpi, gemm_dgrad(h->dZ2 + 3 * BH2, Pm + L.pi_W2, h->H1 + 0 * BH1, h->dZ1 + 3 * BH1, B, h1, h2));
+    gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, h->dZ2 + 3 * BH2, h->grad + L.pi_W2, B, h1, h2));
+
+    // ---- row kernels
+    h->ra = RowsA{h->H2, net_pi(Pm, L), net_pi(Pt, L), net_q(Pm, L, 0), net_q(Pm, L, 1), h->e0, h->e1, h->e2,
+                  h->act0, h->act2, h->logp0, h->logp1, h->save0, h->q1o, h->q2o, B, h2, a, (float)cfg->act_scale};
+    h->rb = RowsB{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_q(Pt, L, 0), net_q(Pt, L, 1), h->r, h->d, h->logp0,
+                  h->logp1, h->q1o, h->q2o, h->dZ2, h->dq, h->loss_part, B, h2,
+                  (float)cfg->alpha, (float)cfg->gamma};
+    h->rc = RowsC{h->H2, h->dZ1 + 2 * BH1, Pm + L.q_W1[0], net_pi(Pm, L), h->e0, h->save0, h->dhead, h->dZ2 + 3 * BH2,
+                  h->loss_part, h->losses, B, h1, h2, o, a, h->rows_b_blocks, (float)cfg->alpha, (float)cfg->act_scale};
+    h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, L.total_int, L.n_pi_int,
+                     (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
+                     (float)cfg->polyak, (float)(1.0 - cfg->polyak)};
+
+    // ---- small weight-gradient jobs
+    std::vector<SwJob> sw;
+    int blocks = 0;
+    auto sw_push = [&](SwJob j) {
+        j.block_start = blocks;
+        j.nblocks = (j.ncols + 63) / 64;
+        blocks += j.nblocks;
+        sw.push_back(j);
+    };
+    float *G = h->grad;
+    {   // pi: W1 + b1 from dZ1 slot 3
+        SwJob j{}; j.M = h->dZ1 + 3 * BH1; j.ldm = h1; j.ncols = h1; j.rows = B; j.nk = o + 1;
+        for (int k = 0; k < o; ++k) { j.sptr[k] = h->x + k; j.sstride[k] = o; j.optr[k] = G + L.pi_W1 + (long long)k * h1; j.ostride[k] = 1; }
+        j.sptr[o] = nullptr; j.sstride[o] = 0; j.optr[o] = G + L.pi_b1; j.ostride[o] = 1;
+        sw_push(j);
+    }
+    {   // pi: b2
+        SwJob j{}; j.M = h->dZ2 + 3 * BH2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 1;
+        j.sptr[0] = nullptr; j.optr[0] = G + L.pi_b2; j.ostride[0] = 1;
+        sw_push(j);
+    }
+    {   // pi: head kernels Wmu[h2,act], Wls[h2,act] from dhead[B,2act] and H2 eval 0
+        SwJob j{}; j.M = h->H2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 2 * a;
+        for (int c = 0; c < 2 * a; ++c) {
+            j.sptr[c] = h->dhead + c; j.sstride[c] = 2 * a;
+            j.optr[c] = G + (c < a ? L.pi_Wmu + c : L.pi_Wls + (c - a)); j.ostride[c] = a;
+        }
+        sw_push(j);
+    }
+    for (int part = 0; part < 2; ++part) {  // pi: head biases
+        SwJob j{}; j.M = h->dhead + part * a; j.ldm = 2 * a; j.ncols = a; j.rows = B; j.nk = 1;
+        j.sptr[0] = nullptr; j.optr[0] = G + (part == 0 ? L.pi_bmu : L.pi_bls); j.ostride[0] = 1;
+        sw_push(j);
+    }
+    for (int q = 0; q < 2; ++q) {
+        {   // W1 + b1 from dZ1 slot q, inputs [x | a]
+            SwJob j{}; j.M = h->dZ1 + q * BH1; j.ldm = h1; j.ncols = h1; j.rows = B; j.nk = o + a + 1;
+            for (int k = 0; k < o; ++k) { j.sptr[k] = h->x + k; j.sstride[k] = o; }
+            for (int k = 0; k < a; ++k) { j.sptr[o + k] = h->a + k; j.sstride[o + k] = a; }
+            for (int k = 0; k < o + a; ++k) { j.optr[k] = G + L.q_W1[q] + (long long)k * h1; j.ostride[k] = 1; }
+            j.sptr[o + a] = nullptr; j.optr[o + a] = G + L.q_b1[q]; j.ostride[o + a] = 1;
+            sw_push(j);
+        }
+        {   // b2
+            SwJob j{}; j.M = h->dZ2 + q * BH2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 1;
+            j.sptr[0] = nullptr; j.optr[0] = G + L.q_b2[q]; j.ostride[0] = 1;
+            sw_push(j);
+        }
+        {   // W3 from dq[q] and H2 eval 3+q
+            SwJob j{}; j.M = h->H2 + (3 + q) * BH2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 1;
+            j.sptr[0] = h->dq + (long long)q * B; j.sstride[0] = 1; j.optr[0] = G + L.q_W3[q]; j.ostride[0] = 1;
+            sw_push(j);
+        }
+        {   // b3
+            SwJob j{}; j.M = h->dq + (long long)q * B; j.ldm = 1; j.ncols = 1; j.rows = B; j.nk = 1;
+            j.sptr[0] = nullptr; j.optr[0] = G + L.q_b3[q]; j.ostride[0] = 1;
+            sw_push(j);
+        }
+    }
+    h->sw_njobs = (int)sw.size();
+    h->sw_blocks = blocks;
+    if (hipMalloc((void **)&h->sw_d, sw.size() * sizeof(SwJob)) != hipSuccess) {
+        ddrl::set_error("hipMalloc failed for job tables");
+        sac1_free(h);
+        return DDRL_ERR_NOMEM;
+    }
+    DDRL_HIP_CHECK(hipMemcpy(h->sw_d, sw.data(), sw.size() * sizeof(SwJob), hipMemcpyHostToDevice));
+    *out = h;
+    return DDRL_OK;
+}
+
+int ddrl_sac1_destroy(ddrl_sac1_t *h) {
+    if (!h) return DDRL_OK;
+    ddrl::DeviceGuard g(h->device);
+    return sac1_free(h);
+}
+
+static float *which_buf(ddrl_sac1 *h, int which) {
+    switch (which) {
+        case DDRL_SAC1_MAIN: return h->main_p;
+        case DDRL_SAC1_TARGET: return h->target_p;
+        case DDRL_SAC1_ADAM_M: return h->m;
+        case DDRL_SAC1_ADAM_V: return h->v;
+        case DDRL_SAC1_GRAD: return h->grad;
+        default: return nullptr;
+    }
+}
+
+int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && flat_d != nullptr, "NULL pointer");
+    float *buf = which_buf(h, which);
+    DDRL_REQUIRE(buf != nullptr, "unknown buffer id");
+    ddrl::DeviceGuard g(h->device);
+    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, buf, flat_d, nullptr, 0);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && flat_d != nullptr, "NULL pointer");
+    float *buf = which_buf(h, which);
+    DDRL_REQUIRE(buf != nullptr, "unknown buffer id");
+    ddrl::DeviceGuard g(h->device);
+    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_d, buf, nullptr, 1);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_sac1_set_weights(ddrl_sac1_t *h, const float *flat_main_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && flat_main_d != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    // copy into main AND target: Learner.set_weights runs target_init (actor_learner.py:125-127)
+    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_main_d, h->main_p,
+                                                                                    h->target_p, 1);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_sac1_get_weights(ddrl_sac1_t *h, float *flat_main_d, void *stream) {
+    return ddrl_sac1_export(h, DDRL_SAC1_MAIN, flat_main_d, stream);
+}
+
+int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    OptState o;
+    hipStream_t s = ddrl::as_stream(stream);
+    DDRL_HIP_CHECK(hipMemcpyAsync(&o, h->opt, sizeof(o), hipMemcpyDeviceToHost, s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    if (t_pi_h) *t_pi_h = o.t_pi;
+    if (t_q_h) *t_q_h = o.t_q;
+    return DDRL_OK;
+}
+
+static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, const float *acts, const float *rews,
+                        const float *done, const float *e0, const float *e1, const float *e2, float *losses_d, float *q1_d,
+                        float *q2_d, float *logp_d, hipStream_t s) {
+    const ddrl_sac1_config_t &c = h->cfg;
+    const int B = c.batch;
+    StageArgs st{};
+    const float *src[8] = {obs1, obs2, acts, rews, done, e0, e1, e2};
+    float *dst[8] = {h->x, h->x2, h->a, h->r, h->d, h->e0, h->e1, h->e2};
+    const int n[8] = {B * c.obs_dim, B * c.obs_dim, B * c.act_dim, B, B, B * c.act_dim, B * c.act_dim, B * c.act_dim};
+    for (int i = 0; i < 8; ++i) { st.src[i] = src[i]; st.dst[i] = dst[i]; st.n[i] = n[i]; }
+    k_stage<<<dim3((unsigned)((B * c.obs_dim + 255) / 256), 8), 256, 0, s>>>(st);
+    const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
+    k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a.njobs), 256, 0, s>>>(h->l1a);
+    k_gemm<<<h->g_fa.total_tiles, 256, 0, s>>>(h->g_fa);
+    k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra);
+    k_l1<<<dim3(l1grid.x, l1grid.y, h->l1b.njobs), 256, 0, s>>>(h->l1b);
+    k_gemm<<<h->g_fb.total_tiles, 256, 0, s>>>(h->g_fb);
+    k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb);
+    k_gemm<<<h->g_bq.total_tiles, 256, 0, s>>>(h->g_bq);
+    k_rows_c<<<(B + 3) / 4, 256, 0, s>>>(h->rc);
+    k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi);
+    k_small_wgrad<<<h->sw_blocks, 256, 0, s>>>(h->sw_d, h->sw_njobs);
+    DDRL_LAUNCH_CHECK();
+    if (losses_d) DDRL_HIP_CHECK(hipMemcpyAsync(losses_d, h->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (q1_d || q2_d || logp_d) {
+        k_copy3<<<(B + 255) / 256, 256, 0, s>>>(h->q1o, h->q2o, h->logp0, q1_d, q2_d, logp_d, B);
+        DDRL_LAUNCH_CHECK();
+    }
+    return DDRL_OK;
+}
+
+int ddrl_sac1_compute_grads(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d,
+                            const float *rews_d, const float *done_d, const float *eps_x_d, const float *eps_x2_d,
+                            const float *eps_t_d, float *losses_d, float *q1_d, float *q2_d, float *logp_pi_d,
+                            void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(obs1_d && obs2_d && acts_d && rews_d && done_d && eps_x_d && eps_x2_d && eps_t_d, "NULL batch/noise pointer");
+    ddrl::DeviceGuard g(h->device);
+    return launch_grads(h, obs1_d, obs2_d, acts_d, rews_d, done_d, eps_x_d, eps_x2_d, eps_t_d, losses_d, q1_d, q2_d,
+                        logp_pi_d, ddrl::as_stream(stream));
+}
+
+int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    long long blocks = (h->L.total_int + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    k_adam_polyak<<<(unsigned)blocks, 256, 0, ddrl::as_stream(stream)>>>(h->ad);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
+                   const float *done_d, const float *eps_x_d, const float *eps_x2_d, const float *eps_t_d,
+                   float *losses_d, float *q1_d, float *q2_d, float *logp_pi_d, void *stream) {
+    int rc = ddrl_sac1_compute_grads(h, obs1_d, obs2_d, acts_d, rews_d, done_d, eps_x_d, eps_x2_d, eps_t_d, losses_d,
+                                     q1_d, q2_d, logp_pi_d, stream);
+    if (rc != DDRL_OK) return rc;
+    return ddrl_sac1_apply_grads(h, stream);
+}
+
+}  // extern "C"
+
+// ==========================================================================================
+// Actor: batched Actor.get_action
+// ==========================================================================================
+struct ddrl_actor {
+    int device;
+    ddrl_sac1_config_t cfg;
+    Layout L;
+    float *pi_p;  // padded internal
+    float *H1, *H2;
+    Seg *segs_d;
+    long long max_rows;
+};
+
+extern "C" {
+
+int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *cfg, int64_t max_rows) {
+    DDRL_REQUIRE(out != nullptr && max_rows > 0, "bad out/max_rows");
+    int rc = check_cfg(cfg);
+    if (rc != DDRL_OK) return rc;
+    ddrl::DeviceGuard g(device);
+    if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
+    ddrl_actor *h = new ddrl_actor();
+    h->device = device; h->cfg = *cfg; h->max_rows = max_rows;
+    h->L = make_layout(*cfg, true);
+    h->pi_p = h->H1 = h->H2 = nullptr; h->segs_d = nullptr;
+    hipError_t e = dev_alloc(&h->pi_p, (size_t)h->L.total_int);
+    if (e == hipSuccess) e = dev_alloc(&h->H1, (size_t)max_rows * cfg->hidden1);
+    if (e == hipSuccess) e = dev_alloc(&h->H2, (size_t)max_rows * cfg->hidden2);
+    if (e == hipSuccess) e = dev_alloc(&h->segs_d, h->L.segs.size());
+    if (e != hipSuccess) {
+        ddrl::set_error("hipMalloc failed in ddrl_actor_create: %s", hipGetErrorString(e));
+        ddrl_actor_destroy(h);
+        return DDRL_ERR_NOMEM;
+    }
+    DDRL_HIP_CHECK(hipMemcpy(h->segs_d, h->L.segs.data(), h->L.segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    *out = h;
+    return DDRL_OK;
+}
+
+int ddrl_actor_destroy(ddrl_actor_t *h) {
+    if (!h) return DDRL_OK;
+    ddrl::DeviceGuard g(h->device);
+    (void)hipFree(h->pi_p); (void)hipFree(h->H1); (void)hipFree(h->H2); (void)hipFree(h->segs_d);
+    delete h;
+    return DDRL_OK;
+}
+
+int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && flat_pi_d != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_pi_d, h->pi_p, nullptr, 1);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_actor_get_weights(ddrl_actor_t *h, float *flat_pi_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && flat_pi_d != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, h->pi_p, flat_pi_d, nullptr, 0);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int64_t n, int deterministic, float *act_d,
+                   void *stream) {
+    DDRL_REQUIRE(h != nullptr && obs_d != nullptr && act_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(n > 0 && n <= h->max_rows, "n outside [1, max_rows]");
+    DDRL_REQUIRE(deterministic || eps_d != nullptr, "eps is required for stochastic actions");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    const ddrl_sac1_config_t &c = h->cfg;
+    const Layout &L = h->L;
+    L1Jobs l1{};
+    l1.njobs = 1;
+    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, c.obs_dim, 0, (int)n, c.hidden1};
+    k_l1<<<dim3((c.hidden1 + 255) / 256, (unsigned)((n + L1_ROWS - 1) / L1_ROWS), 1), 256, 0, s>>>(l1);
+    GemmJobs gj{};
+    gemm_add(gj, gemm_fwd(h->H1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, (int)n, c.hidden1, c.hidden2));
+    k_gemm<<<gj.total_tiles, 256, 0, s>>>(gj);
+    ActArgs aa{h->H2, net_pi(h->pi_p, L), eps_d, act_d, (int)n, c.hidden2, c.act_dim, deterministic, (float)c.act_scale};
+    k_rows_act<<<(unsigned)((n + 3) / 4), 256, 0, s>>>(aa);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+}  // extern "C"

@@ -130,14 +130,17 @@ typedef struct {
     int32_t hidden1;   /* 400  core.py:91 hidden_sizes=(400,300) */
     int32_t hidden2;   /* 300 */
     int32_t batch;     /* 256  hyperparams.py:82 */
-    float alpha;       /* 0.1    hyperparams.py:60 (fixed, not 'auto') */
-    float gamma;       /* 0.997  hyperparams.py:67 */
-    float lr;          /* 5e-5   hyperparams.py:78 */
-    float polyak;      /* 0.995  hyperparams.py:79 */
-    float beta1;       /* 0.9    tf.train.AdamOptimizer defaults */
-    float beta2;       /* 0.999 */
-    float adam_eps;    /* 1e-8 */
-    float act_scale;   /* action_space.high[0] = 1.0  core.py:104-106 */
+    int32_t reserved;  /* 0 */
+    /* Python floats in the reference (doubles): each derived constant is rounded to float32
+     * exactly where TensorFlow would round it (e.g. float32(1 - polyak), float32(alpha)). */
+    double alpha;      /* 0.1    hyperparams.py:60 (fixed, not 'auto') */
+    double gamma;      /* 0.997  hyperparams.py:67 */
+    double lr;         /* 5e-5   hyperparams.py:78 */
+    double polyak;     /* 0.995  hyperparams.py:79 */
+    double beta1;      /* 0.9    tf.train.AdamOptimizer defaults */
+    double beta2;      /* 0.999 */
+    double adam_eps;   /* 1e-8 */
+    double act_scale;  /* action_space.high[0] = 1.0  core.py:104-106 */
 } ddrl_sac1_config_t;
 
 /* Parameter layout (flat float32, TF variable creation order, kernels [in,out] row-major):
@@ -157,10 +160,21 @@ int ddrl_sac1_destroy(ddrl_sac1_t *h);
 int ddrl_sac1_set_weights(ddrl_sac1_t *h, const float *flat_main_d, void *stream);
 /* Learner.get_weights (actor_learner.py:129-133): the "main" variables. */
 int ddrl_sac1_get_weights(ddrl_sac1_t *h, float *flat_main_d, void *stream);
-/* Raw state pointers (device) for tests/checkpoint: main, target, adam m, adam v (each
- * n_pi+2*n_q floats) and the two Adam step counters (host). */
-int ddrl_sac1_state(ddrl_sac1_t *h, float **main_d, float **target_d, float **adam_m_d,
-                    float **adam_v_d, int64_t *t_pi_h, int64_t *t_q_h);
+/* Dense (flat layout above) export / import of the learner's state, on `stream`: main and
+ * target parameters, Adam first/second moments, and the gradient of the last compute_grads.
+ * Used for checkpoint/resume and for the multi-learner gradient all-reduce.
+ * set_weights == import(MAIN) + target_init;  get_weights == export(MAIN). */
+typedef enum {
+    DDRL_SAC1_MAIN = 0,
+    DDRL_SAC1_TARGET = 1,
+    DDRL_SAC1_ADAM_M = 2,
+    DDRL_SAC1_ADAM_V = 3,
+    DDRL_SAC1_GRAD = 4
+} ddrl_sac1_buffer;
+int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream);
+int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *stream);
+/* Adam step counters of the two optimizers (host outputs); synchronises `stream`. */
+int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *stream);
 
 /* Learner.train(batch) == sess.run(step_ops) (actor_learner.py:58-101,135-142): forward of main
  * and target nets, pi_loss / q1_loss / q2_loss from the PRE-update parameters, Adam(pi) then
@@ -175,12 +189,9 @@ int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, con
                    const float *eps_x2_d, const float *eps_t_d, float *losses_d, float *q1_d,
                    float *q2_d, float *logp_pi_d, void *stream);
 
-/* Gradients of the last step (device, flat layout as the parameters) — for parity tests and for
- * the multi-learner all-reduce.  Valid until the next step. */
-int ddrl_sac1_grads(ddrl_sac1_t *h, float **grad_d, int64_t *count);
 /* Two-phase form of ddrl_sac1_step for data-parallel learners: (1) forward+backward only,
  * gradients left in the grad buffer; (2) Adam(pi), Adam(q), polyak using the (possibly
- * all-reduced) grad buffer.  step == grads followed by apply. */
+ * all-reduced, via export/import of DDRL_SAC1_GRAD) grad buffer.  step == compute followed by apply. */
 int ddrl_sac1_compute_grads(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d,
                             const float *acts_d, const float *rews_d, const float *done_d,
                             const float *eps_x_d, const float *eps_x2_d, const float *eps_t_d,
@@ -196,9 +207,10 @@ typedef struct ddrl_actor ddrl_actor_t;
 
 int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *cfg, int64_t max_rows);
 int ddrl_actor_destroy(ddrl_actor_t *h);
-/* Actor.set_weights (actor_learner.py:186-187): the n_pi floats of the main/pi variables (device). */
+/* Actor.set_weights / get_weights (actor_learner.py:186-193): the n_pi floats of the main/pi
+ * variables (device, dense flat layout). */
 int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream);
-int ddrl_actor_params(ddrl_actor_t *h, float **flat_pi_d, int64_t *n_pi);
+int ddrl_actor_get_weights(ddrl_actor_t *h, float *flat_pi_d, void *stream);
 /* get_action for n observations: act = tanh(mu + eps*exp(log_std))*act_scale, or
  * tanh(mu)*act_scale when deterministic (core.py:49-87,104-106).  obs_d[n,obs], eps_d[n,act]
  * (ignored when deterministic; may be NULL then), act_d[n,act].  n <= max_rows. */

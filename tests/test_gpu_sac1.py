@@ -1,0 +1,192 @@
+"""GPU parity: HIP SAC1 learner / actor (through the C-ABI) vs the torch-CPU oracle on identical
+weights, batch and explicit noise.
+
+Tolerances (floating point; north star: losses within 1e-5 relative):
+  * losses vs the float64 oracle: 1e-5 relative (observed ~1e-7..1e-6);
+  * losses vs the float32 oracle: 1e-5 relative + the float32 oracle's own deviation from float64
+    (the reference's literal (pi-mu)/(std+EPS) cancels catastrophically in float32 — see DESIGN.md
+    §numerics and tests/test_oracle_sac1.py);
+  * per-row q1/q2: 1e-5 abs+rel; logp_pi: vs float64 oracle 2e-5 relative;
+  * gradients / parameters after the update: 2e-4 of the tensor's max |value| for gradients (float32
+    accumulation over 256 rows), and parameter deltas within 1e-3 relative of the step size.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import sac1_oracle as so  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ddrl():
+    import distributed_drl_amd as d
+    d._lib.require_gpu()
+    return d
+
+
+def _mk(ddrl, seed=0, **kw):
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    opt = HyperParameters()
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    opt.seed = seed
+    learner = Learner(opt)
+    cfg = so.Config(obs_dim=opt.obs_dim, act_dim=opt.act_dim, hidden1=opt.hidden_sizes[0], hidden2=opt.hidden_sizes[1],
+                    batch=opt.batch_size, alpha=opt.alpha, gamma=opt.gamma, lr=opt.lr, polyak=opt.polyak)
+    return opt, learner, cfg
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+
+def test_weight_roundtrip_and_layout(ddrl):
+    opt, learner, cfg = _mk(ddrl)
+    keys, vals = learner.get_weights()
+    assert keys == [n for n, _ in so.param_specs(cfg)]
+    ref = so.init_params(cfg, 0)  # same glorot/zeros init stream as the agent
+    for k, v in zip(keys, vals):
+        np.testing.assert_array_equal(v, ref[k])
+    # target_init at set_weights (actor_learner.py:125-127)
+    from distributed_drl_amd import _lib
+    np.testing.assert_array_equal(learner.export(_lib.SAC1_TARGET).cpu().numpy(), so.flatten(ref))
+    # subset set_weights
+    learner.set_weights(keys[:2], [np.full_like(vals[0], 0.5), np.full_like(vals[1], -0.25)])
+    k2, v2 = learner.get_weights()
+    assert (v2[0] == 0.5).all() and (v2[1] == -0.25).all()
+    np.testing.assert_array_equal(v2[2], vals[2])
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_first_update_matches_oracle(ddrl, seed):
+    from distributed_drl_amd import _lib
+    opt, learner, cfg = _mk(ddrl, seed)
+    params = so.init_params(cfg, seed)
+    rs = np.random.RandomState(seed + 10)
+    for k in params:  # non-zero biases exercise every term
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.05, 0.05, params[k].shape).astype(np.float32)
+    learner.set_weights(list(params.keys()), list(params.values()))
+    batch, eps = so.synthetic_batch(cfg, seed=1234 + seed)
+    o32, o64 = so.Sac1Oracle(cfg, params, torch.float32), so.Sac1Oracle(cfg, params, torch.float64)
+    w32, w64 = o32.step(batch, *eps), o64.step(batch, *eps)
+    losses, (q1, q2, lp) = learner.train(batch, eps=eps, return_outputs=True)
+    got = losses.cpu().numpy()
+    for i, k in enumerate(("pi_loss", "q1_loss", "q2_loss")):
+        assert _rel(got[i], w64[k]) <= 1e-5, (k, got[i], float(w64[k]))
+        own = abs(float(w32[k]) - float(w64[k]))
+        assert abs(got[i] - float(w32[k])) <= 1e-5 * abs(float(w64[k])) + own, k
+    np.testing.assert_allclose(q1.cpu().numpy(), w64["q1"].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(q2.cpu().numpy(), w64["q2"].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), w64["logp_pi"].numpy(), rtol=2e-5, atol=2e-5)
+    # gradients (pre-update parameters)
+    g = learner.export(_lib.SAC1_GRAD).cpu().numpy()
+    g64 = o64.flat("grads")
+    off = 0
+    for name, shape in so.param_specs(cfg):
+        n = int(np.prod(shape))
+        a, b = g[off:off + n], g64[off:off + n]
+        assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-12), (name, np.abs(a - b).max(), np.abs(b).max())
+        off += n
+    # parameters, Adam moments and polyak targets after the update
+    for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target"), (_lib.SAC1_ADAM_M, "m"),
+                        (_lib.SAC1_ADAM_V, "v")):
+        a, b = learner.export(which).cpu().numpy(), o64.flat(name)
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 2e-4 * scale + 1e-12, (name, np.abs(a - b).max(), scale)
+    # the first Adam step moves every parameter with a non-zero gradient by ~lr: compare deltas
+    d_gpu = learner.export(_lib.SAC1_MAIN).cpu().numpy() - so.flatten(params)
+    d_ref = o64.flat("main") - so.flatten(params).astype(np.float64)
+    assert np.abs(d_gpu - d_ref).max() <= 2e-2 * cfg.lr  # float32 param ulp (~3e-8) vs lr 5e-5
+    assert learner.opt_steps() == (1, 1)
+
+
+def test_twenty_updates_track_oracle(ddrl):
+    """Sequential updates (Adam state, running beta powers, polyak) stay within the float32 band."""
+    from distributed_drl_amd import _lib
+    opt, learner, cfg = _mk(ddrl, 1)
+    params = so.init_params(cfg, 1)
+    learner.set_weights(list(params.keys()), list(params.values()))
+    o64 = so.Sac1Oracle(cfg, params, torch.float64)
+    for it in range(20):
+        batch, eps = so.synthetic_batch(cfg, seed=77 + it)
+        w = o64.step(batch, *eps)
+        losses, _ = learner.train(batch, eps=eps, return_outputs=True)
+        got = losses.cpu().numpy()
+        for i, k in enumerate(("pi_loss", "q1_loss", "q2_loss")):
+            assert _rel(got[i], w[k]) <= 2e-5, (it, k, got[i], float(w[k]))
+    a, b = learner.export(_lib.SAC1_MAIN).cpu().numpy(), o64.flat("main")
+    assert np.abs(a - b).max() <= 20 * 2e-2 * cfg.lr
+    a, b = learner.export(_lib.SAC1_TARGET).cpu().numpy(), o64.flat("target")
+    assert np.abs(a - b).max() <= 1e-6
+    assert learner.opt_steps() == (20, 20)
+
+
+def test_compute_then_apply_equals_step(ddrl):
+    from distributed_drl_amd import _lib
+    _, l1, cfg = _mk(ddrl, 2)
+    _, l2, _ = _mk(ddrl, 2)
+    batch, eps = so.synthetic_batch(cfg, seed=5)
+    l1.train(batch, eps=eps)
+    g = l2.compute_gradients(batch, eps=eps)
+    l2.apply_gradients(g)  # export -> import round trip of the gradient, as the all-reduce path does
+    for which in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V):
+        assert torch.equal(l1.export(which), l2.export(which))
+
+
+def test_update_is_deterministic(ddrl):
+    from distributed_drl_amd import _lib
+    _, l1, cfg = _mk(ddrl, 4)
+    _, l2, _ = _mk(ddrl, 4)
+    for it in range(3):
+        batch, eps = so.synthetic_batch(cfg, seed=it)
+        a, _ = l1.train(batch, eps=eps, return_outputs=True)
+        b, _ = l2.train(batch, eps=eps, return_outputs=True)
+        assert torch.equal(a, b)
+    assert torch.equal(l1.export(_lib.SAC1_MAIN), l2.export(_lib.SAC1_MAIN))
+
+
+def test_other_shapes(ddrl):
+    """Ragged sizes: batch not a multiple of 32, hidden sizes not multiples of the tile, act_dim 3."""
+    from distributed_drl_amd import _lib
+    opt, learner, cfg = _mk(ddrl, 5, obs_dim=5, act_dim=3, hidden_sizes=(70, 45), batch_size=37)
+    params = so.init_params(cfg, 5)
+    learner.set_weights(list(params.keys()), list(params.values()))
+    batch, eps = so.synthetic_batch(cfg, seed=9)
+    o64 = so.Sac1Oracle(cfg, params, torch.float64)
+    w = o64.step(batch, *eps)
+    losses, (q1, q2, lp) = learner.train(batch, eps=eps, return_outputs=True)
+    for i, k in enumerate(("pi_loss", "q1_loss", "q2_loss")):
+        assert _rel(losses[i].item(), w[k]) <= 1e-5, k
+    g, g64 = learner.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
+    assert np.abs(g - g64).max() <= 2e-4 * np.abs(g64).max()
+
+
+def test_actor_matches_oracle(ddrl):
+    from distributed_drl_amd.agent import Actor, HyperParameters
+    opt = HyperParameters()
+    opt.seed = 0
+    actor = Actor(opt, max_rows=4096)
+    cfg = so.Config()
+    params = so.init_params(cfg, 0)
+    pi = {k: v for k, v in params.items() if "/pi/" in k}
+    keys, vals = actor.get_weights()
+    assert keys == list(pi.keys())
+    for k, v in zip(keys, vals):
+        np.testing.assert_array_equal(v, pi[k])
+    rs = np.random.RandomState(0)
+    for n in (1, 37, 4096):
+        obs = rs.randn(n, 8).astype(np.float32)
+        eps = rs.randn(n, 2).astype(np.float32)
+        want = so.actor_act(cfg, params, obs, eps, dtype=torch.float64)
+        got = actor.get_actions(obs, eps=eps).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+        want = so.actor_act(cfg, params, obs, None, deterministic=True, dtype=torch.float64)
+        got = actor.get_actions(obs, deterministic=True).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+    a1 = actor.get_action(obs[0], eps=eps[:1])
+    assert a1.shape == (2,) and a1.dtype == np.float32
+    np.testing.assert_array_equal(a1, actor.get_actions(obs[:1], eps=eps[:1]).cpu().numpy()[0])
