@@ -1,0 +1,369 @@
+// Batched lander environment: one thread per environment, state as struct-of-arrays
+// [DDRL_ENV_STATE_FIELDS][n] in HBM (coalesced per-field loads/stores).  Stands where the
+// reference calls gym's LunarLanderContinuous-v2 env.step / env.reset
+// (example/dsac.py:78-79,102,127) and fuses the worker's per-step episode bookkeeping
+// (example/dsac.py:102-127: ep_len/ep_ret, "time limit is not a terminal", reset at episode end).
+//
+// The dynamics are this build's own Box2D-style rigid-body model — see oracle/env_oracle.py for
+// the specification; this kernel reproduces that restatement BIT-EXACTLY: float32, no FMA
+// contraction (-ffp-contract=off), correctly rounded sqrt/divide, polynomial sin/cos shared with
+// the oracle, counter-hash RNG.  Every arithmetic statement below mirrors one line of the oracle.
+#include "ddrl_common.h"
+
+namespace {
+
+enum { X = 0, Y, VX, VY, ANG, OM, C1, C2, PREV, HASP, EPLEN, EPRET, SLEEP, EPI, T0, PSTEP = 25 };
+constexpr int NF = DDRL_ENV_STATE_FIELDS;
+
+constexpr float FPS = 50.0f, DT = 0.02f, SCALE = 30.0f, H_ = 13.333333f, HELIPAD_Y = 3.3333333f, LEG_DOWN = 0.6f;
+constexpr float GRAV = -10.0f, INV_M = 0.20746888f, INV_I = 1.1904762f, MAIN_POWER = 13.0f, SIDE_POWER = 0.6f;
+constexpr float SIDE_AWAY = 0.4f, SIDE_H = 0.46666667f, LEGX = 0.6666667f, LEGY = -0.8666667f;
+constexpr int NIT = 4;
+constexpr float SLOP = 0.005f, BAUM = 0.2f, MU = 0.5f, SLEEP_V2 = 0.0025f, SLEEP_W = 0.05f, SLEEP_STEPS = 25.0f;
+constexpr uint32_t RESET_STREAM = 0xFFFFFFF0u;
+__constant__ float HULLX[6] = {-0.46666667f, -0.56666666f, -0.56666666f, 0.56666666f, 0.56666666f, 0.46666667f};
+__constant__ float HULLY[6] = {0.56666666f, 0.0f, -0.33333334f, -0.33333334f, 0.0f, 0.56666666f};
+
+struct EnvStats {
+    long long episodes, len_sum;
+    double ret_sum;
+};
+
+__device__ __forceinline__ void sincos32(float x, float &sn, float &cs) {
+    const float k = rintf(x * 0.63661975f);
+    const float r = ((x - k * 1.5703125f) - k * 4.837513e-4f) - k * 7.54979e-8f;
+    const float r2 = r * r;
+    const float s = r + (r * r2) * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
+    const float c = (1.0f - 0.5f * r2) + (r2 * r2) * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f));
+    const int q = ((int)k) & 3;
+    sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+    cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+struct Env {
+    float x, y, vx, vy, ang, om, c1, c2, prev, hasp, eplen, epret, sleep, epi, pstep;
+    float terr[11];
+    uint32_t seed, id;
+
+    __device__ float rng(uint32_t step, uint32_t j) const {
+        const uint32_t seed_e = seed ^ ddrl::mix32((uint32_t)epi);
+        uint32_t h = ddrl::mix32(seed_e ^ 0x9E3779B9u);
+        h = ddrl::mix32(h + id * 0x85EBCA6Bu + 0x27D4EB2Fu);
+        h = ddrl::mix32(h ^ ((step * 16u + j) * 0xC2B2AE35u + 0x165667B1u));
+        return ddrl::u01(h);
+    }
+    __device__ float ground(float px) const {
+        const float fi = clampf(floorf(px * 0.5f), 0.0f, 9.0f);
+        const int idx = (int)fi;
+        // terrain lives in registers: select without dynamic indexing
+        float h0 = terr[0], h1 = terr[1];
+#pragma unroll
+        for (int i = 1; i < 10; ++i)
+            if (idx == i) { h0 = terr[i]; h1 = terr[i + 1]; }
+        const float t = (px - 2.0f * fi) * 0.5f;
+        return h0 + (h1 - h0) * t;
+    }
+    __device__ void obs(float *o) const {
+        o[0] = (x - 10.0f) / 10.0f;
+        o[1] = (y - (HELIPAD_Y + LEG_DOWN)) / 6.6666665f;
+        o[2] = vx * 10.0f / FPS;
+        o[3] = vy * 6.6666665f / FPS;
+        o[4] = ang;
+        o[5] = 20.0f * om / FPS;
+        o[6] = c1;
+        o[7] = c2;
+    }
+    // one physics step (oracle: LanderOracle._physics); returns reward, sets done_env and o[8]
+    __device__ float physics(float act0, float act1, bool &done_env, float *o) {
+        const float a0 = clampf(act0, -1.0f, 1.0f), a1 = clampf(act1, -1.0f, 1.0f);
+        const uint32_t step = (uint32_t)pstep;
+        const float d0 = (rng(step, 0) * 2.0f - 1.0f) / SCALE;
+        const float d1 = (rng(step, 1) * 2.0f - 1.0f) / SCALE;
+        float sn, cs;
+        sincos32(ang, sn, cs);
+        const float tip0 = sn, tip1 = cs, side0 = -tip1, side1 = tip0;
+        // main engine
+        const float m_power = a0 > 0.0f ? (clampf(a0, 0.0f, 1.0f) + 1.0f) * 0.5f : 0.0f;
+        float ox = tip0 * (0.13333334f + 2.0f * d0) + side0 * d1;
+        float oy = -tip1 * (0.13333334f + 2.0f * d0) - side1 * d1;
+        vx = vx + (-ox * MAIN_POWER * m_power) * INV_M;
+        vy = vy + (-oy * MAIN_POWER * m_power) * INV_M;
+        // side engines
+        const float direction = a1 < 0.0f ? -1.0f : 1.0f;
+        const float s_power = fabsf(a1) > 0.5f ? clampf(fabsf(a1), 0.5f, 1.0f) : 0.0f;
+        const float arm = 3.0f * d1 + direction * SIDE_AWAY;
+        ox = tip0 * d0 + side0 * arm;
+        oy = -tip1 * d0 - side1 * arm;
+        const float px_ = -ox * SIDE_POWER * s_power, py_ = -oy * SIDE_POWER * s_power;
+        float rx = ox - tip0 * 0.56666666f, ry = oy + tip1 * SIDE_H;
+        vx = vx + px_ * INV_M;
+        vy = vy + py_ * INV_M;
+        om = om + (rx * py_ - ry * px_) * INV_I;
+        // gravity
+        vy = vy + GRAV * DT;
+        // leg contacts
+        float grx[2], gry[2], gvmin[2], gkn[2], gkt[2], accn[2] = {0.0f, 0.0f}, acct[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int leg = 0; leg < 2; ++leg) {
+            const float pbx = leg == 0 ? -LEGX : LEGX;
+            rx = cs * pbx - sn * LEGY;
+            ry = sn * pbx + cs * LEGY;
+            const float gap = (y + ry) - ground(x + rx);
+            gvmin[leg] = gap >= 0.0f ? -gap / DT : BAUM * fmaxf(-gap - SLOP, 0.0f) / DT;
+            gkn[leg] = INV_M + (rx * rx) * INV_I;
+            gkt[leg] = INV_M + (ry * ry) * INV_I;
+            grx[leg] = rx; gry[leg] = ry;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int leg = 0; leg < 2; ++leg) {
+                const float vn = vy + om * grx[leg];
+                float lam = -(vn - gvmin[leg]) / gkn[leg];
+                float nw = fmaxf(accn[leg] + lam, 0.0f);
+                float dl = nw - accn[leg];
+                accn[leg] = nw;
+                vy = vy + dl * INV_M;
+                om = om + (grx[leg] * dl) * INV_I;
+                const float vt = vx - om * gry[leg];
+                lam = -vt / gkt[leg];
+                const float lim = MU * accn[leg];
+                nw = fminf(fmaxf(acct[leg] + lam, -lim), lim);
+                dl = nw - acct[leg];
+                acct[leg] = nw;
+                vx = vx + dl * INV_M;
+                om = om - (gry[leg] * dl) * INV_I;
+            }
+        }
+        // integrate
+        x = x + vx * DT;
+        y = y + vy * DT;
+        ang = ang + om * DT;
+        c1 = accn[0] > 0.0f ? 1.0f : 0.0f;
+        c2 = accn[1] > 0.0f ? 1.0f : 0.0f;
+        pstep = pstep + 1.0f;
+        // crash test
+        sincos32(ang, sn, cs);
+        bool crash = false;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const float hx = HULLX[v], hy = HULLY[v];
+            const float wx = x + (cs * hx - sn * hy);
+            const float wy = y + (sn * hx + cs * hy);
+            crash = crash || (wy < ground(wx));
+        }
+        // rest detection
+        const bool slow = ((vx * vx + vy * vy) < SLEEP_V2) && (fabsf(om) < SLEEP_W) && (c1 > 0.0f) && (c2 > 0.0f);
+        sleep = slow ? sleep + 1.0f : 0.0f;
+        const bool asleep = sleep >= SLEEP_STEPS;
+        obs(o);
+        const float shaping = ((-100.0f * sqrtf(o[0] * o[0] + o[1] * o[1]) - 100.0f * sqrtf(o[2] * o[2] + o[3] * o[3])) -
+                               100.0f * fabsf(o[4])) + 10.0f * o[6] + 10.0f * o[7];
+        float rew = hasp > 0.0f ? shaping - prev : 0.0f;
+        prev = shaping;
+        hasp = 1.0f;
+        rew = (rew - m_power * 0.30f) - s_power * 0.03f;
+        const bool out = crash || (fabsf(o[0]) >= 1.0f);
+        rew = out ? -100.0f : (asleep ? 100.0f : rew);
+        done_env = out || asleep;
+        return rew;
+    }
+    // env.reset(): terrain, random initial impulse, one no-op step (oracle: LanderOracle.reset)
+    __device__ void reset(float *o) {
+        float hs[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) hs[j] = rng(RESET_STREAM, j) * 6.6666665f;
+#pragma unroll
+        for (int j = 3; j < 8; ++j) hs[j] = HELIPAD_Y;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) terr[i] = 0.33f * ((hs[(i + 11) % 12] + hs[i]) + hs[i + 1]);
+        const float fx = (rng(RESET_STREAM, 12) * 2.0f - 1.0f) * 1000.0f;
+        const float fy = (rng(RESET_STREAM, 13) * 2.0f - 1.0f) * 1000.0f;
+        x = 10.0f; y = H_;
+        vx = (fx * DT) * INV_M; vy = (fy * DT) * INV_M;
+        ang = om = c1 = c2 = prev = hasp = eplen = epret = sleep = pstep = 0.0f;
+        bool d;
+        (void)physics(0.0f, 0.0f, d, o);
+    }
+    __device__ void load(const float *S, long long n, long long i) {
+        x = S[X * n + i]; y = S[Y * n + i]; vx = S[VX * n + i]; vy = S[VY * n + i]; ang = S[ANG * n + i];
+        om = S[OM * n + i]; c1 = S[C1 * n + i]; c2 = S[C2 * n + i]; prev = S[PREV * n + i]; hasp = S[HASP * n + i];
+        eplen = S[EPLEN * n + i]; epret = S[EPRET * n + i]; sleep = S[SLEEP * n + i]; epi = S[EPI * n + i];
+        pstep = S[PSTEP * n + i];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) terr[t] = S[(T0 + t) * n + i];
+    }
+    __device__ void store(float *S, long long n, long long i) const {
+        S[X * n + i] = x; S[Y * n + i] = y; S[VX * n + i] = vx; S[VY * n + i] = vy; S[ANG * n + i] = ang;
+        S[OM * n + i] = om; S[C1 * n + i] = c1; S[C2 * n + i] = c2; S[PREV * n + i] = prev; S[HASP * n + i] = hasp;
+        S[EPLEN * n + i] = eplen; S[EPRET * n + i] = epret; S[SLEEP * n + i] = sleep; S[EPI * n + i] = epi;
+        S[PSTEP * n + i] = pstep;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) S[(T0 + t) * n + i] = terr[t];
+    }
+};
+
+__global__ void __launch_bounds__(256) k_env_reset(float *S, long long n, uint32_t seed, const uint8_t *mask, float *obs_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Env e;
+    e.seed = seed; e.id = (uint32_t)i;
+    e.load(S, n, i);
+    float o[8];
+    if (!mask || mask[i]) {
+        e.reset(o);
+        e.store(S, n, i);
+    } else {
+        e.obs(o);
+    }
+    if (obs_out) {
+        float4 *p = reinterpret_cast<float4 *>(obs_out + i * 8);
+        p[0] = make_float4(o[0], o[1], o[2], o[3]);
+        p[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_env_step(float *S, long long n, uint32_t seed, float max_ep_len, const float *act,
+                                                  float *obs2, float *rew_out, float *done_out, float *next_obs,
+                                                  uint8_t *ended_out, EnvStats *stats) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n_end = 0, len_end = 0;
+    double ret_end = 0.0;
+    if (i < n) {
+        Env e;
+        e.seed = seed; e.id = (uint32_t)i;
+        e.load(S, n, i);
+        float o[8];
+        bool done_env;
+        const float2 a = *reinterpret_cast<const float2 *>(act + i * 2);
+        const float rew = e.physics(a.x, a.y, done_env, o);
+        e.eplen = e.eplen + 1.0f;                       // example/dsac.py:104
+        e.epret = e.epret + rew;                        // :103
+        const bool limit = e.eplen >= max_ep_len;
+        const float done_store = limit ? 0.0f : (done_env ? 1.0f : 0.0f);  // :109
+        const bool ended = done_env || limit;                              // :118
+        if (obs2) {
+            float4 *p = reinterpret_cast<float4 *>(obs2 + i * 8);
+            p[0] = make_float4(o[0], o[1], o[2], o[3]);
+            p[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (rew_out) rew_out[i] = rew;
+        if (done_out) done_out[i] = done_store;
+        if (ended_out) ended_out[i] = ended ? 1 : 0;
+        if (ended) {
+            n_end = 1; len_end = (long long)e.eplen; ret_end = (double)e.epret;
+            e.epi = e.epi + 1.0f;
+            e.reset(o);                                 // :127
+        }
+        if (next_obs) {
+            float4 *p = reinterpret_cast<float4 *>(next_obs + i * 8);
+            p[0] = make_float4(o[0], o[1], o[2], o[3]);
+            p[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        e.store(S, n, i);
+    }
+    // episode statistics: wave reduction, one atomic per wave that saw an episode end
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_end += __shfl_xor(n_end, off);
+        len_end += __shfl_xor(len_end, off);
+        ret_end += __shfl_xor(ret_end, off);
+    }
+    if ((threadIdx.x & 63) == 0 && n_end > 0) {
+        atomicAdd((unsigned long long *)&stats->episodes, (unsigned long long)n_end);
+        atomicAdd((unsigned long long *)&stats->len_sum, (unsigned long long)len_end);
+        atomicAdd(&stats->ret_sum, ret_end);
+    }
+}
+
+}  // namespace
+
+struct ddrl_env {
+    int device;
+    long long n;
+    uint32_t seed;
+    int max_ep_len;
+    float *S;
+    EnvStats *stats;
+};
+
+extern "C" {
+
+int ddrl_env_create(ddrl_env_t **out, int device, int64_t n_envs, uint32_t seed, int32_t max_ep_len) {
+    DDRL_REQUIRE(out != nullptr && n_envs > 0 && max_ep_len > 0, "bad out/n_envs/max_ep_len");
+    DDRL_REQUIRE(max_ep_len < (1 << 24), "max_ep_len must stay exact in float32");
+    ddrl::DeviceGuard g(device);
+    if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
+    ddrl_env *h = new ddrl_env();
+    h->device = device; h->n = n_envs; h->seed = seed; h->max_ep_len = max_ep_len; h->S = nullptr; h->stats = nullptr;
+    if (hipMalloc((void **)&h->S, (size_t)NF * n_envs * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&h->stats, sizeof(EnvStats)) != hipSuccess) {
+        ddrl::set_error("hipMalloc failed for %lld envs", (long long)n_envs);
+        ddrl_env_destroy(h);
+        return DDRL_ERR_NOMEM;
+    }
+    DDRL_HIP_CHECK(hipMemset(h->S, 0, (size_t)NF * n_envs * sizeof(float)));
+    DDRL_HIP_CHECK(hipMemset(h->stats, 0, sizeof(EnvStats)));
+    k_env_reset<<<(unsigned)((n_envs + 255) / 256), 256, 0, nullptr>>>(h->S, h->n, h->seed, nullptr, nullptr);
+    DDRL_LAUNCH_CHECK();
+    DDRL_HIP_CHECK(hipStreamSynchronize(nullptr));
+    *out = h;
+    return DDRL_OK;
+}
+
+int ddrl_env_destroy(ddrl_env_t *h) {
+    if (!h) return DDRL_OK;
+    ddrl::DeviceGuard g(h->device);
+    (void)hipFree(h->S); (void)hipFree(h->stats);
+    delete h;
+    return DDRL_OK;
+}
+
+int ddrl_env_reset(ddrl_env_t *h, const uint8_t *mask_d, float *obs_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    k_env_reset<<<(unsigned)((h->n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->S, h->n, h->seed, mask_d, obs_d);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d, float *done_d, float *next_obs_d,
+                  uint8_t *ended_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && act_d != nullptr, "NULL handle or action pointer");
+    ddrl::DeviceGuard g(h->device);
+    k_env_step<<<(unsigned)((h->n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(
+        h->S, h->n, h->seed, (float)h->max_ep_len, act_d, obs2_d, rew_d, done_d, next_obs_d, ended_d, h->stats);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_env_stats(ddrl_env_t *h, int64_t *episodes_h, double *ret_sum_h, int64_t *len_sum_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    EnvStats st;
+    DDRL_HIP_CHECK(hipMemcpyAsync(&st, h->stats, sizeof(st), hipMemcpyDeviceToHost, s));
+    DDRL_HIP_CHECK(hipMemsetAsync(h->stats, 0, sizeof(EnvStats), s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    if (episodes_h) *episodes_h = st.episodes;
+    if (ret_sum_h) *ret_sum_h = st.ret_sum;
+    if (len_sum_h) *len_sum_h = st.len_sum;
+    return DDRL_OK;
+}
+
+int ddrl_env_get_state(ddrl_env_t *h, float *state_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && state_d != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    DDRL_HIP_CHECK(hipMemcpyAsync(state_d, h->S, (size_t)NF * h->n * sizeof(float), hipMemcpyDeviceToDevice, ddrl::as_stream(stream)));
+    return DDRL_OK;
+}
+
+int ddrl_env_set_state(ddrl_env_t *h, const float *state_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && state_d != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    DDRL_HIP_CHECK(hipMemcpyAsync(h->S, state_d, (size_t)NF * h->n * sizeof(float), hipMemcpyDeviceToDevice, ddrl::as_stream(stream)));
+    return DDRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""GPU parity: batched lander kernel vs oracle/env_oracle.py — BIT-EXACT (float32 arithmetic with
+one rounding per operation on both sides, shared polynomial sin/cos, integer hash RNG)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ddrl():
+    import distributed_drl_amd as d
+    d._lib.require_gpu()
+    return d
+
+
+def _heuristic(s):
+    """gym's lunar_lander heuristic controller (lands the craft; exercises contacts and rest)."""
+    angle_targ = np.clip(s[:, 0] * 0.5 + s[:, 2] * 1.0, -0.4, 0.4)
+    hover_targ = 0.55 * np.abs(s[:, 0])
+    angle_todo = (angle_targ - s[:, 4]) * 0.5 - s[:, 5] * 1.0
+    hover_todo = (hover_targ - s[:, 1]) * 0.5 - s[:, 3] * 0.5
+    legs = (s[:, 6] > 0) | (s[:, 7] > 0)
+    angle_todo = np.where(legs, 0, angle_todo)
+    hover_todo = np.where(legs, -s[:, 3] * 0.5, hover_todo)
+    return np.clip(np.stack([hover_todo * 20 - 1, -angle_todo * 20], 1), -1, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,seed,policy,steps", [(64, 1, "heuristic", 700), (300, 7, "random", 400), (1, 3, "zero", 150)])
+def test_env_bit_exact_vs_oracle(ddrl, n, seed, policy, steps):
+    from distributed_drl_amd.env import VecLunarLander
+    from oracle.env_oracle import LanderOracle
+    max_len = 160 if policy == "heuristic" and n == 64 else 1000
+    env = VecLunarLander(n, seed=seed, max_ep_len=max_len)
+    ora = LanderOracle(n, seed=seed, max_ep_len=max_len)
+    np.testing.assert_array_equal(env.obs.cpu().numpy(), ora.obs())
+    np.testing.assert_array_equal(env.get_state().cpu().numpy(), ora.S)
+    rs = np.random.RandomState(seed)
+    o = ora.obs()
+    n_ended = 0
+    for t in range(steps):
+        if policy == "heuristic":
+            a = _heuristic(o)
+        elif policy == "random":
+            a = rs.uniform(-1.3, 1.3, (n, 2)).astype(np.float32)  # also exercises the action clip
+        else:
+            a = np.zeros((n, 2), np.float32)
+        g = [x.cpu().numpy() for x in env.step(torch.from_numpy(a).cuda())]
+        w = ora.step(a)
+        for name, gv, wv in zip(("obs2", "rew", "done", "next_obs", "ended"), g, w):
+            np.testing.assert_array_equal(gv, wv, err_msg="%s at step %d" % (name, t))
+        o = w[3]
+        n_ended += int(w[4].sum())
+    np.testing.assert_array_equal(env.get_state().cpu().numpy(), ora.S)
+    ge, gr, gl = env.stats()
+    we, wr, wl = ora.stats()
+    assert (ge, gl) == (we, wl) and ge == n_ended
+    assert abs(gr - wr) <= 1e-9 * max(1.0, abs(wr))
+    if policy != "zero":
+        assert n_ended > 0
+
+
+def test_time_limit_is_not_a_terminal(ddrl):
+    """example/dsac.py:109,118: at ep_len == max_ep_len the stored done is 0 but the episode ends."""
+    from distributed_drl_amd.env import VecLunarLander
+    env = VecLunarLander(8, seed=0, max_ep_len=5)
+    hover = torch.tensor([[0.3, 0.0]] * 8, device="cuda")
+    for t in range(5):
+        _, _, done, _, ended = env.step(hover)
+        if t < 4:
+            assert ended.sum().item() == 0
+    assert done.sum().item() == 0 and ended.sum().item() == 8
+    assert env.stats()[0] == 8
+
+
+def test_masked_reset_and_state_roundtrip(ddrl):
+    from distributed_drl_amd.env import VecLunarLander
+    from oracle.env_oracle import LanderOracle
+    env, ora = VecLunarLander(16, seed=5), LanderOracle(16, seed=5)
+    a = np.full((16, 2), 0.7, np.float32)
+    for _ in range(10):
+        env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+    mask = (np.arange(16) % 3 == 0)
+    g = env.reset(torch.from_numpy(mask.astype(np.uint8)).cuda()).cpu().numpy()
+    w = ora.reset(mask)
+    np.testing.assert_array_equal(g, w)
+    s = env.get_state()
+    env2 = VecLunarLander(16, seed=5)
+    env2.set_state(s)
+    g1 = env.step(torch.from_numpy(a).cuda())[0].cpu().numpy()
+    g2 = env2.step(torch.from_numpy(a).cuda())[0].cpu().numpy()
+    np.testing.assert_array_equal(g1, g2)
+
+
+def test_noise_fills_match_oracle(ddrl):
+    from distributed_drl_amd import _lib
+    from oracle import noise_oracle as no
+    lib = _lib.load()
+    for n, seed, ctr in ((1000, 0, 0), (4097, 123, 2 ** 32 - 100)):
+        out = torch.empty(n, device="cuda")
+        _lib.check(lib.ddrl_uniform_fill(_lib.dptr(out), n, -1.0, 1.0, seed, ctr, _lib.stream_ptr()))
+        np.testing.assert_array_equal(out.cpu().numpy(), no.uniform_fill(n, -1.0, 1.0, seed, ctr))
+        _lib.check(lib.ddrl_normal_fill(_lib.dptr(out), n, seed, ctr, _lib.stream_ptr()))
+        np.testing.assert_allclose(out.cpu().numpy(), no.normal_fill(n, seed, ctr), rtol=2e-5, atol=2e-6)
+    big = torch.empty(1 << 20, device="cuda")
+    _lib.check(lib.ddrl_normal_fill(_lib.dptr(big), big.numel(), 9, 0, _lib.stream_ptr()))
+    assert abs(big.mean().item()) < 5e-3 and abs(big.std().item() - 1.0) < 5e-3
+
+
+def test_gym_facade(ddrl):
+    from distributed_drl_amd import env as E
+    e = E.make("LunarLanderContinuous-v2", seed=2, max_ep_len=50)
+    o = e.reset()
+    assert o.shape == (8,) and o.dtype == np.float64
+    a = e.action_space.sample()
+    assert a.shape == (2,) and (np.abs(a) <= 1).all()
+    n = 0
+    for _ in range(60):
+        o2, r, d, info = e.step(np.array([0.0, 0.0]))
+        n += 1
+        if d:
+            break
+    assert d and n <= 50
+    o = e.reset()
+    assert o.shape == (8,)
+    with pytest.raises(ValueError):
+        E.make("BipedalWalker-v2")
