@@ -26,6 +26,8 @@ def __getattr__(name):
         "Learner": "agent", "Actor": "agent", "HyperParameters": "agent",
         "VecLunarLander": "env",
         "worker_rollout": "workers", "worker_train": "workers", "worker_test": "workers",
+        "worker_rollout_sac1": "workers", "worker_train_sac1": "workers",
+        "RolloutDevice": "workers", "TrainDevice": "workers",
     }
     if name in table:
         return getattr(importlib.import_module("." + table[name], __name__), name)

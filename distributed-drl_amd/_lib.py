@@ -17,6 +17,7 @@ DDRL_ERR_NOMEM = -4
 DDRL_ERR_UNSUPPORTED = -5
 DDRL_REPLAY_ACTS_1D = 1
 DDRL_ENV_STATE_FIELDS = 32
+SAC1_STAGES = 12
 SAC1_MAIN, SAC1_TARGET, SAC1_ADAM_M, SAC1_ADAM_V, SAC1_GRAD = range(5)
 
 
@@ -68,6 +69,13 @@ SIGNATURES = {
     "ddrl_sac1_step": (c_int, [_P] + [_P] * 12 + [_P]),
     "ddrl_sac1_compute_grads": (c_int, [_P] + [_P] * 12 + [_P]),
     "ddrl_sac1_apply_grads": (c_int, [_P, _P]),
+    "ddrl_sac1_input_buffers": (c_int, [_P, POINTER(_P)]),
+    "ddrl_sac1_batch": (c_int, [_P]),
+    "ddrl_sac1_fill_noise": (c_int, [_P, c_uint32, _P]),
+    "ddrl_sac1_stage_time": (c_int, [_P, c_int, c_int, POINTER(c_float), _P]),
+    "ddrl_loop_create": (c_int, [POINTER(_P), _P, _P, c_int32, c_uint32]),
+    "ddrl_loop_destroy": (c_int, [_P]),
+    "ddrl_loop_run": (c_int, [_P, c_int64, _P]),
     "ddrl_actor_create": (c_int, [POINTER(_P), c_int, POINTER(Sac1Config), c_int64]),
     "ddrl_actor_destroy": (c_int, [_P]),
     "ddrl_actor_set_weights": (c_int, [_P, _P, _P]),
@@ -96,6 +104,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libddrl_hip.so must bind to the HIP runtime torch has loaded (one runtime per
+    # process), otherwise device pointers and streams would belong to a different runtime instance
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DdrlError(
             "libddrl_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "

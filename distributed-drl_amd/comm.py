@@ -1,0 +1,151 @@
+"""Multi-GPU plumbing over torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for
+the CPU tests).  One process per GPU, launched by torch.distributed.run.
+
+Mapping of the reference's cross-process traffic:
+  * ps.push / ps.pull (example/dsac.py:59-65, every 300 updates / every episode)
+        -> ONE broadcast of the flat float32 parameter vector from the learner rank
+           (`ParamBroadcast`).  1.5 MB: latency-bound, so it is a single collective, never 20.
+  * replay shards (algos/sac1/sac_ray.py:137-141,246; algos/dqn/train.py:191-199,277-279):
+        every rank appends to its LOCAL shard (no collective on store); a sampled batch comes
+        from ONE shard chosen as np.random.choice(num_shards) on the learner's seeded stream
+        (`ShardPicker`); the owner gathers and the 20 KB batch moves with one broadcast from the
+        owner (`fetch_batch`).
+  * 2 learners (BASELINE config 4) -> all-reduce(sum)/k of the flat gradient between learner ranks
+        (`allreduce_mean_`); the reference's multi-learner is unsynchronised last-writer-wins
+        (example/dsac.py:59-62,233), so this is a documented new synchronous semantics.
+The path shards by independent units (envs, replay shards): bench.py reports weak scaling.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for 1 process)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_mean_(flat, group=None):
+    """In-place mean over the group's ranks (learner gradient all-reduce)."""
+    if not dist.is_initialized():
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    n = dist.get_world_size(group)
+    if n > 1:
+        flat.div_(n)
+    return flat
+
+
+def allreduce_max(value, device=None):
+    """MAX over ranks of a python float (bench timing)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64,
+                     device=device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_sum(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64,
+                     device=device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+class ParamBroadcast:
+    """ps.push + ps.pull across ranks: the learner rank's flat parameter vector is broadcast into
+    every rank's receive buffer; `version` counts pushes (ranks call `sync` collectively at the
+    same cadence — every push_freq updates, algos/sac1/sac1.py:149)."""
+
+    def __init__(self, count, device, src=0, group=None):
+        self.buf = torch.zeros(int(count), dtype=torch.float32, device=device)
+        self.src, self.group, self.version = src, group, 0
+
+    def sync(self, flat=None):
+        """Collective.  On the source rank `flat` is the fresh parameter vector."""
+        if rank() == self.src:
+            assert flat is not None and flat.numel() == self.buf.numel()
+            self.buf.copy_(flat.reshape(-1))
+        if dist.is_initialized():
+            dist.broadcast(self.buf, src=self.src, group=self.group)
+        self.version += 1
+        return self.buf
+
+    # the slice of ParameterServer's surface the device workers use
+    def pull_flat(self, offset, count, out=None):
+        v = self.buf[int(offset):int(offset) + int(count)]
+        if out is not None:
+            out.copy_(v)
+            return out
+        return v.clone()
+
+    def span(self, keys):
+        return getattr(self, "_spans", {}).get(tuple(keys))
+
+    def register_span(self, keys, offset, count):
+        self.__dict__.setdefault("_spans", {})[tuple(keys)] = (int(offset), int(count))
+
+
+class ShardPicker:
+    """Shard choice of the sharded sampler: `np.random.choice(num_shards, 1)[0]` in the reference
+    (algos/sac1/sac_ray.py:137; algos/dqn/train.py:191-193), which consumes the legacy MT19937
+    stream exactly like randint(0, num_shards) (SURVEY §7.2 probe).  Every rank holds the same
+    seeded stream, so all ranks agree on the owner without communication."""
+
+    def __init__(self, num_shards, seed=0):
+        self.num_shards = int(num_shards)
+        self.rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+
+    def next(self):
+        return int(self.rs.randint(0, self.num_shards))
+
+
+def fetch_batch(local_batch_fn, owner, like, group=None):
+    """Move one sampled batch from the shard owner to every rank of the group (the learner uses
+    it; at 20 KB the transfer is latency-bound, one broadcast per tensor of the dict is avoided
+    by packing the batch into one flat buffer).
+
+    local_batch_fn() -> dict(obs1, obs2, acts, rews, done) is called on the owner only;
+    `like` is a dict of tensors giving shapes/dtypes/device on the receivers."""
+    names = ("obs1", "obs2", "acts", "rews", "done")
+    sizes = [int(like[k].numel()) for k in names]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=like["rews"].device)
+    if rank() == owner:
+        b = local_batch_fn()
+        torch.cat([b[k].reshape(-1) for k in names], out=flat)
+    if dist.is_initialized():
+        dist.broadcast(flat, src=owner, group=group)
+    out, off = {}, 0
+    for k, n in zip(names, sizes):
+        out[k] = flat[off:off + n].view(like[k].shape)
+        off += n
+    return out

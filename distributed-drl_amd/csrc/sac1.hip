@@ -26,7 +26,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int MAXA = 8;        // act_dim supported by the row kernels
 constexpr int NEVAL = 8;       // network evaluations per update
-constexpr int SW_MAXK = 12;    // max "scale" columns of a small-wgrad job (obs+act+1 <= 12 at LunarLander dims)
 constexpr float LOG2PI = 1.8378770664093453f;  // float32(np.log(2*np.pi))
 constexpr float STD_EPS = 1e-8f;               // core.py:5 EPS
 
@@ -42,6 +41,7 @@ struct GemmJob {
     int a_kc;  // 1: A(i,k) = A[i*lda + k]   0: A(i,k) = A[k*lda + i]
     int b_kc;  // 1: B(k,j) = B[j*ldb + k]   0: B(k,j) = B[k*ldb + j]
     int relu;
+    int a_ones_row;  // >= 0: that row of A is all ones (bias gradients ride as an extra row of a wgrad)
     int tiles_n, tile_start, ntiles;
 };
 constexpr int MAX_GEMM_JOBS = 8;
@@ -50,25 +50,15 @@ struct GemmJobs {
     GemmJob job[MAX_GEMM_JOBS];
 };
 
-struct L1Job {  // H1 = relu([in0 | in1] * W1 + b1)
+struct L1Job {  // H1 = relu([in0 | in1] * W1 + b1); optionally also writes the concatenated input rows
     const float *in0, *in1, *W, *b;
-    float *out;
+    float *out, *aug_out;
     int d0, d1, rows, h1;
 };
 constexpr int MAX_L1_JOBS = 5;
 struct L1Jobs {
     int njobs;
     L1Job job[MAX_L1_JOBS];
-};
-
-struct SwJob {  // out_k[j*ostride_k] = sum_r S_k[r] * M[r*ldm + j];   S_k == nullptr means ones
-    const float *M;
-    int ldm, ncols, rows, nk;
-    const float *sptr[SW_MAXK];
-    int sstride[SW_MAXK];
-    float *optr[SW_MAXK];
-    int ostride[SW_MAXK];
-    int block_start, nblocks;
 };
 
 struct Seg {  // one tensor: dense external offset <-> padded internal offset
@@ -79,6 +69,7 @@ struct OptState {  // device-resident Adam bookkeeping (running beta powers like
     float b1p_pi, b2p_pi, b1p_q, b2p_q;
     long long t_pi, t_q;
     unsigned int ticket_adam, pad;
+    unsigned long long noise_ctr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -97,6 +88,7 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
         float v = 0.f;
         if (r < jb.rows) v = (k < jb.d0) ? jb.in0[(long long)r * jb.d0 + k] : jb.in1[(long long)r * jb.d1 + (k - jb.d0)];
         s_in[rr][k] = v;
+        if (jb.aug_out && blockIdx.x == 0 && r < jb.rows) jb.aug_out[(long long)r * din + k] = v;  // [x | a] rows for the layer-1 wgrad
     }
     __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -118,34 +110,94 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K: batched small GEMM on v_mfma_f32_32x32x2_f32.
-// One workgroup = one 32x32 output tile; its 4 waves split K four ways (in-workgroup split-K:
-// at M = batch = 256 a stage has only ~80-130 tiles per network, so K is what fills the 1024
-// SIMDs), each wave streams its operands straight from L2 into registers (nothing is shared
-// between waves, so LDS staging would only add a round trip), and the four partial tiles are
-// combined through LDS in a fixed order (deterministic).
+// K: batched small GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+// One workgroup = one 32x32 output tile; its 4 waves split K four ways (in-workgroup split-K: at
+// M = batch = 256 a stage has only ~80-130 tiles per network, so K is what fills the 1024 SIMDs)
+// and the four partial tiles are combined through LDS in a fixed order (deterministic).
+// Operand fetch, per 32-deep K sub-chunk and per wave: BOTH operands are read from global memory
+// as float4 (full 128-B row segments: 8 lanes per row, 8 rows per instruction, 4 instructions per
+// operand) and handed to the MFMA lanes through a wave-private LDS tile:
+//   * operand contiguous along K in memory (activations of fwd/dgrad, W2 rows of dgrad):
+//       LDS image [idx][k] (row stride 34), each lane picks float2 (k, k+1) of its row/col;
+//   * operand contiguous along M/N (weights of fwd, both operands of wgrad):
+//       LDS image [k][idx] (row stride 36), each lane picks two b32 of its column.
+// (Reading lane-per-row straight from global touches one cache line per lane and per-load address
+// arithmetic dominated: 10x slower.)  The next sub-chunk's global loads are issued before the
+// current sub-chunk's 16 MFMAs.
 // ------------------------------------------------------------------------------------------
-constexpr int G_IT = 26;  // 4 k per iteration and lane-half -> up to 104 k per wave pass
+constexpr int KS = 32;
+constexpr int OP_LDS = 32 * 36;  // floats per operand tile
 
-__device__ __forceinline__ void ld_pair(const float *__restrict__ base, int kc, int idx, int nidx, int ld, int k, int kend,
-                                        float &x, float &y) {
-    x = 0.f; y = 0.f;
-    if (idx < nidx && k < kend) {
+// up to 4 consecutive floats; `nvalid` leading elements exist, the rest read as 0
+__device__ __forceinline__ float4 ld4(const float *__restrict__ p, int nvalid) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid >= 4 && (((uintptr_t)p) & 15) == 0) {
+        t = *reinterpret_cast<const float4 *>(p);
+    } else if (nvalid > 0) {
+        t.x = p[0];
+        if (nvalid > 1) t.y = p[1];
+        if (nvalid > 2) t.z = p[2];
+        if (nvalid > 3) t.w = p[3];
+    }
+    return t;
+}
+
+// Global -> registers for one operand tile (32 idx x 32 k).  kc: rows = idx, columns = k.
+// nc: rows = k, columns = idx.  `ones` (nc only): that idx reads as 1.0 for every valid k.
+__device__ __forceinline__ void ld_tile(const float *__restrict__ base, bool kc, int ld, int idx0, int nidx, int kb, int k1,
+                                        int ones, int lane, float4 (&v)[4]) {
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         if (kc) {
-            const float *p = base + (long long)idx * ld + k;
-            if (k + 1 < kend) {
-                if ((((uintptr_t)p) & 7) == 0) { const float2 v = *reinterpret_cast<const float2 *>(p); x = v.x; y = v.y; }
-                else { x = p[0]; y = p[1]; }
-            } else x = p[0];
+            const int gi = idx0 + q * 8 + r8, k = kb + c4;
+            const int nv = gi < nidx ? k1 - k : 0;
+            v[q] = ld4(base + (long long)(gi < nidx ? gi : 0) * ld + k, nv);
         } else {
-            x = base[(long long)k * ld + idx];
-            if (k + 1 < kend) y = base[(long long)(k + 1) * ld + idx];
+            const int k = kb + q * 8 + r8, gi = idx0 + c4;
+            const int nv = k < k1 ? nidx - gi : 0;
+            float4 t = ld4(base + (long long)(k < k1 ? k : 0) * ld + gi, nv);
+            if (ones >= 0 && k < k1) {
+                if (gi == ones) t.x = 1.f;
+                if (gi + 1 == ones) t.y = 1.f;
+                if (gi + 2 == ones) t.z = 1.f;
+                if (gi + 3 == ones) t.w = 1.f;
+            }
+            v[q] = t;
+        }
+    }
+}
+
+__device__ __forceinline__ void st_tile(float *__restrict__ s, bool kc, int lane, const float4 (&v)[4]) {
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + r8;
+        if (kc) {
+            *reinterpret_cast<float2 *>(s + row * 34 + c4) = make_float2(v[q].x, v[q].y);
+            *reinterpret_cast<float2 *>(s + row * 34 + c4 + 2) = make_float2(v[q].z, v[q].w);
+        } else {
+            *reinterpret_cast<float4 *>(s + row * 36 + c4) = v[q];
+        }
+    }
+}
+
+__device__ __forceinline__ void rd_tile(const float *__restrict__ s, bool kc, int l31, int h, float (&x)[8], float (&y)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = 4 * c + 2 * h;
+        if (kc) {
+            const float2 t = *reinterpret_cast<const float2 *>(s + l31 * 34 + k);
+            x[c] = t.x; y[c] = t.y;
+        } else {
+            x[c] = s[k * 36 + l31];
+            y[c] = s[(k + 1) * 36 + l31];
         }
     }
 }
 
 __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
-    __shared__ float red[4][32][33];
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * OP_LDS];  // per wave: A tile, B tile; reused for the split-K combine
     int t = blockIdx.x, ji = 0;
 #pragma unroll 1
     while (ji + 1 < jobs.njobs && t >= jobs.job[ji + 1].tile_start) ++ji;
@@ -158,27 +210,39 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     const int chunk = ((K + 15) >> 4) << 2;
     const int k0 = w * chunk;
     const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
+    const int nsub = (chunk + KS - 1) / KS;  // same for the four waves (barriers below)
+    const bool akc = jb.a_kc != 0, bkc = jb.b_kc != 0;
+    float *sA = smem + (w * 2 + 0) * OP_LDS, *sB = smem + (w * 2 + 1) * OP_LDS;
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int ai = m0 + l31, bj = n0 + l31;
-    for (int kb = k0; kb < k1; kb += 4 * G_IT) {
-        float ax[G_IT], ay[G_IT], bx[G_IT], by[G_IT];
-#pragma unroll
-        for (int it = 0; it < G_IT; ++it) {
-            const int k = kb + 4 * it + 2 * h;
-            ld_pair(jb.A, jb.a_kc, ai, jb.M, jb.lda, k, k1, ax[it], ay[it]);
-            ld_pair(jb.B, jb.b_kc, bj, jb.N, jb.ldb, k, k1, bx[it], by[it]);
+    float4 pa[4], pb[4];
+    ld_tile(jb.A, akc, jb.lda, m0, jb.M, k0, k1, jb.a_ones_row, lane, pa);
+    ld_tile(jb.B, bkc, jb.ldb, n0, jb.N, k0, k1, -1, lane, pb);
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int kb = k0 + sub * KS;
+        __syncthreads();  // WAR: the previous sub-chunk's LDS reads are done
+        st_tile(sA, akc, lane, pa);
+        st_tile(sB, bkc, lane, pb);
+        __syncthreads();
+        float ax[8], ay[8], bx[8], by[8];
+        rd_tile(sA, akc, l31, h, ax, ay);
+        rd_tile(sB, bkc, l31, h, bx, by);
+        if (sub + 1 < nsub) {  // prefetch the next sub-chunk behind the MFMAs
+            ld_tile(jb.A, akc, jb.lda, m0, jb.M, kb + KS, k1, jb.a_ones_row, lane, pa);
+            ld_tile(jb.B, bkc, jb.ldb, n0, jb.N, kb + KS, k1, -1, lane, pb);
         }
 #pragma unroll
-        for (int it = 0; it < G_IT; ++it) {
-            if (kb + 4 * it < k1) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[it], bx[it], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[it], by[it], acc, 0, 0, 0);
+        for (int c = 0; c < 8; ++c) {
+            if (kb + 4 * c < k1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[c], bx[c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[c], by[c], acc, 0, 0, 0);
             }
         }
     }
-    // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // split-K combine.  D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    __syncthreads();
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
     __syncthreads();
@@ -432,47 +496,6 @@ __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K: small weight gradients (layer-1 kernels, all biases, head / W3 kernels): column sums
-//     out_k[j] = sum_r S_k[r] * M[r][j]
-// 64 columns x 4 row groups per workgroup, fixed-order LDS combine (deterministic).
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_small_wgrad(const SwJob *__restrict__ jobs, int njobs) {
-    __shared__ float s_red[4][SW_MAXK][64];
-    int ji = 0;
-    while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block_start) ++ji;
-    const SwJob &jb = jobs[ji];
-    const int cb = blockIdx.x - jb.block_start;
-    const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = cb * 64 + cj;
-    const int per = (jb.rows + 3) >> 2;
-    const int ra = rg * per, rb = (ra + per < jb.rows) ? ra + per : jb.rows;
-    float acc[SW_MAXK];
-#pragma unroll
-    for (int k = 0; k < SW_MAXK; ++k) acc[k] = 0.f;
-    if (j < jb.ncols) {
-        for (int r = ra; r < rb; ++r) {
-            const float mv = jb.M[(long long)r * jb.ldm + j];
-#pragma unroll
-            for (int k = 0; k < SW_MAXK; ++k)
-                if (k < jb.nk) {
-                    const float sv = jb.sptr[k] ? jb.sptr[k][(long long)r * jb.sstride[k]] : 1.0f;
-                    acc[k] = fmaf(sv, mv, acc[k]);
-                }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < SW_MAXK; ++k) s_red[rg][k][cj] = acc[k];
-    __syncthreads();
-    if (rg == 0 && j < jb.ncols) {
-#pragma unroll
-        for (int k = 0; k < SW_MAXK; ++k)
-            if (k < jb.nk)
-                jb.optr[k][(long long)j * jb.ostride[k]] =
-                    ((s_red[0][k][cj] + s_red[1][k][cj]) + s_red[2][k][cj]) + s_red[3][k][cj];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // K: Adam(pi) + Adam(q1,q2) + polyak, fused over the flat (padded) parameter buffer.
 // tf.train.AdamOptimizer's ApplyAdam update form; actor_learner.py:73-87.
 // ------------------------------------------------------------------------------------------
@@ -483,21 +506,32 @@ struct AdamArgs {
     long long n, n_pi;
     float lr, b1, b2, eps, pk, pk1;
 };
+__device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, float &t, float omb1, float omb2, float al,
+                                      float eps, float pk, float pk1) {
+    m = m + (g - m) * omb1;
+    v = v + (g * g - v) * omb2;
+    p = p - (m * al) / (sqrtf(v) + eps);
+    t = pk * t + pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
+}
 __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     const float one = 1.0f;
     const float al_pi = a.lr * sqrtf(one - a.opt->b2p_pi) / (one - a.opt->b1p_pi);
     const float al_q = a.lr * sqrtf(one - a.opt->b2p_q) / (one - a.opt->b1p_q);
     const float omb1 = one - a.b1, omb2 = one - a.b2;
+    const long long n4 = a.n >> 2, npi4 = a.n_pi >> 2;  // both buffers are padded to multiples of 4
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        const float g = a.g[i];
-        float m = a.m[i], v = a.v[i], p = a.p[i];
-        m = m + (g - m) * omb1;
-        v = v + (g * g - v) * omb2;
-        const float al = i < a.n_pi ? al_pi : al_q;
-        p = p - (m * al) / (sqrtf(v) + a.eps);
-        a.m[i] = m; a.v[i] = v; a.p[i] = p;
-        a.t[i] = a.pk * a.t[i] + a.pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
+    float4 *P = reinterpret_cast<float4 *>(a.p), *T = reinterpret_cast<float4 *>(a.t);
+    float4 *M = reinterpret_cast<float4 *>(a.m), *V = reinterpret_cast<float4 *>(a.v);
+    const float4 *G = reinterpret_cast<const float4 *>(a.g);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 g = G[i];
+        float4 m = M[i], v = V[i], p = P[i], t = T[i];
+        const float al = i < npi4 ? al_pi : al_q;
+        adam1(g.x, m.x, v.x, p.x, t.x, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        adam1(g.y, m.y, v.y, p.y, t.y, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        adam1(g.z, m.z, v.z, p.z, t.z, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        adam1(g.w, m.w, v.w, p.w, t.w, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        M[i] = m; V[i] = v; P[i] = p; T[i] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -535,6 +569,25 @@ struct StageArgs {
 __global__ void __launch_bounds__(256) k_stage(StageArgs a) {
     const int w = blockIdx.y;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[w]; i += gridDim.x * 256) a.dst[w][i] = a.src[w][i];
+}
+
+// N(0,1) for the three noise buffers (contiguous [3][B*act]) from a device-resident counter; one
+// workgroup so that the counter update needs no cross-block ordering.  Same generator as
+// ddrl_normal_fill / oracle/noise_oracle.normal_fill.
+__global__ void __launch_bounds__(256) k_noise3(float *e0, float *e1, float *e2, int n_each, uint32_t seed, OptState *opt) {
+    const unsigned long long base = opt->noise_ctr;
+    for (int i = threadIdx.x; i < 3 * n_each; i += 256) {
+        const unsigned long long c = base + (unsigned long long)i;
+        const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+        const uint32_t h1 = ddrl::hash3(seed, lo, 2u * hi), h2 = ddrl::hash3(seed, lo, 2u * hi + 1u);
+        const float u1 = (float)((h1 >> 8) + 1u) * (1.0f / 16777216.0f);
+        const float u2 = ddrl::u01(h2);
+        const float v = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+        const int w = i / n_each, k = i - w * n_each;
+        (w == 0 ? e0 : (w == 1 ? e1 : e2))[k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) opt->noise_ctr = base + (unsigned long long)(3 * n_each);
 }
 
 __global__ void k_copy3(const float *a, const float *b, const float *c, float *oa, float *ob, float *oc, int n) {
@@ -581,22 +634,26 @@ struct Layout {
 };
 
 static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only) {
+    // Internal layout: every kernel is followed IMMEDIATELY by its bias (so that a bias gradient
+    // is just one more row of the kernel's wgrad GEMM); each (kernel, bias) pair starts on a
+    // 16-byte boundary.
     Layout L;
     const long long o = c.obs_dim, a = c.act_dim, h1 = c.hidden1, h2 = c.hidden2;
     long long in = 0, ext = 0;
-    auto add = [&](long long &slot, long long n) {
+    auto add = [&](long long &slot, long long n, bool pad_after) {
         slot = in;
         L.segs.push_back(Seg{ext, in, n});
-        in += pad4(n);
+        in += n;
+        if (pad_after) in = pad4(in);
         ext += n;
     };
-    add(L.pi_W1, o * h1); add(L.pi_b1, h1); add(L.pi_W2, h1 * h2); add(L.pi_b2, h2);
-    add(L.pi_Wmu, h2 * a); add(L.pi_bmu, a); add(L.pi_Wls, h2 * a); add(L.pi_bls, a);
+    add(L.pi_W1, o * h1, false); add(L.pi_b1, h1, true); add(L.pi_W2, h1 * h2, false); add(L.pi_b2, h2, true);
+    add(L.pi_Wmu, h2 * a, false); add(L.pi_bmu, a, true); add(L.pi_Wls, h2 * a, false); add(L.pi_bls, a, true);
     L.n_pi_int = in;
     L.n_pi = ext;
     for (int q = 0; q < 2 && !pi_only; ++q) {
-        add(L.q_W1[q], (o + a) * h1); add(L.q_b1[q], h1); add(L.q_W2[q], h1 * h2); add(L.q_b2[q], h2);
-        add(L.q_W3[q], h2); add(L.q_b3[q], 1);
+        add(L.q_W1[q], (o + a) * h1, false); add(L.q_b1[q], h1, true); add(L.q_W2[q], h1 * h2, false); add(L.q_b2[q], h2, true);
+        add(L.q_W3[q], h2, false); add(L.q_b3[q], 1, true);
     }
     L.total_int = in;
     L.total_ext = ext;
@@ -622,19 +679,22 @@ static void gemm_add(GemmJobs &js, GemmJob j) {
 static GemmJob gemm_fwd(const float *H1, const float *W2, const float *b2, float *H2, int rows, int h1, int h2) {
     GemmJob j{};
     j.A = H1; j.B = W2; j.C = H2; j.bias = b2; j.mask = nullptr;
-    j.M = rows; j.N = h2; j.K = h1; j.lda = h1; j.ldb = h2; j.ldc = h2; j.a_kc = 1; j.b_kc = 0; j.relu = 1;
+    j.M = rows; j.N = h2; j.K = h1; j.lda = h1; j.ldb = h2; j.ldc = h2; j.a_kc = 1; j.b_kc = 0; j.relu = 1; j.a_ones_row = -1;
     return j;
 }
 static GemmJob gemm_dgrad(const float *dZ2, const float *W2, const float *H1mask, float *dZ1, int rows, int h1, int h2) {
     GemmJob j{};  // dZ1 = (dZ2 * W2^T) .* (H1 > 0)
     j.A = dZ2; j.B = W2; j.C = dZ1; j.bias = nullptr; j.mask = H1mask;
-    j.M = rows; j.N = h1; j.K = h2; j.lda = h2; j.ldb = h2; j.ldc = h1; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
+    j.M = rows; j.N = h1; j.K = h2; j.lda = h2; j.ldb = h2; j.ldc = h1; j.a_kc = 1; j.b_kc = 1; j.relu = 0; j.a_ones_row = -1;
     return j;
 }
-static GemmJob gemm_wgrad(const float *H1, const float *dZ2, float *dW2, int rows, int h1, int h2) {
-    GemmJob j{};  // dW2 = H1^T * dZ2
-    j.A = H1; j.B = dZ2; j.C = dW2; j.bias = nullptr; j.mask = nullptr;
-    j.M = h1; j.N = h2; j.K = rows; j.lda = h1; j.ldb = h2; j.ldc = h2; j.a_kc = 0; j.b_kc = 0; j.relu = 0;
+// [dW ; db] = [X | 1]^T * dZ : X[rows, nin] (row stride ldx), dZ[rows, nout] (row stride ldz) -> C[(nin+1), nout]
+// (row stride ldc); the kernel's bias lives right behind it in the internal layout.
+static GemmJob gemm_wgrad(const float *X, int ldx, int nin, const float *dZ, int ldz, int nout, float *C, int ldc, int rows) {
+    GemmJob j{};
+    j.A = X; j.B = dZ; j.C = C; j.bias = nullptr; j.mask = nullptr;
+    j.M = nin + 1; j.N = nout; j.K = rows; j.lda = ldx; j.ldb = ldz; j.ldc = ldc; j.a_kc = 0; j.b_kc = 0; j.relu = 0;
+    j.a_ones_row = nin;
     return j;
 }
 
@@ -649,7 +709,7 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
     DDRL_REQUIRE(c != nullptr, "config is NULL");
     DDRL_REQUIRE(c->obs_dim > 0 && c->act_dim > 0 && c->hidden1 > 0 && c->hidden2 > 0 && c->batch > 0, "dims must be positive");
     DDRL_REQUIRE(c->act_dim <= MAXA, "act_dim > 8 unsupported");
-    DDRL_REQUIRE(c->obs_dim + c->act_dim + 1 <= SW_MAXK && c->obs_dim + c->act_dim <= 40, "obs_dim + act_dim too large for the layer-1 kernels (<= 11)");
+    DDRL_REQUIRE(c->obs_dim + c->act_dim <= 40, "obs_dim + act_dim > 40 unsupported by the layer-1 kernel");
     return DDRL_OK;
 }
 
@@ -660,16 +720,15 @@ struct ddrl_sac1 {
     int device;
     ddrl_sac1_config_t cfg;
     Layout L;
+    float *slab;
     float *main_p, *target_p, *m, *v, *grad;
     float *x, *x2, *a, *r, *d, *e0, *e1, *e2;
-    float *H1, *H2, *dZ2, *dZ1;
+    float *H1, *H2, *dZ2, *dZ1, *xa;
     float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o, *dq, *dhead, *loss_part, *losses;
     OptState *opt;
     Seg *segs_d;
-    SwJob *sw_d;
-    int sw_njobs, sw_blocks;
     L1Jobs l1a, l1b;
-    GemmJobs g_fa, g_fb, g_bq, g_bpi;
+    GemmJobs g_fa, g_fb, g_bq, g_bpi, g_last;
     RowsA ra;
     RowsB rb;
     RowsC rc;
@@ -678,11 +737,7 @@ struct ddrl_sac1 {
 };
 
 static int sac1_free(ddrl_sac1 *h) {
-    float **ps[] = {&h->main_p, &h->target_p, &h->m, &h->v, &h->grad, &h->x, &h->x2, &h->a, &h->r, &h->d,
-                    &h->e0, &h->e1, &h->e2, &h->H1, &h->H2, &h->dZ2, &h->dZ1, &h->act0, &h->act2, &h->logp0, &h->logp1,
-                    &h->save0, &h->q1o, &h->q2o, &h->dq, &h->dhead, &h->loss_part, &h->losses};
-    for (auto p : ps) (void)hipFree(*p);
-    (void)hipFree(h->opt); (void)hipFree(h->segs_d); (void)hipFree(h->sw_d);
+    (void)hipFree(h->slab);
     delete h;
     return DDRL_OK;
 }
@@ -720,25 +775,36 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     const Layout &L = h->L;
     const int B = cfg->batch, o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
     const size_t NT = (size_t)L.total_int;
-    hipError_t e = hipSuccess;
-#define ALLOC(ptr, cnt) if (e == hipSuccess) e = dev_alloc(&h->ptr, (size_t)(cnt))
+    // ONE slab for every buffer of the learner (parameters, optimizer state, activations, job
+    // tables): a single large allocation is mapped with large page fragments, so the ~30 buffers a
+    // stage touches share a handful of TLB entries instead of missing on one 4 KB page each.
+    h->rows_b_blocks = (B + 3) / 4;
+    size_t slab_floats = 0;
+    auto reserve = [&](size_t cnt) { size_t off = slab_floats; slab_floats += (cnt + 63) & ~(size_t)63; return off; };  // 256-B aligned
+    struct Item { float **p; size_t off; };
+    std::vector<Item> items;
+#define ALLOC(ptr, cnt) items.push_back(Item{&h->ptr, reserve((size_t)(cnt))})
     ALLOC(main_p, NT); ALLOC(target_p, NT); ALLOC(m, NT); ALLOC(v, NT); ALLOC(grad, NT);
     ALLOC(x, B * o); ALLOC(x2, B * o); ALLOC(a, B * a); ALLOC(r, B); ALLOC(d, B);
     ALLOC(e0, B * a); ALLOC(e1, B * a); ALLOC(e2, B * a);
     ALLOC(H1, (size_t)NEVAL * B * h1); ALLOC(H2, (size_t)NEVAL * B * h2);
-    ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1);
+    ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1); ALLOC(xa, (size_t)B * (o + a));
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
     ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(dq, 2 * B); ALLOC(dhead, (size_t)B * 2 * a);
-    h->rows_b_blocks = (B + 3) / 4;
     ALLOC(loss_part, (size_t)h->rows_b_blocks * 3); ALLOC(losses, 4);
-    if (e == hipSuccess) e = dev_alloc(&h->opt, 1);
-    if (e == hipSuccess) e = dev_alloc(&h->segs_d, L.segs.size());
 #undef ALLOC
+    const size_t opt_off = reserve((sizeof(OptState) + 3) / 4);
+    const size_t segs_off = reserve((L.segs.size() * sizeof(Seg) + 3) / 4);
+    hipError_t e = hipMalloc((void **)&h->slab, slab_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->slab, 0, slab_floats * sizeof(float));
     if (e != hipSuccess) {
-        ddrl::set_error("hipMalloc failed in ddrl_sac1_create: %s", hipGetErrorString(e));
+        ddrl::set_error("hipMalloc of %zu bytes failed in ddrl_sac1_create: %s", slab_floats * sizeof(float), hipGetErrorString(e));
         sac1_free(h);
         return DDRL_ERR_NOMEM;
     }
+    for (auto &it : items) *it.p = h->slab + it.off;
+    h->opt = reinterpret_cast<OptState *>(h->slab + opt_off);
+    h->segs_d = reinterpret_cast<Seg *>(h->slab + segs_off);
     DDRL_HIP_CHECK(hipMemcpy(h->segs_d, L.segs.data(), L.segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
     rc = reset_opt(h, nullptr);
     if (rc != DDRL_OK) { sac1_free(h); return rc; }
@@ -747,7 +813,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     const long long BH1 = (long long)B * h1, BH2 = (long long)B * h2;
     // ---- layer-1 jobs.  evals: 0 pi(x) 1 pi(x2) 2 piT(x2) 3 q1(x,a) 4 q2(x,a) | 5 q1(x,pi) 6 q1T(x2,piT) 7 q2T(x2,piT)
     auto l1 = [&](const float *in0, int d0, const float *in1, int d1, const float *W, const float *b, int ev) {
-        return L1Job{in0, in1, W, b, h->H1 + ev * BH1, d0, d1, B, h1};
+        return L1Job{in0, in1, W, b, h->H1 + ev * BH1, nullptr, d0, d1, B, h1};
     };
     h->l1a.njobs = 5;
     h->l1a.job[0] = l1(h->x, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 0);
@@ -755,6 +821,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     h->l1a.job[2] = l1(h->x2, o, nullptr, 0, Pt + L.pi_W1, Pt + L.pi_b1, 2);
     h->l1a.job[3] = l1(h->x, o, h->a, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 3);
     h->l1a.job[4] = l1(h->x, o, h->a, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 4);
+    h->l1a.job[3].aug_out = h->xa;  // [x | a] rows, the A operand of the Q layer-1 wgrads
     h->l1b.njobs = 3;
     h->l1b.job[0] = l1(h->x, o, h->act0, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 5);
     h->l1b.job[1] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[0], Pt + L.q_b1[0], 6);
@@ -771,15 +838,26 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     gemm_add(h->g_fb, fwd(Pm, L.q_W2[0], L.q_b2[0], 5));
     gemm_add(h->g_fb, fwd(Pt, L.q_W2[0], L.q_b2[0], 6));
     gemm_add(h->g_fb, fwd(Pt, L.q_W2[1], L.q_b2[1], 7));
-    // ---- backward layer-2 GEMMs, Q paths: dZ2 slots 0 q1(x,a) 1 q2(x,a) 2 q1(x,pi); dZ1 same slots
-    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 2 * BH2, Pm + L.q_W2[0], h->H1 + 5 * BH1, h->dZ1 + 2 * BH1, B, h1, h2));  // first: pi waits on it
+    // ---- backward GEMM launches.  dZ2 / dZ1 slots: 0 q1(x,a), 1 q2(x,a), 2 q1(x,pi), 3 pi.
+    // Every bias gradient rides as the "ones row" of its kernel's wgrad.
+    float *G = h->grad;
+    // launch "bwd Q": needs dZ2[0..2], dq
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 2 * BH2, Pm + L.q_W2[0], h->H1 + 5 * BH1, h->dZ1 + 2 * BH1, B, h1, h2));
     gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 0 * BH2, Pm + L.q_W2[0], h->H1 + 3 * BH1, h->dZ1 + 0 * BH1, B, h1, h2));
     gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 1 * BH2, Pm + L.q_W2[1], h->H1 + 4 * BH1, h->dZ1 + 1 * BH1, B, h1, h2));
-    gemm_add(h->g_bq, gemm_wgrad(h->H1 + 3 * BH1, h->dZ2 + 0 * BH2, h->grad + L.q_W2[0], B, h1, h2));
-    gemm_add(h->g_bq, gemm_wgrad(h->H1 + 4 * BH1, h->dZ2 + 1 * BH2, h->grad + L.q_W2[1], B, h1, h2));
-    // ---- policy trunk backward (slot 3)
+    for (int q = 0; q < 2; ++q) {
+        gemm_add(h->g_bq, gemm_wgrad(h->H1 + (3 + q) * BH1, h1, h1, h->dZ2 + q * BH2, h2, h2, G + L.q_W2[q], h2, B));  // W2, b2
+        gemm_add(h->g_bq, gemm_wgrad(h->H2 + (3 + q) * BH2, h2, h2, h->dq + (long long)q * B, 1, 1, G + L.q_W3[q], 1, B));  // W3, b3
+    }
+    // launch "bwd pi": needs dZ2[3], dhead (k_rows_c) and dZ1[0..1] (launch above)
     gemm_add(h->g_bpi, gemm_dgrad(h->dZ2 + 3 * BH2, Pm + L.pi_W2, h->H1 + 0 * BH1, h->dZ1 + 3 * BH1, B, h1, h2));
-    gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, h->dZ2 + 3 * BH2, h->grad + L.pi_W2, B, h1, h2));
+    gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, h1, h1, h->dZ2 + 3 * BH2, h2, h2, G + L.pi_W2, h2, B));           // W2, b2
+    gemm_add(h->g_bpi, gemm_wgrad(h->H2, h2, h2, h->dhead, 2 * a, a, G + L.pi_Wmu, a, B));                                // Wmu, bmu
+    gemm_add(h->g_bpi, gemm_wgrad(h->H2, h2, h2, h->dhead + a, 2 * a, a, G + L.pi_Wls, a, B));                            // Wls, bls
+    for (int q = 0; q < 2; ++q)
+        gemm_add(h->g_bpi, gemm_wgrad(h->xa, o + a, o + a, h->dZ1 + q * BH1, h1, h1, G + L.q_W1[q], h1, B));             // Q W1, b1
+    // launch "last": needs dZ1[3]
+    gemm_add(h->g_last, gemm_wgrad(h->x, o, o, h->dZ1 + 3 * BH1, h1, h1, G + L.pi_W1, h1, B));                             // pi W1, b1
 
     // ---- row kernels
     h->ra = RowsA{h->H2, net_pi(Pm, L), net_pi(Pt, L), net_q(Pm, L, 0), net_q(Pm, L, 1), h->e0, h->e1, h->e2,
@@ -793,73 +871,6 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak)};
 
-    // ---- small weight-gradient jobs
-    std::vector<SwJob> sw;
-    int blocks = 0;
-    auto sw_push = [&](SwJob j) {
-        j.block_start = blocks;
-        j.nblocks = (j.ncols + 63) / 64;
-        blocks += j.nblocks;
-        sw.push_back(j);
-    };
-    float *G = h->grad;
-    {   // pi: W1 + b1 from dZ1 slot 3
-        SwJob j{}; j.M = h->dZ1 + 3 * BH1; j.ldm = h1; j.ncols = h1; j.rows = B; j.nk = o + 1;
-        for (int k = 0; k < o; ++k) { j.sptr[k] = h->x + k; j.sstride[k] = o; j.optr[k] = G + L.pi_W1 + (long long)k * h1; j.ostride[k] = 1; }
-        j.sptr[o] = nullptr; j.sstride[o] = 0; j.optr[o] = G + L.pi_b1; j.ostride[o] = 1;
-        sw_push(j);
-    }
-    {   // pi: b2
-        SwJob j{}; j.M = h->dZ2 + 3 * BH2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 1;
-        j.sptr[0] = nullptr; j.optr[0] = G + L.pi_b2; j.ostride[0] = 1;
-        sw_push(j);
-    }
-    {   // pi: head kernels Wmu[h2,act], Wls[h2,act] from dhead[B,2act] and H2 eval 0
-        SwJob j{}; j.M = h->H2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 2 * a;
-        for (int c = 0; c < 2 * a; ++c) {
-            j.sptr[c] = h->dhead + c; j.sstride[c] = 2 * a;
-            j.optr[c] = G + (c < a ? L.pi_Wmu + c : L.pi_Wls + (c - a)); j.ostride[c] = a;
-        }
-        sw_push(j);
-    }
-    for (int part = 0; part < 2; ++part) {  // pi: head biases
-        SwJob j{}; j.M = h->dhead + part * a; j.ldm = 2 * a; j.ncols = a; j.rows = B; j.nk = 1;
-        j.sptr[0] = nullptr; j.optr[0] = G + (part == 0 ? L.pi_bmu : L.pi_bls); j.ostride[0] = 1;
-        sw_push(j);
-    }
-    for (int q = 0; q < 2; ++q) {
-        {   // W1 + b1 from dZ1 slot q, inputs [x | a]
-            SwJob j{}; j.M = h->dZ1 + q * BH1; j.ldm = h1; j.ncols = h1; j.rows = B; j.nk = o + a + 1;
-            for (int k = 0; k < o; ++k) { j.sptr[k] = h->x + k; j.sstride[k] = o; }
-            for (int k = 0; k < a; ++k) { j.sptr[o + k] = h->a + k; j.sstride[o + k] = a; }
-            for (int k = 0; k < o + a; ++k) { j.optr[k] = G + L.q_W1[q] + (long long)k * h1; j.ostride[k] = 1; }
-            j.sptr[o + a] = nullptr; j.optr[o + a] = G + L.q_b1[q]; j.ostride[o + a] = 1;
-            sw_push(j);
-        }
-        {   // b2
-            SwJob j{}; j.M = h->dZ2 + q * BH2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 1;
-            j.sptr[0] = nullptr; j.optr[0] = G + L.q_b2[q]; j.ostride[0] = 1;
-            sw_push(j);
-        }
-        {   // W3 from dq[q] and H2 eval 3+q
-            SwJob j{}; j.M = h->H2 + (3 + q) * BH2; j.ldm = h2; j.ncols = h2; j.rows = B; j.nk = 1;
-            j.sptr[0] = h->dq + (long long)q * B; j.sstride[0] = 1; j.optr[0] = G + L.q_W3[q]; j.ostride[0] = 1;
-            sw_push(j);
-        }
-        {   // b3
-            SwJob j{}; j.M = h->dq + (long long)q * B; j.ldm = 1; j.ncols = 1; j.rows = B; j.nk = 1;
-            j.sptr[0] = nullptr; j.optr[0] = G + L.q_b3[q]; j.ostride[0] = 1;
-            sw_push(j);
-        }
-    }
-    h->sw_njobs = (int)sw.size();
-    h->sw_blocks = blocks;
-    if (hipMalloc((void **)&h->sw_d, sw.size() * sizeof(SwJob)) != hipSuccess) {
-        ddrl::set_error("hipMalloc failed for job tables");
-        sac1_free(h);
-        return DDRL_ERR_NOMEM;
-    }
-    DDRL_HIP_CHECK(hipMemcpy(h->sw_d, sw.data(), sw.size() * sizeof(SwJob), hipMemcpyHostToDevice));
     *out = h;
     return DDRL_OK;
 }
@@ -927,34 +938,98 @@ int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *s
     return DDRL_OK;
 }
 
+// One stage of the update.  Stage ids as documented for ddrl_sac1_stage_time in include/ddrl.h.
+static void launch_stage(ddrl_sac1 *h, int stage, hipStream_t s) {
+    const ddrl_sac1_config_t &c = h->cfg;
+    const int B = c.batch;
+    const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
+    switch (stage) {
+        case 1: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a.njobs), 256, 0, s>>>(h->l1a); break;
+        case 2: k_gemm<<<h->g_fa.total_tiles, 256, 0, s>>>(h->g_fa); break;
+        case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra); break;
+        case 4: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1b.njobs), 256, 0, s>>>(h->l1b); break;
+        case 5: k_gemm<<<h->g_fb.total_tiles, 256, 0, s>>>(h->g_fb); break;
+        case 6: k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb); break;
+        case 7: k_gemm<<<h->g_bq.total_tiles, 256, 0, s>>>(h->g_bq); break;
+        case 8: k_rows_c<<<(B + 3) / 4, 256, 0, s>>>(h->rc); break;
+        case 9: k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi); break;
+        case 10: k_gemm<<<h->g_last.total_tiles, 256, 0, s>>>(h->g_last); break;
+        case 11: {
+            long long blocks = (h->L.total_int / 4 + 255) / 256;
+            if (blocks > 1024) blocks = 1024;
+            k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
+            break;
+        }
+        default: break;
+    }
+}
+
 static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, const float *acts, const float *rews,
                         const float *done, const float *e0, const float *e1, const float *e2, float *losses_d, float *q1_d,
                         float *q2_d, float *logp_d, hipStream_t s) {
     const ddrl_sac1_config_t &c = h->cfg;
     const int B = c.batch;
-    StageArgs st{};
     const float *src[8] = {obs1, obs2, acts, rews, done, e0, e1, e2};
     float *dst[8] = {h->x, h->x2, h->a, h->r, h->d, h->e0, h->e1, h->e2};
-    const int n[8] = {B * c.obs_dim, B * c.obs_dim, B * c.act_dim, B, B, B * c.act_dim, B * c.act_dim, B * c.act_dim};
-    for (int i = 0; i < 8; ++i) { st.src[i] = src[i]; st.dst[i] = dst[i]; st.n[i] = n[i]; }
-    k_stage<<<dim3((unsigned)((B * c.obs_dim + 255) / 256), 8), 256, 0, s>>>(st);
-    const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
-    k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a.njobs), 256, 0, s>>>(h->l1a);
-    k_gemm<<<h->g_fa.total_tiles, 256, 0, s>>>(h->g_fa);
-    k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra);
-    k_l1<<<dim3(l1grid.x, l1grid.y, h->l1b.njobs), 256, 0, s>>>(h->l1b);
-    k_gemm<<<h->g_fb.total_tiles, 256, 0, s>>>(h->g_fb);
-    k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb);
-    k_gemm<<<h->g_bq.total_tiles, 256, 0, s>>>(h->g_bq);
-    k_rows_c<<<(B + 3) / 4, 256, 0, s>>>(h->rc);
-    k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi);
-    k_small_wgrad<<<h->sw_blocks, 256, 0, s>>>(h->sw_d, h->sw_njobs);
+    bool in_place = true;
+    for (int i = 0; i < 8; ++i) in_place = in_place && (src[i] == dst[i]);
+    if (!in_place) {  // callers that gather straight into ddrl_sac1_input_buffers skip this copy (stage 0)
+        StageArgs st{};
+        const int n[8] = {B * c.obs_dim, B * c.obs_dim, B * c.act_dim, B, B, B * c.act_dim, B * c.act_dim, B * c.act_dim};
+        for (int i = 0; i < 8; ++i) { st.src[i] = src[i]; st.dst[i] = dst[i]; st.n[i] = n[i]; }
+        k_stage<<<dim3((unsigned)((B * c.obs_dim + 255) / 256), 8), 256, 0, s>>>(st);
+    }
+    for (int stage = 1; stage <= 10; ++stage) launch_stage(h, stage, s);
     DDRL_LAUNCH_CHECK();
     if (losses_d) DDRL_HIP_CHECK(hipMemcpyAsync(losses_d, h->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (q1_d || q2_d || logp_d) {
         k_copy3<<<(B + 255) / 256, 256, 0, s>>>(h->q1o, h->q2o, h->logp0, q1_d, q2_d, logp_d, B);
         DDRL_LAUNCH_CHECK();
     }
+    return DDRL_OK;
+}
+
+static int launch_apply(ddrl_sac1 *h, hipStream_t s) {
+    launch_stage(h, 11, s);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_sac1_input_buffers(ddrl_sac1_t *h, float **bufs_h) {
+    DDRL_REQUIRE(h != nullptr && bufs_h != nullptr, "NULL pointer");
+    float *b[8] = {h->x, h->x2, h->a, h->r, h->d, h->e0, h->e1, h->e2};
+    for (int i = 0; i < 8; ++i) bufs_h[i] = b[i];
+    return DDRL_OK;
+}
+
+int ddrl_sac1_batch(ddrl_sac1_t *h) { return h ? h->cfg.batch : DDRL_ERR_BAD_ARG; }
+
+int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    k_noise3<<<1, 256, 0, ddrl::as_stream(stream)>>>(h->e0, h->e1, h->e2, h->cfg.batch * h->cfg.act_dim, seed, h->opt);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_sac1_stage_time(ddrl_sac1_t *h, int stage, int reps, float *ms_per_launch_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr && ms_per_launch_h != nullptr, "NULL pointer");
+    DDRL_REQUIRE(stage >= 1 && stage <= 10 && reps > 0, "stage must be in [1,10] (idempotent stages), reps > 0");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    hipEvent_t e0, e1;
+    DDRL_HIP_CHECK(hipEventCreate(&e0));
+    DDRL_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_stage(h, stage, s);
+    DDRL_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) launch_stage(h, stage, s);
+    DDRL_HIP_CHECK(hipEventRecord(e1, s));
+    DDRL_LAUNCH_CHECK();
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    DDRL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch_h = ms / (float)reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return DDRL_OK;
 }
 
@@ -972,11 +1047,7 @@ int ddrl_sac1_compute_grads(ddrl_sac1_t *h, const float *obs1_d, const float *ob
 int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream) {
     DDRL_REQUIRE(h != nullptr, "handle is NULL");
     ddrl::DeviceGuard g(h->device);
-    long long blocks = (h->L.total_int + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    k_adam_polyak<<<(unsigned)blocks, 256, 0, ddrl::as_stream(stream)>>>(h->ad);
-    DDRL_LAUNCH_CHECK();
-    return DDRL_OK;
+    return launch_apply(h, ddrl::as_stream(stream));
 }
 
 int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
@@ -1064,7 +1135,7 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     const Layout &L = h->L;
     L1Jobs l1{};
     l1.njobs = 1;
-    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, c.obs_dim, 0, (int)n, c.hidden1};
+    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, nullptr, c.obs_dim, 0, (int)n, c.hidden1};
     k_l1<<<dim3((c.hidden1 + 255) / 256, (unsigned)((n + L1_ROWS - 1) / L1_ROWS), 1), 256, 0, s>>>(l1);
     GemmJobs gj{};
     gemm_add(gj, gemm_fwd(h->H1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, (int)n, c.hidden1, c.hidden2));

@@ -1,0 +1,302 @@
+"""worker_rollout / worker_train / worker_test with the reference's call shapes.
+
+Mirrors:
+  example/dsac.py:76-130    worker_rollout(ps, replay_buffer, args)
+  example/dsac.py:133-150   worker_train(ps, replay_buffer, args)
+  example/dsac.py:153-177   worker_test(ps, start_time)            (here: explicit args)
+  algos/sac1/sac1.py:133-154,157-213,216-252   the SAC1 flavours (opt, index; a_l_ratio throttle)
+
+`ps` / `replay_buffer` are actor handles (`remote.py` shim or Ray): methods are invoked as
+`handle.method.remote(...)` and awaited with `get`.  Two execution styles share these semantics:
+
+  * reference style (one env per worker, one transition per store RPC) — `worker_rollout`,
+    `worker_train`: exactly the reference's event order (pinned by tests/test_workers_cpu.py
+    against traces recorded from the reference's own functions);
+  * device style — `rollout_loop_device`, `train_loop_device`: `opt.num_envs` environments per
+    worker stepped by one kernel, `store_batch` of num_envs transitions, batched policy forward,
+    learner sampling straight out of HBM.  Per-env semantics are those of num_envs independent
+    reference workers, except that fresh weights are adopted at the next vector step after a
+    push (the reference adopts them at each worker's episode end) — never staler than the
+    reference.
+"""
+import time
+
+from . import remote as _ray
+
+
+def _remote(method, *args):
+    """handle.method.remote(*args) for actor handles; direct call for plain objects."""
+    r = getattr(method, "remote", None)
+    return r(*args) if r is not None else method(*args)
+
+
+def _get(x):
+    return _ray.get(x)
+
+
+def _default_env(name, args):
+    from . import env as _env
+    return _env.make(name, seed=int(getattr(args, "seed", 0)), max_ep_len=int(args.max_ep_len))
+
+
+def _stop(args):
+    ev = getattr(args, "stop_event", None)
+    return ev is not None and ev.is_set()
+
+
+# ------------------------------------------------------------------------------------------
+# example/dsac.py flavour
+# ------------------------------------------------------------------------------------------
+def worker_rollout(ps, replay_buffer, args, make_env=None, make_agent=None):
+    """example/dsac.py:76-130."""
+    if make_env is None:
+        make_env = lambda name: _default_env(name, args)
+    if make_agent is None:
+        from .agent import Actor
+        make_agent = lambda a: Actor(a, job="worker")
+    env = make_env(args.env)
+    o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+    total_steps = args.steps_per_epoch * args.epochs
+
+    agent = make_agent(args)
+    keys = agent.get_weights()[0]
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+
+    for t in range(total_steps):
+        if _stop(args):
+            break
+        # uniform-random actions for the first start_steps+1 steps (strict '>': dsac.py:96)
+        if t > args.start_steps:
+            a = agent.get_action(o)
+        else:
+            a = env.action_space.sample()
+        o2, r, d, _ = env.step(a)
+        ep_ret += r
+        ep_len += 1
+        # hitting the time horizon is not a terminal state (dsac.py:109)
+        d = False if ep_len == args.max_ep_len else d
+        _remote(replay_buffer.store, o, a, r, o2, d)  # fire-and-forget (dsac.py:112)
+        o = o2
+        if d or (ep_len == args.max_ep_len):
+            o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+            weights = _get(_remote(ps.pull, keys))
+            agent.set_weights(keys, weights)
+
+
+def worker_train(ps, replay_buffer, args, make_agent=None):
+    """example/dsac.py:133-150: pull, then `train; push every 300th update` forever."""
+    if make_agent is None:
+        from .agent import Learner
+
+        class _Model(Learner):  # example/model.py:92-101: train = sample_batch RPC + one step
+            def train(self, replay_buffer, args):
+                batch = _get(_remote(replay_buffer.sample_batch, args.batch_size))
+                return super().train(batch)
+        make_agent = lambda a: _Model(a, job="learner")
+    agent = make_agent(args)
+    keys = agent.get_weights()[0]
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+
+    push_freq = int(getattr(args, "push_freq", 300))
+    max_updates = getattr(args, "max_updates", None)
+    cnt = 1
+    while True:
+        agent.train(replay_buffer, args)
+        if cnt % push_freq == 0:
+            keys, values = agent.get_weights()
+            _remote(ps.push, keys, values)
+        if (max_updates is not None and cnt >= max_updates) or _stop(args):
+            return cnt
+        cnt += 1
+
+
+def worker_test(ps, args, start_time=None, n=10, make_env=None, make_agent=None, log=print, max_rounds=None):
+    """example/dsac.py:153-177: pull, run n deterministic episodes, log, repeat."""
+    if make_env is None:
+        make_env = lambda name: _default_env(name, args)
+    if make_agent is None:
+        from .agent import Actor
+        make_agent = lambda a: Actor(a, job="main")
+    start_time = time.time() if start_time is None else start_time
+    agent = make_agent(args)
+    keys = agent.get_weights()[0]
+    test_env = make_env(args.env)
+    rounds, last = 0, None
+    while True:
+        weights = _get(_remote(ps.pull, keys))
+        agent.set_weights(keys, weights)
+        last = agent.test(test_env, None, n)
+        log("AverageTestEpRet %.3f  Time %.1f" % (last, time.time() - start_time))
+        rounds += 1
+        if (max_rounds is not None and rounds >= max_rounds) or _stop(args):
+            return last
+
+
+# ------------------------------------------------------------------------------------------
+# algos/sac1/sac1.py flavour (opt, index; throttle on steps / sample_times)
+# ------------------------------------------------------------------------------------------
+def worker_rollout_sac1(ps, replay_buffer, opt, worker_index, make_env=None, make_agent=None, sleep=time.sleep):
+    """algos/sac1/sac1.py:157-213."""
+    if make_env is None:
+        make_env = lambda name: _default_env(name, opt)
+    if make_agent is None:
+        from .agent import Actor
+        make_agent = lambda o_: Actor(o_, job="worker")
+    env = make_env(opt.env_name)
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+
+    t = 0
+    while not _stop(opt):
+        if t > opt.start_steps:
+            a = agent.get_action(o)
+        else:
+            a = env.action_space.sample()
+        t += 1
+        o2, r, d, _ = env.step(a)
+        ep_ret += r
+        ep_len += 1
+        d = False if ep_len == opt.max_ep_len else d
+        _remote(replay_buffer.store, o, a, r, o2, d)
+        o = o2
+        if d or (ep_len == opt.max_ep_len):
+            # actor/learner ratio gate (sac1.py:203-207)
+            sample_times, steps, _ = _get(_remote(replay_buffer.get_counts))
+            while sample_times > 0 and steps / sample_times > opt.a_l_ratio:
+                sample_times, steps, _ = _get(_remote(replay_buffer.get_counts))
+                sleep(0.1)
+            weights = _get(_remote(ps.pull, keys))
+            agent.set_weights(keys, weights)
+            o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+
+
+def worker_train_sac1(ps, replay_buffer, opt, learner_index, make_agent=None):
+    """algos/sac1/sac1.py:133-154.  The reference hides the sample RPC behind a `Cache` helper
+    process (depth-10 batch queue, depth-5 weight queue, sac1.py:103-130); with replay and learner
+    in the same HBM the sample is one kernel on the learner's stream and the prefetch queue has
+    nothing left to hide."""
+    if make_agent is None:
+        from .agent import Learner
+        make_agent = lambda o_: Learner(o_, job="learner")
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+    push_freq = int(getattr(opt, "push_freq", 300))
+    max_updates = getattr(opt, "max_updates", None)
+    cnt = 1
+    while True:
+        batch = _get(_remote(replay_buffer.sample_batch, opt.batch_size))
+        agent.train(batch)
+        if cnt % push_freq == 0:
+            keys, values = agent.get_weights()
+            _remote(ps.push, keys, values)
+        if (max_updates is not None and cnt >= max_updates) or _stop(opt):
+            return cnt
+        cnt += 1
+
+
+# ------------------------------------------------------------------------------------------
+# device style: everything stays in HBM (plain objects, not actor handles)
+# ------------------------------------------------------------------------------------------
+class RolloutDevice:
+    """State of one vectorised rollout worker: `opt.num_envs` envs, one Actor, a local replay
+    shard and a ParameterServer (or a comm.ParamBroadcast on multi-GPU runs)."""
+
+    def __init__(self, ps, replay_buffer, opt, worker_index=0):
+        import torch
+        from .agent import Actor
+        from .env import VecLunarLander
+        self.ps, self.rb, self.opt = ps, replay_buffer, opt
+        self.env = VecLunarLander(opt.num_envs, seed=int(opt.seed) + 1000003 * int(worker_index),
+                                  max_ep_len=opt.max_ep_len)
+        self.actor = Actor(opt, job="worker", max_rows=opt.num_envs)
+        self.span = ps.span(self.actor.keys) if ps is not None else None
+        self.version = -1
+        self.t = 0
+        self.o = torch.empty_like(self.env.obs)
+        self.act = torch.empty(opt.num_envs, 2, dtype=torch.float32, device=self.env.device)
+        self.pull()
+
+    def pull(self):
+        """ps.pull(keys) + agent.set_weights when the server has something newer."""
+        if self.ps is None or self.ps.version == self.version:
+            return False
+        self.version = self.ps.version
+        if self.span is not None:
+            self.actor.set_weights_flat(self.ps.pull_flat(*self.span))
+        else:
+            self.actor.set_weights(self.actor.keys, self.ps.pull_device(self.actor.keys))
+        return True
+
+    def step(self):
+        """One vector step = num_envs reference iterations (dsac.py:96-130)."""
+        env = self.env
+        self.o.copy_(env.obs)
+        if self.t > self.opt.start_steps:
+            self.actor.get_actions(self.o, out=self.act)
+        else:
+            env.sample_actions(out=self.act)
+        o2, r, d, _, _ = env.step(self.act)
+        self.rb.store_batch(self.o, self.act, r, o2, d)
+        self.t += 1
+        self.pull()
+
+
+class TrainDevice:
+    """State of one device-resident learner worker: the hot loop of sac1.py:146-151
+    (`batch = sample; agent.train(batch); push every push_freq-th update`) with the sample/train
+    iterations enqueued by ddrl_loop_run (graph-captured, no host work per update)."""
+
+    def __init__(self, ps, replay_buffer, opt, learner_index=0, updates_per_graph=16, on_push=None):
+        import ctypes
+        from . import _lib
+        from .agent import Learner
+        self.ps, self.rb, self.opt = ps, replay_buffer, opt
+        self.agent = Learner(opt, job="learner")
+        self.on_push = on_push  # multi-GPU: comm.ParamBroadcast.sync
+        if ps is not None:
+            span = ps.span(self.agent.keys)
+            if span is not None:
+                self.agent.set_weights_flat(ps.pull_flat(*span))
+            else:
+                self.agent.set_weights(self.agent.keys, ps.pull_device(self.agent.keys))
+        self.cnt = 1
+        self.push_freq = int(getattr(opt, "push_freq", 300))
+        self._lib, self._libmod = _lib.load(), _lib
+        h = ctypes.c_void_p()
+        seed = (int(getattr(opt, "seed", 0)) * 2654435761 + 97 * int(learner_index) + 1) & 0xFFFFFFFF
+        _lib.check(self._lib.ddrl_loop_create(ctypes.byref(h), self.agent._h, replay_buffer._h, int(updates_per_graph), seed))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_loop_destroy(h)
+
+    def push(self):
+        flat = self.agent.get_weights_flat()
+        if self.ps is not None:
+            self.ps.push_flat(flat)
+        if self.on_push is not None:
+            self.on_push(flat)
+
+    def run(self, n_updates):
+        """n_updates iterations of sample -> train, pushing after every push_freq-th update."""
+        left = int(n_updates)
+        while left > 0:
+            to_push = self.push_freq - ((self.cnt - 1) % self.push_freq)  # updates until cnt % push_freq == 0
+            k = min(left, to_push)
+            self._libmod.check(self._lib.ddrl_loop_run(self._h, k, self._libmod.stream_ptr()))
+            self.cnt += k
+            left -= k
+            if (self.cnt - 1) % self.push_freq == 0:
+                self.push()
+
+    def step(self):
+        self.run(1)

@@ -199,6 +199,44 @@ int ddrl_sac1_compute_grads(ddrl_sac1_t *h, const float *obs1_d, const float *ob
                             void *stream);
 int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream);
 
+/* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
+ * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of
+ * device pointers).  Passing exactly these pointers to ddrl_sac1_step / compute_grads skips the
+ * staging copy, so ddrl_replay_sample can gather straight into the learner (zero-copy). */
+int ddrl_sac1_input_buffers(ddrl_sac1_t *h, float **bufs_h);
+/* The batch size the learner was created with. */
+int ddrl_sac1_batch(ddrl_sac1_t *h);
+/* Fill the three internal noise buffers with N(0,1) from the counter generator
+ * (hash(seed, counter+i)); the counter lives on the device and advances by 3*B*act per call, so
+ * the call can be captured in a hipGraph.  Stand-in for tf.random_normal (core.py:77). */
+int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream);
+/* Roofline accounting (bench.py): launch one stage of the update `reps` times back to back on
+ * `stream` between two HIP events (after 3 untimed launches) and return the mean milliseconds
+ * per launch (host output); synchronises `stream`.  The stages read the buffers left by the last
+ * ddrl_sac1_step and are idempotent.  Stage ids (launch order of one update):
+ * 1 layer1(A: 5 nets) 2 gemm fwd(A) 3 heads(A) 4 layer1(B: 3 nets) 5 gemm fwd(B) 6 heads(B)+losses
+ * 7 gemm bwd(Q: 3 dgrad + 4 wgrad) 8 policy-head bwd 9 gemm bwd(pi: 1 dgrad + 5 wgrad)
+ * 10 gemm (pi layer-1 wgrad).  [0 = input staging copy, 11 = adam+polyak: not idempotent] */
+#define DDRL_SAC1_STAGES 12
+int ddrl_sac1_stage_time(ddrl_sac1_t *h, int stage, int reps, float *ms_per_launch_h, void *stream);
+
+/* ===================================================================================== */
+/* Learner hot loop — replaces the body of worker_train                                    */
+/*   `while True: batch = sample_batch(B); agent.train(batch)`                              */
+/*   (algos/sac1/sac1.py:146-148; example/dsac.py:142-144 + example/model.py:92-101)        */
+/* sample (MT19937 indices + gather, straight into the learner's buffers) -> noise -> update, */
+/* n times, with no host work per update: the sequence for `updates_per_graph` updates is   */
+/* captured once into a hipGraph (all cursors, RNG state and Adam state are device-resident) */
+/* and replayed.                                                                            */
+/* ===================================================================================== */
+typedef struct ddrl_loop ddrl_loop_t;
+int ddrl_loop_create(ddrl_loop_t **out, ddrl_sac1_t *learner, ddrl_replay_t *replay, int32_t updates_per_graph,
+                     uint32_t noise_seed);
+int ddrl_loop_destroy(ddrl_loop_t *h);
+/* Enqueue n_updates sample+train iterations on `stream` (graph replays + an eager remainder).
+ * Returns DDRL_ERR_EMPTY_BUFFER if the ring is empty. */
+int ddrl_loop_run(ddrl_loop_t *h, int64_t n_updates, void *stream);
+
 /* ===================================================================================== */
 /* Batched policy forward — replaces Actor.get_action (actor_learner.py:195-197) called    */
 /* once per env step in worker_rollout (example/dsac.py:96-97)                             */
