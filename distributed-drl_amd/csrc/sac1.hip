@@ -29,6 +29,11 @@ constexpr int NEVAL = 8;       // network evaluations per update
 constexpr float LOG2PI = 1.8378770664093453f;  // float32(np.log(2*np.pi))
 constexpr float STD_EPS = 1e-8f;               // core.py:5 EPS
 
+// Performance rule for every kernel in this file (measured: a kernel's duration here is set by its
+// chain of dependent global round trips, not by arithmetic): loads are issued branch-free and all
+// at once — clamped addresses + selects instead of per-lane `if`, fixed-trip unrolled loops instead
+// of runtime-trip loops — so that one round trip covers a whole phase.
+
 // ------------------------------------------------------------------------------------------
 // job descriptors
 // ------------------------------------------------------------------------------------------
@@ -36,24 +41,25 @@ struct GemmJob {
     const float *A, *B;
     float *C;
     const float *bias;  // forward: C = relu(A*B + bias)
-    const float *mask;  // dgrad:   C = (A*B) where mask > 0 else 0   (mask laid out like C)
-    int M, N, K, lda, ldb, ldc;
+    const float *mask;  // dgrad:   C = (A*B) where mask > 0 else 0   (row stride ldmask)
+    int M, N, K, lda, ldb, ldc, ldmask;
     int a_kc;  // 1: A(i,k) = A[i*lda + k]   0: A(i,k) = A[k*lda + i]
     int b_kc;  // 1: B(k,j) = B[j*ldb + k]   0: B(k,j) = B[k*ldb + j]
     int relu;
-    int a_ones_row;  // >= 0: that row of A is all ones (bias gradients ride as an extra row of a wgrad)
+    int fast;  // operands 16-B aligned with row strides % 4 == 0 (and K % 4 == 0 for K-contiguous ones)
     int tiles_n, tile_start, ntiles;
 };
 constexpr int MAX_GEMM_JOBS = 8;
 struct GemmJobs {
     int njobs, total_tiles;
+    int tile_start[MAX_GEMM_JOBS];  // flat copy: the job lookup is one scalar load, not a pointer chase
     GemmJob job[MAX_GEMM_JOBS];
 };
 
 struct L1Job {  // H1 = relu([in0 | in1] * W1 + b1); optionally also writes the concatenated input rows
     const float *in0, *in1, *W, *b;
     float *out, *aug_out;
-    int d0, d1, rows, h1;
+    int d0, d1, rows, h1, ldo, aug_ld;
 };
 constexpr int MAX_L1_JOBS = 5;
 struct L1Jobs {
@@ -73,39 +79,45 @@ struct OptState {  // device-resident Adam bookkeeping (running beta powers like
 };
 
 // ------------------------------------------------------------------------------------------
-// K: layer 1 (K = obs_dim or obs_dim+act_dim: tiny) — VALU, threads along the output feature
+// K: layer 1 (K = obs_dim or obs_dim+act_dim: tiny) — VALU, threads along the output feature.
+// Input rows and the W1 column block are staged in LDS with one coalesced burst each.
 // ------------------------------------------------------------------------------------------
 constexpr int L1_ROWS = 16;
+constexpr int L1_MAXD = 40;
 __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
     const L1Job &jb = jobs.job[blockIdx.z];
-    __shared__ float s_in[L1_ROWS][40];
+    __shared__ float s_in[L1_ROWS][L1_MAXD];
+    __shared__ float s_w[L1_MAXD][256];
     const int din = jb.d0 + jb.d1;
     const int r0 = blockIdx.y * L1_ROWS;
     if (r0 >= jb.rows) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int jc = j < jb.h1 ? j : jb.h1 - 1;
+    for (int k = 0; k < din; ++k) s_w[k][threadIdx.x] = jb.W[(long long)k * jb.h1 + jc];  // independent loads, stores only
+    const float bj = jb.b[jc];
     for (int e = threadIdx.x; e < L1_ROWS * din; e += 256) {
         const int rr = e / din, k = e - rr * din;
         const int r = r0 + rr;
-        float v = 0.f;
-        if (r < jb.rows) v = (k < jb.d0) ? jb.in0[(long long)r * jb.d0 + k] : jb.in1[(long long)r * jb.d1 + (k - jb.d0)];
+        const int rc = r < jb.rows ? r : jb.rows - 1;
+        const float v = (k < jb.d0) ? jb.in0[(long long)rc * jb.d0 + k] : jb.in1[(long long)rc * jb.d1 + (k - jb.d0)];
         s_in[rr][k] = v;
-        if (jb.aug_out && blockIdx.x == 0 && r < jb.rows) jb.aug_out[(long long)r * din + k] = v;  // [x | a] rows for the layer-1 wgrad
+        if (jb.aug_out && blockIdx.x == 0 && r < jb.rows) jb.aug_out[(long long)r * jb.aug_ld + k] = v;  // [x | a] rows for the layer-1 wgrad
     }
     __syncthreads();
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= jb.h1) return;
     float acc[L1_ROWS];
-    const float bj = jb.b[j];
 #pragma unroll
     for (int rr = 0; rr < L1_ROWS; ++rr) acc[rr] = 0.f;
     for (int k = 0; k < din; ++k) {
-        const float w = jb.W[(long long)k * jb.h1 + j];
+        const float w = s_w[k][threadIdx.x];
 #pragma unroll
         for (int rr = 0; rr < L1_ROWS; ++rr) acc[rr] = fmaf(s_in[rr][k], w, acc[rr]);
     }
+    if (j < jb.h1) {
 #pragma unroll
-    for (int rr = 0; rr < L1_ROWS; ++rr) {
-        const int r = r0 + rr;
-        if (r < jb.rows) jb.out[(long long)r * jb.h1 + j] = fmaxf(acc[rr] + bj, 0.f);
+        for (int rr = 0; rr < L1_ROWS; ++rr) {
+            const int r = r0 + rr;
+            if (r < jb.rows) jb.out[(long long)r * jb.ldo + j] = fmaxf(acc[rr] + bj, 0.f);
+        }
     }
 }
 
@@ -116,64 +128,91 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
 // and the four partial tiles are combined through LDS in a fixed order (deterministic).
 // Operand fetch, per 32-deep K sub-chunk and per wave: BOTH operands are read from global memory
 // as float4 (full 128-B row segments: 8 lanes per row, 8 rows per instruction, 4 instructions per
-// operand) and handed to the MFMA lanes through a wave-private LDS tile:
+// operand, no branches: clamped addresses + selects) and handed to the MFMA lanes through a
+// wave-private LDS tile:
 //   * operand contiguous along K in memory (activations of fwd/dgrad, W2 rows of dgrad):
 //       LDS image [idx][k] (row stride 34), each lane picks float2 (k, k+1) of its row/col;
 //   * operand contiguous along M/N (weights of fwd, both operands of wgrad):
 //       LDS image [k][idx] (row stride 36), each lane picks two b32 of its column.
-// (Reading lane-per-row straight from global touches one cache line per lane and per-load address
-// arithmetic dominated: 10x slower.)  The next sub-chunk's global loads are issued before the
-// current sub-chunk's 16 MFMAs.
+// The next sub-chunk's global loads are issued before the current sub-chunk's 16 MFMAs.
+// Bias gradients need no special case: activations carry a physical column of ones
+// (H1[:, h1] = H2[:, h2] = XA[:, obs+act] = 1), so [dW ; db] = [X | 1]^T dZ is one wgrad job.
+// Jobs whose operands are not 16-B aligned / stride % 4 (odd layer sizes) take a slow path with
+// per-element guards.
 // ------------------------------------------------------------------------------------------
 constexpr int KS = 32;
 constexpr int OP_LDS = 32 * 36;  // floats per operand tile
 
-// up to 4 consecutive floats; `nvalid` leading elements exist, the rest read as 0
-__device__ __forceinline__ float4 ld4(const float *__restrict__ p, int nvalid) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nvalid >= 4 && (((uintptr_t)p) & 15) == 0) {
-        t = *reinterpret_cast<const float4 *>(p);
-    } else if (nvalid > 0) {
-        t.x = p[0];
-        if (nvalid > 1) t.y = p[1];
-        if (nvalid > 2) t.z = p[2];
-        if (nvalid > 3) t.w = p[3];
-    }
-    return t;
+__device__ __forceinline__ float4 sel4(bool c0, bool c1, bool c2, bool c3, float4 t) {
+    return make_float4(c0 ? t.x : 0.f, c1 ? t.y : 0.f, c2 ? t.z : 0.f, c3 ? t.w : 0.f);
 }
 
-// Global -> registers for one operand tile (32 idx x 32 k).  kc: rows = idx, columns = k.
-// nc: rows = k, columns = idx.  `ones` (nc only): that idx reads as 1.0 for every valid k.
-__device__ __forceinline__ void ld_tile(const float *__restrict__ base, bool kc, int ld, int idx0, int nidx, int kb, int k1,
-                                        int ones, int lane, float4 (&v)[4]) {
+// Fast path, global -> registers: unconditional aligned float4 loads from clamped addresses; the
+// values of out-of-range elements are discarded later (st_tile_fast), NOT here, so that all eight
+// loads of a sub-chunk are in flight together.  KC: rows = idx, columns = k.  !KC: rows = k, cols = idx.
+template <bool KC>
+__device__ __forceinline__ void ld_tile_fast(const float *__restrict__ base, int ld, int idx0, int nidx, int kb, int k1, int lane,
+                                             float4 (&v)[4]) {
     const int r8 = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (kc) {
-            const int gi = idx0 + q * 8 + r8, k = kb + c4;
-            const int nv = gi < nidx ? k1 - k : 0;
-            v[q] = ld4(base + (long long)(gi < nidx ? gi : 0) * ld + k, nv);
+        const int row = (KC ? idx0 : kb) + q * 8 + r8, col = (KC ? kb : idx0) + c4;
+        const int nrow = KC ? nidx : k1, ncol = KC ? k1 : nidx;
+        const bool ok = row < nrow && col < ncol;
+        v[q] = *reinterpret_cast<const float4 *>(base + (long long)(ok ? row : 0) * ld + (ok ? col : 0));
+    }
+}
+
+// registers -> wave-private LDS image, zeroing what lies outside the matrix / this wave's K range
+template <bool KC>
+__device__ __forceinline__ void st_tile_fast(float *__restrict__ s, int idx0, int nidx, int kb, int k1, int lane,
+                                             const float4 (&v)[4]) {
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int lrow = q * 8 + r8;
+        const int row = (KC ? idx0 : kb) + lrow, col = (KC ? kb : idx0) + c4;
+        const int nrow = KC ? nidx : k1, ncol = KC ? k1 : nidx;
+        const bool ok = row < nrow;
+        if (KC) {  // K % 4 == 0: the four k of a float4 are valid or not as a whole
+            const bool okk = ok && col < ncol;
+            *reinterpret_cast<float2 *>(s + lrow * 34 + c4) = make_float2(okk ? v[q].x : 0.f, okk ? v[q].y : 0.f);
+            *reinterpret_cast<float2 *>(s + lrow * 34 + c4 + 2) = make_float2(okk ? v[q].z : 0.f, okk ? v[q].w : 0.f);
         } else {
-            const int k = kb + q * 8 + r8, gi = idx0 + c4;
-            const int nv = k < k1 ? nidx - gi : 0;
-            float4 t = ld4(base + (long long)(k < k1 ? k : 0) * ld + gi, nv);
-            if (ones >= 0 && k < k1) {
-                if (gi == ones) t.x = 1.f;
-                if (gi + 1 == ones) t.y = 1.f;
-                if (gi + 2 == ones) t.z = 1.f;
-                if (gi + 3 == ones) t.w = 1.f;
-            }
-            v[q] = t;
+            *reinterpret_cast<float4 *>(s + lrow * 36 + c4) =
+                sel4(ok && col < ncol, ok && col + 1 < ncol, ok && col + 2 < ncol, ok && col + 3 < ncol, v[q]);
         }
     }
 }
 
-__device__ __forceinline__ void st_tile(float *__restrict__ s, bool kc, int lane, const float4 (&v)[4]) {
+// Slow path (unaligned / odd strides): per-element guarded scalar loads, values already masked.
+template <bool KC>
+__device__ __forceinline__ void ld_tile_slow(const float *__restrict__ base, int ld, int idx0, int nidx, int kb, int k1, int lane,
+                                             float4 (&v)[4]) {
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gi = KC ? idx0 + q * 8 + r8 : idx0 + c4 + u;
+            const int k = KC ? kb + c4 + u : kb + q * 8 + r8;
+            const bool ok = gi < nidx && k < k1;
+            const long long off = KC ? (long long)(ok ? gi : 0) * ld + (ok ? k : 0) : (long long)(ok ? k : 0) * ld + (ok ? gi : 0);
+            const float t = base[off];
+            e[u] = ok ? t : 0.f;
+        }
+        v[q] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void st_tile_slow(float *__restrict__ s, int lane, const float4 (&v)[4]) {
     const int r8 = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = q * 8 + r8;
-        if (kc) {
+        if (KC) {
             *reinterpret_cast<float2 *>(s + row * 34 + c4) = make_float2(v[q].x, v[q].y);
             *reinterpret_cast<float2 *>(s + row * 34 + c4 + 2) = make_float2(v[q].z, v[q].w);
         } else {
@@ -182,11 +221,12 @@ __device__ __forceinline__ void st_tile(float *__restrict__ s, bool kc, int lane
     }
 }
 
-__device__ __forceinline__ void rd_tile(const float *__restrict__ s, bool kc, int l31, int h, float (&x)[8], float (&y)[8]) {
+template <bool KC>
+__device__ __forceinline__ void rd_tile(const float *__restrict__ s, int l31, int h, float (&x)[8], float (&y)[8]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int k = 4 * c + 2 * h;
-        if (kc) {
+        if (KC) {
             const float2 t = *reinterpret_cast<const float2 *>(s + l31 * 34 + k);
             x[c] = t.x; y[c] = t.y;
         } else {
@@ -196,49 +236,82 @@ __device__ __forceinline__ void rd_tile(const float *__restrict__ s, bool kc, in
     }
 }
 
+// K loop of one wave for one tile; specialised on the operand layouts so that every variant is
+// straight-line code (fwd: A along K, B along N; dgrad: both along K; wgrad: both along M/N).
+template <bool AKC, bool BKC, bool FAST>
+__device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *sB, int m0, int n0, int k0, int k1, int nsub,
+                                           int lane, floatx16 &acc) {
+    const int l31 = lane & 31, h = lane >> 5;
+    float4 pa[4], pb[4];
+    if (FAST) {
+        ld_tile_fast<AKC>(jb.A, jb.lda, m0, jb.M, k0, k1, lane, pa);
+        ld_tile_fast<BKC>(jb.B, jb.ldb, n0, jb.N, k0, k1, lane, pb);
+    } else {
+        ld_tile_slow<AKC>(jb.A, jb.lda, m0, jb.M, k0, k1, lane, pa);
+        ld_tile_slow<BKC>(jb.B, jb.ldb, n0, jb.N, k0, k1, lane, pb);
+    }
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int kb = k0 + sub * KS;
+        __syncthreads();  // WAR: the previous sub-chunk's LDS reads are done
+        if (FAST) {
+            st_tile_fast<AKC>(sA, m0, jb.M, kb, k1, lane, pa);
+            st_tile_fast<BKC>(sB, n0, jb.N, kb, k1, lane, pb);
+        } else {
+            st_tile_slow<AKC>(sA, lane, pa);
+            st_tile_slow<BKC>(sB, lane, pb);
+        }
+        __syncthreads();
+        float ax[8], ay[8], bx[8], by[8];
+        rd_tile<AKC>(sA, l31, h, ax, ay);
+        rd_tile<BKC>(sB, l31, h, bx, by);
+        if (sub + 1 < nsub) {  // prefetch the next sub-chunk behind the MFMAs
+            if (FAST) {
+                ld_tile_fast<AKC>(jb.A, jb.lda, m0, jb.M, kb + KS, k1, lane, pa);
+                ld_tile_fast<BKC>(jb.B, jb.ldb, n0, jb.N, kb + KS, k1, lane, pb);
+            } else {
+                ld_tile_slow<AKC>(jb.A, jb.lda, m0, jb.M, kb + KS, k1, lane, pa);
+                ld_tile_slow<BKC>(jb.B, jb.ldb, n0, jb.N, kb + KS, k1, lane, pb);
+            }
+        }
+        const int nc = (k1 - kb + 3) >> 2;  // valid 4-k groups of this sub-chunk (scalar)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < nc) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[c], bx[c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[c], by[c], acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 2 * OP_LDS];  // per wave: A tile, B tile; reused for the split-K combine
     int t = blockIdx.x, ji = 0;
-#pragma unroll 1
-    while (ji + 1 < jobs.njobs && t >= jobs.job[ji + 1].tile_start) ++ji;
+#pragma unroll
+    for (int i = 1; i < MAX_GEMM_JOBS; ++i) ji += (t >= jobs.tile_start[i]) ? 1 : 0;
     const GemmJob &jb = jobs.job[ji];
     t -= jb.tile_start;
     const int m0 = (t / jb.tiles_n) * 32, n0 = (t % jb.tiles_n) * 32;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: K range and loop guards stay scalar
     const int l31 = lane & 31, h = lane >> 5;
     const int K = jb.K;
     const int chunk = ((K + 15) >> 4) << 2;
     const int k0 = w * chunk;
     const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
-    const int nsub = (chunk + KS - 1) / KS;  // same for the four waves (barriers below)
-    const bool akc = jb.a_kc != 0, bkc = jb.b_kc != 0;
+    const int nsub = (chunk + KS - 1) / KS;  // same for the four waves (barriers in the K loop)
     float *sA = smem + (w * 2 + 0) * OP_LDS, *sB = smem + (w * 2 + 1) * OP_LDS;
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 pa[4], pb[4];
-    ld_tile(jb.A, akc, jb.lda, m0, jb.M, k0, k1, jb.a_ones_row, lane, pa);
-    ld_tile(jb.B, bkc, jb.ldb, n0, jb.N, k0, k1, -1, lane, pb);
-    for (int sub = 0; sub < nsub; ++sub) {
-        const int kb = k0 + sub * KS;
-        __syncthreads();  // WAR: the previous sub-chunk's LDS reads are done
-        st_tile(sA, akc, lane, pa);
-        st_tile(sB, bkc, lane, pb);
-        __syncthreads();
-        float ax[8], ay[8], bx[8], by[8];
-        rd_tile(sA, akc, l31, h, ax, ay);
-        rd_tile(sB, bkc, l31, h, bx, by);
-        if (sub + 1 < nsub) {  // prefetch the next sub-chunk behind the MFMAs
-            ld_tile(jb.A, akc, jb.lda, m0, jb.M, kb + KS, k1, jb.a_ones_row, lane, pa);
-            ld_tile(jb.B, bkc, jb.ldb, n0, jb.N, kb + KS, k1, -1, lane, pb);
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (kb + 4 * c < k1) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[c], bx[c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[c], by[c], acc, 0, 0, 0);
-            }
-        }
+    const int variant = (jb.fast ? 4 : 0) + (jb.a_kc ? 2 : 0) + (jb.b_kc ? 1 : 0);
+    switch (variant) {
+        case 4 + 2 + 0: gemm_kloop<true, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;   // fwd
+        case 4 + 2 + 1: gemm_kloop<true, true, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;    // dgrad
+        case 4 + 0 + 0: gemm_kloop<false, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;  // wgrad
+        case 2 + 0: gemm_kloop<true, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;
+        case 2 + 1: gemm_kloop<true, true, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;
+        default: gemm_kloop<false, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;
     }
     // split-K combine.  D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     __syncthreads();
@@ -246,18 +319,28 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
     __syncthreads();
+    float outv[4], biasv[4], maskv[4];
+    bool okv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {  // issue the epilogue's loads together
         const int o = tid + 256 * q;
         const int row = o >> 5, col = o & 31;
         const int gi = m0 + row, gj = n0 + col;
-        if (gi < jb.M && gj < jb.N) {
-            float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
-            if (jb.bias) v += jb.bias[gj];
-            if (jb.relu) v = fmaxf(v, 0.f);
-            if (jb.mask) v = (jb.mask[(long long)gi * jb.ldc + gj] > 0.f) ? v : 0.f;
-            jb.C[(long long)gi * jb.ldc + gj] = v;
-        }
+        okv[q] = gi < jb.M && gj < jb.N;
+        const int gic = okv[q] ? gi : 0, gjc = okv[q] ? gj : 0;
+        biasv[q] = jb.bias ? jb.bias[gjc] : 0.f;
+        maskv[q] = jb.mask ? jb.mask[(long long)gic * jb.ldmask + gjc] : 1.f;
+        outv[q] = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+        float v = outv[q];
+        if (jb.bias) v += biasv[q];
+        if (jb.relu) v = fmaxf(v, 0.f);
+        v = maskv[q] > 0.f ? v : 0.f;
+        if (okv[q]) jb.C[(long long)gi * jb.ldc + gj] = v;
     }
 }
 
@@ -270,45 +353,62 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+constexpr int RV = 8;  // row vectors of up to 512 elements live in 8 registers per lane
+
+// v[i] = p[lane + 64 i] (address clamped for lane + 64 i >= n: the value there is unspecified —
+// mask_row() one operand of a product before use).  Eight independent loads, no branch, no select:
+// a kernel issues ALL its load_row calls first so that they share one memory round trip.
+__device__ __forceinline__ void load_row(const float *__restrict__ p, int n, int lane, float (&v)[RV], int stride = 1, int off = 0) {
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = p[(long long)(j < n ? j : 0) * stride + off];
+    }
+}
+__device__ __forceinline__ void mask_row(float (&v)[RV], int n, int lane) {
+#pragma unroll
+    for (int i = 0; i < RV; ++i) v[i] = (lane + 64 * i < n) ? v[i] : 0.f;
+}
+__device__ __forceinline__ float dot_rv(const float (&a)[RV], const float (&b)[RV]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RV; ++i) s = fmaf(a[i], b[i], s);
+    return s;
+}
+
 struct NetPi { const float *W1, *b1, *W2, *b2, *Wmu, *bmu, *Wls, *bls; };
 struct NetQ { const float *W1, *b1, *W2, *b2, *W3, *b3; };
 
-struct Consts {
-    float alpha, gamma, scale, inv_b;
-};
-
-// One policy head for one row held by one wave: returns (valid in lanes c < act) the per-dim
-// quantities; all lanes get logp.  core.py:49-87,104-106.
-struct HeadOut { float act, a, std, t, logp; };
-__device__ __forceinline__ HeadOut policy_head(const float *__restrict__ h2row, int h2, int act, const NetPi &p,
-                                               const float *__restrict__ eps_row, float scale, int lane, bool deterministic) {
-    float part[2 * MAXA];
-#pragma unroll
-    for (int c = 0; c < 2 * MAXA; ++c) part[c] = 0.f;
-    for (int j = lane; j < h2; j += 64) {
-        const float hv = h2row[j];
-#pragma unroll
-        for (int c = 0; c < MAXA; ++c)
-            if (c < act) {
-                part[c] = fmaf(hv, p.Wmu[j * act + c], part[c]);
-                part[MAXA + c] = fmaf(hv, p.Wls[j * act + c], part[MAXA + c]);
-            }
-    }
+// One policy head for one row held by one wave (hidden2 <= 512): per-dim quantities are valid in
+// lanes c < act; every lane gets logp.  core.py:49-87,104-106.  `hrow` must be mask_row()ed.
+// The head-kernel rows are fetched two action dims at a time (all of them at once for act <= 2).
+struct HeadOut { float act, a, std, t, logp, eps; };
+__device__ __forceinline__ HeadOut policy_head(const float (&hrow)[RV], int h2, int act, const NetPi &p, float eps_lane,
+                                               float scale, int lane) {
     float mu = 0.f, lsr = 0.f;
+    const float bm = p.bmu[lane < act ? lane : 0], bl = p.bls[lane < act ? lane : 0];
 #pragma unroll
-    for (int c = 0; c < MAXA; ++c)
-        if (c < act) {
-            const float s0 = wave_sum(part[c]), s1 = wave_sum(part[MAXA + c]);
-            if (lane == c) { mu = s0 + p.bmu[c]; lsr = s1 + p.bls[c]; }
+    for (int c0 = 0; c0 < MAXA; c0 += 2)
+        if (c0 < act) {  // wave-uniform
+            const int c1 = c0 + 1 < act ? c0 + 1 : c0;
+            float wm0[RV], wl0[RV], wm1[RV], wl1[RV];
+            load_row(p.Wmu, h2, lane, wm0, act, c0);
+            load_row(p.Wls, h2, lane, wl0, act, c0);
+            load_row(p.Wmu, h2, lane, wm1, act, c1);
+            load_row(p.Wls, h2, lane, wl1, act, c1);
+            const float s0 = wave_sum(dot_rv(hrow, wm0)), s1 = wave_sum(dot_rv(hrow, wl0));
+            const float s2 = wave_sum(dot_rv(hrow, wm1)), s3 = wave_sum(dot_rv(hrow, wl1));
+            if (lane == c0) { mu = s0 + bm; lsr = s1 + bl; }
+            if (lane == c0 + 1 && c0 + 1 < act) { mu = s2 + bm; lsr = s3 + bl; }
         }
     HeadOut o;
-    o.act = 0.f; o.a = 0.f; o.std = 0.f; o.t = 0.f;
+    o.act = 0.f; o.a = 0.f; o.std = 0.f; o.t = 0.f; o.eps = eps_lane;
     float pre = 0.f, corr = 0.f;
     if (lane < act) {
         const float t = tanhf(lsr);
         const float log_std = -20.0f + 11.0f * (t + 1.0f);  // LOG_STD_MIN + 0.5*(MAX-MIN)*(ls+1), core.py:73-74
         const float std = expf(log_std);
-        const float e = deterministic ? 0.f : eps_row[lane];
+        const float e = eps_lane;
         const float u = mu + e * std;                          // core.py:76-77
         const float z = (e * std) / (std + STD_EPS);           // == (pi - mu)/(std + EPS), core.py:31
         pre = -0.5f * ((z * z + 2.0f * log_std) + LOG2PI);
@@ -326,22 +426,16 @@ __device__ __forceinline__ HeadOut policy_head(const float *__restrict__ h2row, 
     return o;
 }
 
-__device__ __forceinline__ float row_dot(const float *__restrict__ a, const float *__restrict__ b, int n, int lane) {
-    float s = 0.f;
-    for (int j = lane; j < n; j += 64) s = fmaf(a[j], b[j], s);
-    return wave_sum(s);
-}
-
 // ------------------------------------------------------------------------------------------
 // K: heads, stage A — one wave per (row, eval in {pi@x, pi@x2, piT@x2, q1(x,a), q2(x,a)})
 // ------------------------------------------------------------------------------------------
 struct RowsA {
-    const float *H2;  // [NEVAL][B][h2]
+    const float *H2;  // [NEVAL][B][ldh2]
     NetPi pi_main, pi_targ;
     NetQ q1, q2;
     const float *e0, *e1, *e2;
     float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o;
-    int B, h2, act;
+    int B, h2, ldh2, act;
     float scale;
 };
 __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
@@ -349,16 +443,18 @@ __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= a.B * 5) return;
     const int e = wid / a.B, r = wid - e * a.B;
-    const float *hrow = a.H2 + ((long long)e * a.B + r) * a.h2;
+    float hrow[RV];
+    load_row(a.H2 + ((long long)e * a.B + r) * a.ldh2, a.h2, lane, hrow);
     if (e < 3) {
         const NetPi &p = (e == 2) ? a.pi_targ : a.pi_main;
         const float *eps = (e == 0 ? a.e0 : (e == 1 ? a.e1 : a.e2)) + (long long)r * a.act;
-        const HeadOut o = policy_head(hrow, a.h2, a.act, p, eps, a.scale, lane, false);
+        const float el = eps[lane < a.act ? lane : 0];
+        mask_row(hrow, a.h2, lane);
+        const HeadOut o = policy_head(hrow, a.h2, a.act, p, el, a.scale, lane);
         if (e == 0) {
             if (lane < a.act) {
                 a.act0[r * a.act + lane] = o.act;
-                float *s = a.save0 + ((long long)r * a.act + lane) * 4;
-                s[0] = o.a; s[1] = o.std; s[2] = o.t; s[3] = 0.f;
+                *reinterpret_cast<float4 *>(a.save0 + ((long long)r * a.act + lane) * 4) = make_float4(o.a, o.std, o.t, o.eps);
             }
             if (lane == 0) a.logp0[r] = o.logp;
         } else if (e == 1) {
@@ -368,23 +464,27 @@ __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
         }
     } else {
         const NetQ &q = (e == 3) ? a.q1 : a.q2;
-        const float v = row_dot(hrow, q.W3, a.h2, lane) + q.b3[0];
+        float w3[RV];
+        load_row(q.W3, a.h2, lane, w3);
+        const float b3 = q.b3[0];
+        mask_row(hrow, a.h2, lane);
+        const float v = wave_sum(dot_rv(hrow, w3)) + b3;
         if (lane == 0) (e == 3 ? a.q1o : a.q2o)[r] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K: heads, stage B — Q(x,pi), target Qs, backup, losses, dq and dZ2 of the three Q paths.
-// actor_learner.py:58-69.  One wave per row; deterministic block partials + last-block sum.
+// actor_learner.py:58-69.  One wave per row; deterministic block partials (summed by k_rows_c).
 // ------------------------------------------------------------------------------------------
 struct RowsB {
     const float *H2;
     NetQ q1, q2, q1t, q2t;
     const float *rew, *done, *logp0, *logp1, *q1o, *q2o;
     float *dZ2;  // [4][B][h2]  slots: 0 = q1(x,a), 1 = q2(x,a), 2 = q1(x,pi), 3 = pi
-    float *dq;   // [2][B]
+    float *dq4;  // [2][B][4]   (column 0 used; padded so that it is a 16-B aligned GEMM operand)
     float *loss_part;
-    int B, h2;
+    int B, h2, ldh2;
     float alpha, gamma;
 };
 __global__ void __launch_bounds__(256) k_rows_b(RowsB a) {
@@ -393,28 +493,45 @@ __global__ void __launch_bounds__(256) k_rows_b(RowsB a) {
     const int r = blockIdx.x * 4 + wv;
     float lpi = 0.f, l1 = 0.f, l2 = 0.f;
     if (r < a.B) {
-        const long long BH = (long long)a.B * a.h2;
-        const float *h3 = a.H2 + 3 * BH + (long long)r * a.h2, *h4 = a.H2 + 4 * BH + (long long)r * a.h2;
-        const float *h5 = a.H2 + 5 * BH + (long long)r * a.h2, *h6 = a.H2 + 6 * BH + (long long)r * a.h2;
-        const float *h7 = a.H2 + 7 * BH + (long long)r * a.h2;
-        const float q1pi = row_dot(h5, a.q1.W3, a.h2, lane) + a.q1.b3[0];
-        const float q1t = row_dot(h6, a.q1t.W3, a.h2, lane) + a.q1t.b3[0];
-        const float q2t = row_dot(h7, a.q2t.W3, a.h2, lane) + a.q2t.b3[0];
-        const float minq = fminf(q1t, q2t);                                   // actor_learner.py:59
-        const float vb = minq - a.alpha * a.logp1[r];                         // :62
-        const float backup = a.rew[r] + (a.gamma * (1.0f - a.done[r])) * vb;  // :63
-        const float e1 = backup - a.q1o[r], e2 = backup - a.q2o[r];
-        lpi = a.alpha * a.logp0[r] - q1pi;                                    // :66
-        l1 = e1 * e1; l2 = e2 * e2;                                           // :67-68
+        const long long BH = (long long)a.B * a.ldh2, BZ = (long long)a.B * a.h2;
+        float h3[RV], h4[RV], h5[RV], h6[RV], h7[RV], w1[RV], w2[RV], w1t[RV], w2t[RV];
+        // every load of the kernel up front: one memory round trip
+        load_row(a.H2 + 3 * BH + (long long)r * a.ldh2, a.h2, lane, h3);
+        load_row(a.H2 + 4 * BH + (long long)r * a.ldh2, a.h2, lane, h4);
+        load_row(a.H2 + 5 * BH + (long long)r * a.ldh2, a.h2, lane, h5);
+        load_row(a.H2 + 6 * BH + (long long)r * a.ldh2, a.h2, lane, h6);
+        load_row(a.H2 + 7 * BH + (long long)r * a.ldh2, a.h2, lane, h7);
+        load_row(a.q1.W3, a.h2, lane, w1);
+        load_row(a.q2.W3, a.h2, lane, w2);
+        load_row(a.q1t.W3, a.h2, lane, w1t);
+        load_row(a.q2t.W3, a.h2, lane, w2t);
+        const float rew = a.rew[r], done = a.done[r], lp0 = a.logp0[r], lp1 = a.logp1[r], q1v = a.q1o[r], q2v = a.q2o[r];
+        const float b1 = a.q1.b3[0], b1t = a.q1t.b3[0], b2t = a.q2t.b3[0];
+        mask_row(w1, a.h2, lane); mask_row(w1t, a.h2, lane); mask_row(w2t, a.h2, lane);
+        const float q1pi = wave_sum(dot_rv(h5, w1)) + b1;
+        const float q1t = wave_sum(dot_rv(h6, w1t)) + b1t;
+        const float q2t = wave_sum(dot_rv(h7, w2t)) + b2t;
+        const float minq = fminf(q1t, q2t);                          // actor_learner.py:59
+        const float vb = minq - a.alpha * lp1;                       // :62
+        const float backup = rew + (a.gamma * (1.0f - done)) * vb;   // :63
+        const float e1 = backup - q1v, e2 = backup - q2v;
+        lpi = a.alpha * lp0 - q1pi;                                  // :66
+        l1 = e1 * e1; l2 = e2 * e2;                                  // :67-68
         const float inv_b = 1.0f / (float)a.B;
         const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b, dqp = -inv_b;
-        if (lane == 0) { a.dq[r] = dq1; a.dq[a.B + r] = dq2; }
-        float *z0 = a.dZ2 + (long long)r * a.h2, *z1 = z0 + BH, *z2 = z1 + BH;
-        for (int j = lane; j < a.h2; j += 64) {
-            const float w1 = a.q1.W3[j], w2 = a.q2.W3[j];
-            z0[j] = h3[j] > 0.f ? dq1 * w1 : 0.f;
-            z1[j] = h4[j] > 0.f ? dq2 * w2 : 0.f;
-            z2[j] = h5[j] > 0.f ? dqp * w1 : 0.f;
+        if (lane == 0) {
+            *reinterpret_cast<float4 *>(a.dq4 + (long long)r * 4) = make_float4(dq1, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(a.dq4 + ((long long)a.B + r) * 4) = make_float4(dq2, 0.f, 0.f, 0.f);
+        }
+        float *z0 = a.dZ2 + (long long)r * a.h2, *z1 = z0 + BZ, *z2 = z1 + BZ;
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < a.h2) {
+                z0[j] = h3[i] > 0.f ? dq1 * w1[i] : 0.f;
+                z1[j] = h4[i] > 0.f ? dq2 * w2[i] : 0.f;
+                z2[j] = h5[i] > 0.f ? dqp * w1[i] : 0.f;
+            }
         }
     }
     if (lane == 0) { s_part[wv][0] = lpi; s_part[wv][1] = l1; s_part[wv][2] = l2; }
@@ -430,16 +547,16 @@ __global__ void __launch_bounds__(256) k_rows_b(RowsB a) {
 // K: policy-head backward — d pi_loss / d (mu_raw, log_std_raw) and dZ2 of the policy trunk
 // ------------------------------------------------------------------------------------------
 struct RowsC {
-    const float *H2;    // eval 0 rows
+    const float *H2;    // eval 0 rows (stride ldh2)
     const float *dZ1q;  // dZ1 of the q1(x,pi) path: [B][h1]
     const float *W1q1;  // main q1 layer-1 kernel [(obs+act)][h1]
     NetPi pi;
-    const float *e0, *save0;
-    float *dhead;  // [B][2*act]
+    const float *save0;
+    float *dhead;  // [B][ldd]
     float *dZ2pi;  // [B][h2]
     const float *loss_part;  // [loss_blocks][3] from k_rows_b
     float *losses;           // [3] pi_loss, q1_loss, q2_loss (actor_learner.py:66-68)
-    int B, h1, h2, obs, act, loss_blocks;
+    int B, h1, h2, ldh2, obs, act, ldd, loss_blocks;
     float alpha, scale;
 };
 __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
@@ -452,19 +569,36 @@ __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
     }
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.B) return;
-    const float *dz = a.dZ1q + (long long)r * a.h1;
+    // everything this wave needs for the first two action dims, in one burst
+    float dz[RV], hrow[RV], wq0[RV], wq1[RV], wm0[RV], wl0[RV], wm1[RV], wl1[RV];
+    const int cB = a.act > 1 ? 1 : 0;
+    load_row(a.dZ1q + (long long)r * a.h1, a.h1, lane, dz);
+    load_row(a.H2 + (long long)r * a.ldh2, a.h2, lane, hrow);
+    load_row(a.W1q1 + (long long)(a.obs + 0) * a.h1, a.h1, lane, wq0);
+    load_row(a.W1q1 + (long long)(a.obs + cB) * a.h1, a.h1, lane, wq1);
+    load_row(a.pi.Wmu, a.h2, lane, wm0, a.act, 0);
+    load_row(a.pi.Wls, a.h2, lane, wl0, a.act, 0);
+    load_row(a.pi.Wmu, a.h2, lane, wm1, a.act, cB);
+    load_row(a.pi.Wls, a.h2, lane, wl1, a.act, cB);
+    const float4 sv = *reinterpret_cast<const float4 *>(a.save0 + ((long long)r * a.act + (lane < a.act ? lane : 0)) * 4);
+    mask_row(dz, a.h1, lane);
     float ga = 0.f;
+    {
+        const float s0 = wave_sum(dot_rv(dz, wq0)), s1 = wave_sum(dot_rv(dz, wq1));
+        if (lane == 0) ga = s0;
+        if (lane == 1 && a.act > 1) ga = s1;
+    }
 #pragma unroll
-    for (int c = 0; c < MAXA; ++c)
-        if (c < a.act) {
-            const float s = row_dot(dz, a.W1q1 + (long long)(a.obs + c) * a.h1, a.h1, lane);
-            if (lane == c) ga = s;
+    for (int c = 2; c < MAXA; ++c)
+        if (c < a.act) {  // act > 2: one more round trip per extra dim
+            float w[RV];
+            load_row(a.W1q1 + (long long)(a.obs + c) * a.h1, a.h1, lane, w);
+            const float sdot = wave_sum(dot_rv(dz, w));
+            if (lane == c) ga = sdot;
         }
     float dmu = 0.f, dls = 0.f;
     if (lane < a.act) {
-        const float *s = a.save0 + ((long long)r * a.act + lane) * 4;
-        const float av = s[0], std = s[1], t = s[2];
-        const float e = a.e0[(long long)r * a.act + lane];
+        const float av = sv.x, std = sv.y, t = sv.z, e = sv.w;
         const float glp = a.alpha / (float)a.B;  // d pi_loss / d logp_pi
         const float om = 1.0f - av * av;
         const float cl = fminf(fmaxf(om, 0.f), 1.f);
@@ -475,23 +609,42 @@ __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
         const float dl = du * (e * std) + glp * (-(z * dzdl) - 1.0f);
         dmu = du;
         dls = dl * (11.0f * (1.0f - t * t));
-        a.dhead[(long long)r * 2 * a.act + lane] = dmu;
-        a.dhead[(long long)r * 2 * a.act + a.act + lane] = dls;
     }
     float gm[MAXA], gl[MAXA];
 #pragma unroll
     for (int c = 0; c < MAXA; ++c) { gm[c] = __shfl(dmu, c); gl[c] = __shfl(dls, c); }
-    const float *hrow = a.H2 + (long long)r * a.h2;
-    float *out = a.dZ2pi + (long long)r * a.h2;
-    for (int j = lane; j < a.h2; j += 64) {
+    if (lane < a.ldd) {  // dhead row = [dmu | dls | zero padding]
         float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXA; ++c)
-            if (c < a.act) {
-                v = fmaf(gm[c], a.pi.Wmu[j * a.act + c], v);
-                v = fmaf(gl[c], a.pi.Wls[j * a.act + c], v);
+        for (int c = 0; c < MAXA; ++c) {
+            if (c < a.act && lane == c) v = gm[c];
+            if (c < a.act && lane == a.act + c) v = gl[c];
+        }
+        a.dhead[(long long)r * a.ldd + lane] = v;
+    }
+    float acc[RV];
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+        acc[i] = fmaf(gl[0], wl0[i], gm[0] * wm0[i]);
+        if (a.act > 1) { acc[i] = fmaf(gm[1], wm1[i], acc[i]); acc[i] = fmaf(gl[1], wl1[i], acc[i]); }
+    }
+#pragma unroll
+    for (int c = 2; c < MAXA; ++c)
+        if (c < a.act) {
+            float wm[RV], wl[RV];
+            load_row(a.pi.Wmu, a.h2, lane, wm, a.act, c);
+            load_row(a.pi.Wls, a.h2, lane, wl, a.act, c);
+#pragma unroll
+            for (int i = 0; i < RV; ++i) {
+                acc[i] = fmaf(gm[c], wm[i], acc[i]);
+                acc[i] = fmaf(gl[c], wl[i], acc[i]);
             }
-        out[j] = hrow[j] > 0.f ? v : 0.f;
+        }
+    float *out = a.dZ2pi + (long long)r * a.h2;
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < a.h2) out[j] = hrow[i] > 0.f ? acc[i] : 0.f;
     }
 }
 
@@ -514,18 +667,20 @@ __device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, flo
     t = pk * t + pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
 }
 __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
-    const float one = 1.0f;
-    const float al_pi = a.lr * sqrtf(one - a.opt->b2p_pi) / (one - a.opt->b1p_pi);
-    const float al_q = a.lr * sqrtf(one - a.opt->b2p_q) / (one - a.opt->b1p_q);
-    const float omb1 = one - a.b1, omb2 = one - a.b2;
     const long long n4 = a.n >> 2, npi4 = a.n_pi >> 2;  // both buffers are padded to multiples of 4
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // grid covers n4 exactly once
     float4 *P = reinterpret_cast<float4 *>(a.p), *T = reinterpret_cast<float4 *>(a.t);
     float4 *M = reinterpret_cast<float4 *>(a.m), *V = reinterpret_cast<float4 *>(a.v);
     const float4 *G = reinterpret_cast<const float4 *>(a.g);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 g = G[i];
-        float4 m = M[i], v = V[i], p = P[i], t = T[i];
+    const long long ic = i < n4 ? i : 0;
+    const float4 g = G[ic];  // all loads of the kernel issued together
+    float4 m = M[ic], v = V[ic], p = P[ic], t = T[ic];
+    const float b1p_pi = a.opt->b1p_pi, b2p_pi = a.opt->b2p_pi, b1p_q = a.opt->b1p_q, b2p_q = a.opt->b2p_q;
+    const float one = 1.0f;
+    const float al_pi = a.lr * sqrtf(one - b2p_pi) / (one - b1p_pi);
+    const float al_q = a.lr * sqrtf(one - b2p_q) / (one - b1p_q);
+    const float omb1 = one - a.b1, omb2 = one - a.b2;
+    if (i < n4) {
         const float al = i < npi4 ? al_pi : al_q;
         adam1(g.x, m.x, v.x, p.x, t.x, omb1, omb2, al, a.eps, a.pk, a.pk1);
         adam1(g.y, m.y, v.y, p.y, t.y, omb1, omb2, al, a.eps, a.pk, a.pk1);
@@ -537,7 +692,7 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     if (threadIdx.x == 0) {
         const unsigned tk = atomicAdd(&a.opt->ticket_adam, 1u);
         if (tk == gridDim.x - 1) {  // every block has read the powers before taking its ticket
-            a.opt->b1p_pi *= a.b1; a.opt->b2p_pi *= a.b2; a.opt->b1p_q *= a.b1; a.opt->b2p_q *= a.b2;
+            a.opt->b1p_pi = b1p_pi * a.b1; a.opt->b2p_pi = b2p_pi * a.b2; a.opt->b1p_q = b1p_q * a.b1; a.opt->b2p_q = b2p_q * a.b2;
             a.opt->t_pi += 1; a.opt->t_q += 1;
             a.opt->ticket_adam = 0;
         }
@@ -571,9 +726,9 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs a) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[w]; i += gridDim.x * 256) a.dst[w][i] = a.src[w][i];
 }
 
-// N(0,1) for the three noise buffers (contiguous [3][B*act]) from a device-resident counter; one
-// workgroup so that the counter update needs no cross-block ordering.  Same generator as
-// ddrl_normal_fill / oracle/noise_oracle.normal_fill.
+// N(0,1) for the three noise buffers from a device-resident counter; one workgroup so that the
+// counter update needs no cross-block ordering.  Same generator as ddrl_normal_fill /
+// oracle/noise_oracle.normal_fill.
 __global__ void __launch_bounds__(256) k_noise3(float *e0, float *e1, float *e2, int n_each, uint32_t seed, OptState *opt) {
     const unsigned long long base = opt->noise_ctr;
     for (int i = threadIdx.x; i < 3 * n_each; i += 256) {
@@ -599,6 +754,11 @@ __global__ void k_copy3(const float *a, const float *b, const float *c, float *o
     }
 }
 
+__global__ void k_fill_col(float *p, long long rows, int ld, int col, float v) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) p[r * ld + col] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // K: batched get_action — one wave per observation row (Actor.get_action, actor_learner.py:195-197)
 // ------------------------------------------------------------------------------------------
@@ -607,15 +767,18 @@ struct ActArgs {
     NetPi pi;
     const float *eps;
     float *act_out;
-    int rows, h2, act, deterministic;
+    int rows, h2, ldh2, act, deterministic;
     float scale;
 };
 __global__ void __launch_bounds__(256) k_rows_act(ActArgs a) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.rows) return;
-    const HeadOut o = policy_head(a.H2 + r * a.h2, a.h2, a.act, a.pi, a.eps ? a.eps + r * a.act : nullptr, a.scale, lane,
-                                  a.deterministic != 0);
+    float hrow[RV];
+    load_row(a.H2 + r * a.ldh2, a.h2, lane, hrow);
+    const float el = (a.deterministic || !a.eps) ? 0.f : a.eps[r * a.act + (lane < a.act ? lane : 0)];
+    mask_row(hrow, a.h2, lane);
+    const HeadOut o = policy_head(hrow, a.h2, a.act, a.pi, el, a.scale, lane);
     if (lane < a.act) a.act_out[r * a.act + lane] = o.act;
 }
 
@@ -674,27 +837,41 @@ static void gemm_add(GemmJobs &js, GemmJob j) {
     j.ntiles = ((j.M + 31) / 32) * j.tiles_n;
     j.tile_start = js.total_tiles;
     js.total_tiles += j.ntiles;
+    for (int i = js.njobs; i < MAX_GEMM_JOBS; ++i) js.tile_start[i] = 0x7fffffff;
+    js.tile_start[js.njobs] = j.tile_start;
     js.job[js.njobs++] = j;
 }
-static GemmJob gemm_fwd(const float *H1, const float *W2, const float *b2, float *H2, int rows, int h1, int h2) {
+static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+static void set_fast(GemmJob &j) {
+    bool ok = al16(j.A) && al16(j.B) && (j.lda % 4 == 0) && (j.ldb % 4 == 0);
+    if (j.a_kc || j.b_kc) ok = ok && (j.K % 4 == 0);
+    if (!j.a_kc) ok = ok && j.M <= j.lda;  // float4 reads stay inside the row stride
+    if (!j.b_kc) ok = ok && j.N <= j.ldb;
+    j.fast = ok ? 1 : 0;
+}
+// H2 = relu(H1 * W2 + b2)
+static GemmJob gemm_fwd(const float *H1, int ldh1, const float *W2, const float *b2, float *H2, int ldh2, int rows, int h1, int h2) {
     GemmJob j{};
     j.A = H1; j.B = W2; j.C = H2; j.bias = b2; j.mask = nullptr;
-    j.M = rows; j.N = h2; j.K = h1; j.lda = h1; j.ldb = h2; j.ldc = h2; j.a_kc = 1; j.b_kc = 0; j.relu = 1; j.a_ones_row = -1;
+    j.M = rows; j.N = h2; j.K = h1; j.lda = ldh1; j.ldb = h2; j.ldc = ldh2; j.ldmask = 0; j.a_kc = 1; j.b_kc = 0; j.relu = 1;
+    set_fast(j);
     return j;
 }
-static GemmJob gemm_dgrad(const float *dZ2, const float *W2, const float *H1mask, float *dZ1, int rows, int h1, int h2) {
-    GemmJob j{};  // dZ1 = (dZ2 * W2^T) .* (H1 > 0)
+// dZ1 = (dZ2 * W2^T) .* (H1 > 0)
+static GemmJob gemm_dgrad(const float *dZ2, const float *W2, const float *H1mask, int ldh1, float *dZ1, int rows, int h1, int h2) {
+    GemmJob j{};
     j.A = dZ2; j.B = W2; j.C = dZ1; j.bias = nullptr; j.mask = H1mask;
-    j.M = rows; j.N = h1; j.K = h2; j.lda = h2; j.ldb = h2; j.ldc = h1; j.a_kc = 1; j.b_kc = 1; j.relu = 0; j.a_ones_row = -1;
+    j.M = rows; j.N = h1; j.K = h2; j.lda = h2; j.ldb = h2; j.ldc = h1; j.ldmask = ldh1; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
+    set_fast(j);
     return j;
 }
-// [dW ; db] = [X | 1]^T * dZ : X[rows, nin] (row stride ldx), dZ[rows, nout] (row stride ldz) -> C[(nin+1), nout]
-// (row stride ldc); the kernel's bias lives right behind it in the internal layout.
+// [dW ; db] = [X | 1]^T * dZ : X[rows, nin | 1] (row stride ldx, physical ones column at nin), dZ[rows, nout]
+// (row stride ldz) -> C[(nin+1), nout] (row stride ldc); the kernel's bias lives right behind it.
 static GemmJob gemm_wgrad(const float *X, int ldx, int nin, const float *dZ, int ldz, int nout, float *C, int ldc, int rows) {
     GemmJob j{};
     j.A = X; j.B = dZ; j.C = C; j.bias = nullptr; j.mask = nullptr;
-    j.M = nin + 1; j.N = nout; j.K = rows; j.lda = ldx; j.ldb = ldz; j.ldc = ldc; j.a_kc = 0; j.b_kc = 0; j.relu = 0;
-    j.a_ones_row = nin;
+    j.M = nin + 1; j.N = nout; j.K = rows; j.lda = ldx; j.ldb = ldz; j.ldc = ldc; j.ldmask = 0; j.a_kc = 0; j.b_kc = 0; j.relu = 0;
+    set_fast(j);
     return j;
 }
 
@@ -709,7 +886,8 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
     DDRL_REQUIRE(c != nullptr, "config is NULL");
     DDRL_REQUIRE(c->obs_dim > 0 && c->act_dim > 0 && c->hidden1 > 0 && c->hidden2 > 0 && c->batch > 0, "dims must be positive");
     DDRL_REQUIRE(c->act_dim <= MAXA, "act_dim > 8 unsupported");
-    DDRL_REQUIRE(c->obs_dim + c->act_dim <= 40, "obs_dim + act_dim > 40 unsupported by the layer-1 kernel");
+    DDRL_REQUIRE(c->obs_dim + c->act_dim <= L1_MAXD, "obs_dim + act_dim > 40 unsupported by the layer-1 kernel");
+    DDRL_REQUIRE(c->hidden1 <= 64 * RV && c->hidden2 <= 64 * RV, "hidden sizes > 512 unsupported by the row kernels");
     return DDRL_OK;
 }
 
@@ -723,8 +901,9 @@ struct ddrl_sac1 {
     float *slab;
     float *main_p, *target_p, *m, *v, *grad;
     float *x, *x2, *a, *r, *d, *e0, *e1, *e2;
-    float *H1, *H2, *dZ2, *dZ1, *xa;
-    float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o, *dq, *dhead, *loss_part, *losses;
+    float *H1, *H2, *dZ2, *dZ1, *xa, *xp;
+    float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o, *dq4, *dhead, *loss_part, *losses;
+    int ldh1, ldh2, ldxa, ldxp, ldd;
     OptState *opt;
     Seg *segs_d;
     L1Jobs l1a, l1b;
@@ -784,13 +963,17 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     struct Item { float **p; size_t off; };
     std::vector<Item> items;
 #define ALLOC(ptr, cnt) items.push_back(Item{&h->ptr, reserve((size_t)(cnt))})
+    // activations carry one extra physical column of ones (the bias-gradient row of the wgrads)
+    h->ldh1 = (int)pad4(h1 + 1); h->ldh2 = (int)pad4(h2 + 1);
+    h->ldxa = (int)pad4(o + a + 1); h->ldxp = (int)pad4(o + 1); h->ldd = (int)pad4(2 * a);
     ALLOC(main_p, NT); ALLOC(target_p, NT); ALLOC(m, NT); ALLOC(v, NT); ALLOC(grad, NT);
     ALLOC(x, B * o); ALLOC(x2, B * o); ALLOC(a, B * a); ALLOC(r, B); ALLOC(d, B);
     ALLOC(e0, B * a); ALLOC(e1, B * a); ALLOC(e2, B * a);
-    ALLOC(H1, (size_t)NEVAL * B * h1); ALLOC(H2, (size_t)NEVAL * B * h2);
-    ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1); ALLOC(xa, (size_t)B * (o + a));
+    ALLOC(H1, (size_t)NEVAL * B * h->ldh1); ALLOC(H2, (size_t)NEVAL * B * h->ldh2);
+    ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1);
+    ALLOC(xa, (size_t)B * h->ldxa); ALLOC(xp, (size_t)B * h->ldxp);
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
-    ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(dq, 2 * B); ALLOC(dhead, (size_t)B * 2 * a);
+    ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(dq4, (size_t)2 * B * 4); ALLOC(dhead, (size_t)B * h->ldd);
     ALLOC(loss_part, (size_t)h->rows_b_blocks * 3); ALLOC(losses, 4);
 #undef ALLOC
     const size_t opt_off = reserve((sizeof(OptState) + 3) / 4);
@@ -809,11 +992,20 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     rc = reset_opt(h, nullptr);
     if (rc != DDRL_OK) { sac1_free(h); return rc; }
 
+    // the physical ones columns (never overwritten: kernels write columns < h1 / h2 / obs(+act) only)
+    k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H1, (long long)NEVAL * B, h->ldh1, h1, 1.0f);
+    k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H2, (long long)NEVAL * B, h->ldh2, h2, 1.0f);
+    k_fill_col<<<(B + 255) / 256, 256>>>(h->xa, B, h->ldxa, o + a, 1.0f);
+    k_fill_col<<<(B + 255) / 256, 256>>>(h->xp, B, h->ldxp, o, 1.0f);
+    DDRL_LAUNCH_CHECK();
+    DDRL_HIP_CHECK(hipDeviceSynchronize());
+
     const float *Pm = h->main_p, *Pt = h->target_p;
-    const long long BH1 = (long long)B * h1, BH2 = (long long)B * h2;
+    const int ldh1 = h->ldh1, ldh2 = h->ldh2;
+    const long long BH1 = (long long)B * ldh1, BH2 = (long long)B * ldh2, BZ1 = (long long)B * h1, BZ2 = (long long)B * h2;
     // ---- layer-1 jobs.  evals: 0 pi(x) 1 pi(x2) 2 piT(x2) 3 q1(x,a) 4 q2(x,a) | 5 q1(x,pi) 6 q1T(x2,piT) 7 q2T(x2,piT)
     auto l1 = [&](const float *in0, int d0, const float *in1, int d1, const float *W, const float *b, int ev) {
-        return L1Job{in0, in1, W, b, h->H1 + ev * BH1, nullptr, d0, d1, B, h1};
+        return L1Job{in0, in1, W, b, h->H1 + ev * BH1, nullptr, d0, d1, B, h1, ldh1, 0};
     };
     h->l1a.njobs = 5;
     h->l1a.job[0] = l1(h->x, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 0);
@@ -821,14 +1013,15 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     h->l1a.job[2] = l1(h->x2, o, nullptr, 0, Pt + L.pi_W1, Pt + L.pi_b1, 2);
     h->l1a.job[3] = l1(h->x, o, h->a, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 3);
     h->l1a.job[4] = l1(h->x, o, h->a, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 4);
-    h->l1a.job[3].aug_out = h->xa;  // [x | a] rows, the A operand of the Q layer-1 wgrads
+    h->l1a.job[0].aug_out = h->xp; h->l1a.job[0].aug_ld = h->ldxp;  // [x | 1]      : A operand of the pi layer-1 wgrad
+    h->l1a.job[3].aug_out = h->xa; h->l1a.job[3].aug_ld = h->ldxa;  // [x | a | 1]  : A operand of the Q layer-1 wgrads
     h->l1b.njobs = 3;
     h->l1b.job[0] = l1(h->x, o, h->act0, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 5);
     h->l1b.job[1] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[0], Pt + L.q_b1[0], 6);
     h->l1b.job[2] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[1], Pt + L.q_b1[1], 7);
     // ---- forward layer-2 GEMMs
     auto fwd = [&](const float *P, long long W2, long long b2, int ev) {
-        return gemm_fwd(h->H1 + ev * BH1, P + W2, P + b2, h->H2 + ev * BH2, B, h1, h2);
+        return gemm_fwd(h->H1 + ev * BH1, ldh1, P + W2, P + b2, h->H2 + ev * BH2, ldh2, B, h1, h2);
     };
     gemm_add(h->g_fa, fwd(Pm, L.pi_W2, L.pi_b2, 0));
     gemm_add(h->g_fa, fwd(Pm, L.pi_W2, L.pi_b2, 1));
@@ -839,38 +1032,38 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     gemm_add(h->g_fb, fwd(Pt, L.q_W2[0], L.q_b2[0], 6));
     gemm_add(h->g_fb, fwd(Pt, L.q_W2[1], L.q_b2[1], 7));
     // ---- backward GEMM launches.  dZ2 / dZ1 slots: 0 q1(x,a), 1 q2(x,a), 2 q1(x,pi), 3 pi.
-    // Every bias gradient rides as the "ones row" of its kernel's wgrad.
+    // Every bias gradient rides as the "ones column" row of its kernel's wgrad.
     float *G = h->grad;
-    // launch "bwd Q": needs dZ2[0..2], dq
-    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 2 * BH2, Pm + L.q_W2[0], h->H1 + 5 * BH1, h->dZ1 + 2 * BH1, B, h1, h2));
-    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 0 * BH2, Pm + L.q_W2[0], h->H1 + 3 * BH1, h->dZ1 + 0 * BH1, B, h1, h2));
-    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 1 * BH2, Pm + L.q_W2[1], h->H1 + 4 * BH1, h->dZ1 + 1 * BH1, B, h1, h2));
+    // launch "bwd Q": needs dZ2[0..2], dq4
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 2 * BZ2, Pm + L.q_W2[0], h->H1 + 5 * BH1, ldh1, h->dZ1 + 2 * BZ1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 0 * BZ2, Pm + L.q_W2[0], h->H1 + 3 * BH1, ldh1, h->dZ1 + 0 * BZ1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 1 * BZ2, Pm + L.q_W2[1], h->H1 + 4 * BH1, ldh1, h->dZ1 + 1 * BZ1, B, h1, h2));
     for (int q = 0; q < 2; ++q) {
-        gemm_add(h->g_bq, gemm_wgrad(h->H1 + (3 + q) * BH1, h1, h1, h->dZ2 + q * BH2, h2, h2, G + L.q_W2[q], h2, B));  // W2, b2
-        gemm_add(h->g_bq, gemm_wgrad(h->H2 + (3 + q) * BH2, h2, h2, h->dq + (long long)q * B, 1, 1, G + L.q_W3[q], 1, B));  // W3, b3
+        gemm_add(h->g_bq, gemm_wgrad(h->H1 + (3 + q) * BH1, ldh1, h1, h->dZ2 + q * BZ2, h2, h2, G + L.q_W2[q], h2, B));       // W2, b2
+        gemm_add(h->g_bq, gemm_wgrad(h->H2 + (3 + q) * BH2, ldh2, h2, h->dq4 + (long long)q * B * 4, 4, 1, G + L.q_W3[q], 1, B));  // W3, b3
     }
     // launch "bwd pi": needs dZ2[3], dhead (k_rows_c) and dZ1[0..1] (launch above)
-    gemm_add(h->g_bpi, gemm_dgrad(h->dZ2 + 3 * BH2, Pm + L.pi_W2, h->H1 + 0 * BH1, h->dZ1 + 3 * BH1, B, h1, h2));
-    gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, h1, h1, h->dZ2 + 3 * BH2, h2, h2, G + L.pi_W2, h2, B));           // W2, b2
-    gemm_add(h->g_bpi, gemm_wgrad(h->H2, h2, h2, h->dhead, 2 * a, a, G + L.pi_Wmu, a, B));                                // Wmu, bmu
-    gemm_add(h->g_bpi, gemm_wgrad(h->H2, h2, h2, h->dhead + a, 2 * a, a, G + L.pi_Wls, a, B));                            // Wls, bls
+    gemm_add(h->g_bpi, gemm_dgrad(h->dZ2 + 3 * BZ2, Pm + L.pi_W2, h->H1 + 0 * BH1, ldh1, h->dZ1 + 3 * BZ1, B, h1, h2));
+    gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, ldh1, h1, h->dZ2 + 3 * BZ2, h2, h2, G + L.pi_W2, h2, B));     // W2, b2
+    gemm_add(h->g_bpi, gemm_wgrad(h->H2, ldh2, h2, h->dhead, h->ldd, a, G + L.pi_Wmu, a, B));                      // Wmu, bmu
+    gemm_add(h->g_bpi, gemm_wgrad(h->H2, ldh2, h2, h->dhead + a, h->ldd, a, G + L.pi_Wls, a, B));                  // Wls, bls
     for (int q = 0; q < 2; ++q)
-        gemm_add(h->g_bpi, gemm_wgrad(h->xa, o + a, o + a, h->dZ1 + q * BH1, h1, h1, G + L.q_W1[q], h1, B));             // Q W1, b1
+        gemm_add(h->g_bpi, gemm_wgrad(h->xa, h->ldxa, o + a, h->dZ1 + q * BZ1, h1, h1, G + L.q_W1[q], h1, B));    // Q W1, b1
     // launch "last": needs dZ1[3]
-    gemm_add(h->g_last, gemm_wgrad(h->x, o, o, h->dZ1 + 3 * BH1, h1, h1, G + L.pi_W1, h1, B));                             // pi W1, b1
+    gemm_add(h->g_last, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 3 * BZ1, h1, h1, G + L.pi_W1, h1, B));               // pi W1, b1
 
     // ---- row kernels
     h->ra = RowsA{h->H2, net_pi(Pm, L), net_pi(Pt, L), net_q(Pm, L, 0), net_q(Pm, L, 1), h->e0, h->e1, h->e2,
-                  h->act0, h->act2, h->logp0, h->logp1, h->save0, h->q1o, h->q2o, B, h2, a, (float)cfg->act_scale};
+                  h->act0, h->act2, h->logp0, h->logp1, h->save0, h->q1o, h->q2o, B, h2, ldh2, a, (float)cfg->act_scale};
     h->rb = RowsB{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_q(Pt, L, 0), net_q(Pt, L, 1), h->r, h->d, h->logp0,
-                  h->logp1, h->q1o, h->q2o, h->dZ2, h->dq, h->loss_part, B, h2,
+                  h->logp1, h->q1o, h->q2o, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
                   (float)cfg->alpha, (float)cfg->gamma};
-    h->rc = RowsC{h->H2, h->dZ1 + 2 * BH1, Pm + L.q_W1[0], net_pi(Pm, L), h->e0, h->save0, h->dhead, h->dZ2 + 3 * BH2,
-                  h->loss_part, h->losses, B, h1, h2, o, a, h->rows_b_blocks, (float)cfg->alpha, (float)cfg->act_scale};
+    h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 3 * BZ2,
+                  h->loss_part, h->losses, B, h1, h2, ldh2, o, a, h->ldd, h->rows_b_blocks, (float)cfg->alpha,
+                  (float)cfg->act_scale};
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, L.total_int, L.n_pi_int,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak)};
-
     *out = h;
     return DDRL_OK;
 }
@@ -955,8 +1148,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, hipStream_t s) {
         case 9: k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi); break;
         case 10: k_gemm<<<h->g_last.total_tiles, 256, 0, s>>>(h->g_last); break;
         case 11: {
-            long long blocks = (h->L.total_int / 4 + 255) / 256;
-            if (blocks > 1024) blocks = 1024;
+            const long long blocks = (h->L.total_int / 4 + 255) / 256;
             k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
             break;
         }
@@ -1072,6 +1264,7 @@ struct ddrl_actor {
     float *H1, *H2;
     Seg *segs_d;
     long long max_rows;
+    int ldh1, ldh2;
 };
 
 extern "C" {
@@ -1087,8 +1280,9 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
     h->L = make_layout(*cfg, true);
     h->pi_p = h->H1 = h->H2 = nullptr; h->segs_d = nullptr;
     hipError_t e = dev_alloc(&h->pi_p, (size_t)h->L.total_int);
-    if (e == hipSuccess) e = dev_alloc(&h->H1, (size_t)max_rows * cfg->hidden1);
-    if (e == hipSuccess) e = dev_alloc(&h->H2, (size_t)max_rows * cfg->hidden2);
+    h->ldh1 = (int)pad4(cfg->hidden1); h->ldh2 = (int)pad4(cfg->hidden2);
+    if (e == hipSuccess) e = dev_alloc(&h->H1, (size_t)max_rows * h->ldh1);
+    if (e == hipSuccess) e = dev_alloc(&h->H2, (size_t)max_rows * h->ldh2);
     if (e == hipSuccess) e = dev_alloc(&h->segs_d, h->L.segs.size());
     if (e != hipSuccess) {
         ddrl::set_error("hipMalloc failed in ddrl_actor_create: %s", hipGetErrorString(e));
@@ -1135,12 +1329,12 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     const Layout &L = h->L;
     L1Jobs l1{};
     l1.njobs = 1;
-    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, nullptr, c.obs_dim, 0, (int)n, c.hidden1};
+    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, nullptr, c.obs_dim, 0, (int)n, c.hidden1, h->ldh1, 0};
     k_l1<<<dim3((c.hidden1 + 255) / 256, (unsigned)((n + L1_ROWS - 1) / L1_ROWS), 1), 256, 0, s>>>(l1);
     GemmJobs gj{};
-    gemm_add(gj, gemm_fwd(h->H1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, (int)n, c.hidden1, c.hidden2));
+    gemm_add(gj, gemm_fwd(h->H1, h->ldh1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, h->ldh2, (int)n, c.hidden1, c.hidden2));
     k_gemm<<<gj.total_tiles, 256, 0, s>>>(gj);
-    ActArgs aa{h->H2, net_pi(h->pi_p, L), eps_d, act_d, (int)n, c.hidden2, c.act_dim, deterministic, (float)c.act_scale};
+    ActArgs aa{h->H2, net_pi(h->pi_p, L), eps_d, act_d, (int)n, c.hidden2, h->ldh2, c.act_dim, deterministic, (float)c.act_scale};
     k_rows_act<<<(unsigned)((n + 3) / 4), 256, 0, s>>>(aa);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
