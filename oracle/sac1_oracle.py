@@ -107,9 +107,11 @@ def _clip_but_pass_gradient(x, l=-1.0, u=1.0):  # core.py:35-38
     return x + ((u - x) * clip_up + (l - x) * clip_low).detach()
 
 
-def policy(p, scope, x, eps, cfg):
+def policy(p, scope, x, eps, cfg, stable=False):
     """mlp_gaussian_policy + apply_squashing_func + action scaling (core.py:49-87,95-106).
-    Returns (mu, pi, logp_pi) with mu/pi already scaled by act_scale."""
+    Returns (mu, pi, logp_pi) with mu/pi already scaled by act_scale.
+    stable=True evaluates (pi - mu)/(std + EPS) as eps*std/(std + EPS) (identical algebra, since
+    pi = mu + eps*std; free of the float32 cancellation of the literal form — the HIP kernel's form)."""
     h = torch.relu(_dense(x, p, scope + "/pi/dense"))
     h = torch.relu(_dense(h, p, scope + "/pi/dense_1"))
     mu = _dense(h, p, scope + "/pi/dense_2")
@@ -117,7 +119,8 @@ def policy(p, scope, x, eps, cfg):
     log_std = LOG_STD_MIN + 0.5 * (LOG_STD_MAX - LOG_STD_MIN) * (log_std + 1)
     std = torch.exp(log_std)
     pi = mu + eps * std
-    pre_sum = -0.5 * (((pi - mu) / (std + EPS)) ** 2 + 2 * log_std + np.log(2 * np.pi))
+    z = (eps * std) / (std + EPS) if stable else (pi - mu) / (std + EPS)
+    pre_sum = -0.5 * (z ** 2 + 2 * log_std + np.log(2 * np.pi))
     logp_pi = pre_sum.sum(dim=1)
     mu = torch.tanh(mu)
     pi = torch.tanh(pi)
@@ -136,8 +139,8 @@ def qf(p, scope, x, a):
 class Sac1Oracle:
     """Learner (actor_learner.py:19-148) with explicit noise; dtype float32 or float64."""
 
-    def __init__(self, cfg, params, dtype=torch.float32):
-        self.cfg, self.dtype = cfg, dtype
+    def __init__(self, cfg, params, dtype=torch.float32, stable=False):
+        self.cfg, self.dtype, self.stable = cfg, dtype, stable
         self.names = [n for n, _ in param_specs(cfg)]
         self.main = OrderedDict((n, torch.tensor(np.asarray(params[n]), dtype=dtype).clone()) for n in self.names)
         self.set_weights(self.names, [self.main[n] for n in self.names])
@@ -167,13 +170,13 @@ class Sac1Oracle:
         x, x2, a = self._t(batch["obs1"]), self._t(batch["obs2"]), self._t(batch["acts"])
         r, d = self._t(batch["rews"]), self._t(batch["done"])
         eps_x, eps_x2, eps_t = self._t(eps_x), self._t(eps_x2), self._t(eps_t)
-        mu, pi, logp_pi = policy(p, "main", x, eps_x, cfg)
-        _, _, logp_pi2 = policy(p, "main", x2, eps_x2, cfg)
+        mu, pi, logp_pi = policy(p, "main", x, eps_x, cfg, self.stable)
+        _, _, logp_pi2 = policy(p, "main", x2, eps_x2, cfg, self.stable)
         q1 = qf(p, "main/q1", x, a)
         q2 = qf(p, "main/q2", x, a)
         q1_pi = qf(p, "main/q1", x, pi)
         # target network: a full actor-critic copy evaluated at x2 (actor_learner.py:36-38)
-        _, pi_t, _ = policy(self.target, "target", x2, eps_t, cfg)
+        _, pi_t, _ = policy(self.target, "target", x2, eps_t, cfg, self.stable)
         q1_pi_t = qf(self.target, "target/q1", x2, pi_t)
         q2_pi_t = qf(self.target, "target/q2", x2, pi_t)
         min_q_pi = torch.minimum(q1_pi_t, q2_pi_t)
