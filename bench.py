@@ -223,7 +223,7 @@ def main():
     cfgd = dict(B=opt.batch_size, obs=opt.obs_dim, act=opt.act_dim, h1=opt.hidden_sizes[0], h2=opt.hidden_sizes[1])
     lib = _lib.load()
     bufs = (ctypes.c_void_p * 8)()
-    _lib.check(lib.ddrl_sac1_input_buffers(trainer.agent._h, bufs))
+    _lib.check(lib.ddrl_sac1_input_buffers(trainer.agent._h, 0, bufs))
     stage = np.zeros(_lib.SAC1_STAGES, np.float64)
     ms = ctypes.c_float()
     for st in range(1, 11):   # idempotent stages, `stage_samples` back-to-back launches between two HIP events

@@ -1,30 +1,99 @@
 // Learner hot loop: `while True: batch = replay_buffer.sample_batch(B); agent.train(batch)`
 // (algos/sac1/sac1.py:146-148; example/dsac.py:142-144 with example/model.py:92-101), n iterations
 // per call with no host work per update.  Built on the public C-ABI only: the replay gathers
-// straight into the learner's input buffers, the noise comes from the learner's device counter,
-// and because every cursor / RNG state / optimizer state lives on the device the sequence for
-// `updates_per_graph` updates is captured ONCE into a hipGraph and replayed (an eager launch
-// stream would be host-bound at ~3.5 us per kernel, MI355X guide "graph-replay-floor").
+// straight into one of the learner's two input sets, the noise comes from the learner's device
+// counter, and because every cursor / RNG state / optimizer state lives on the device the
+// sequence for `updates_per_graph` updates is captured ONCE into a hipGraph and replayed (an
+// eager launch stream would be host-bound at ~3.5 us per kernel, MI355X guide
+// "graph-replay-floor").  Consecutive updates alternate between the learner's two input sets, so
+// the sampler of update u+1 never overwrites what update u still reads; optionally
+// (DDRL_LOOP_FORK=1) the sampler runs on a forked graph branch and overlaps the previous update —
+// the job of the reference's `Cache` prefetch process (algos/sac1/sac1.py:103-130).
 #include "ddrl_common.h"
+
+#include <cstdlib>
+#include <vector>
 
 struct ddrl_loop {
     ddrl_sac1_t *learner;
     ddrl_replay_t *replay;
     int per_graph;
     uint32_t seed;
-    float *buf[8];
+    float *buf[2][8];
     int batch;
     hipGraphExec_t exec;
     bool captured;
+    int parity;  // input set of the next eager update
 };
 
+static int sample_into(ddrl_loop *h, int set, void *stream) {
+    float **b = h->buf[set];
+    return ddrl_replay_sample(h->replay, h->batch, b[0], b[1], b[2], b[3], b[4], nullptr, stream);
+}
+
+static int update_from(ddrl_loop *h, int set, void *stream) {
+    float **b = h->buf[set];
+    int rc = ddrl_sac1_fill_noise(h->learner, h->seed, stream);  // arms in-kernel noise generation
+    if (rc != DDRL_OK) return rc;
+    return ddrl_sac1_step(h->learner, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr, stream);
+}
+
 static int one_update(ddrl_loop *h, void *stream) {
-    int rc = ddrl_replay_sample(h->replay, h->batch, h->buf[0], h->buf[1], h->buf[2], h->buf[3], h->buf[4], nullptr, stream);
+    const int set = h->parity;
+    h->parity ^= 1;
+    int rc = sample_into(h, set, stream);
     if (rc != DDRL_OK) return rc;
-    rc = ddrl_sac1_fill_noise(h->learner, h->seed, stream);
-    if (rc != DDRL_OK) return rc;
-    return ddrl_sac1_step(h->learner, h->buf[0], h->buf[1], h->buf[2], h->buf[3], h->buf[4], h->buf[5], h->buf[6], h->buf[7],
-                          nullptr, nullptr, nullptr, nullptr, stream);
+    return update_from(h, set, stream);
+}
+
+// Capture `per_graph` updates with the sampler on a forked branch.
+static int capture(ddrl_loop *h, hipStream_t main_s) {
+    hipStream_t side = nullptr;
+    DDRL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    const int n = h->per_graph;
+    std::vector<hipEvent_t> e_smp(n), e_upd(n);
+    hipEvent_t e_fork;
+    DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
+    for (int i = 0; i < n; ++i) {
+        DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_smp[i], hipEventDisableTiming));
+        DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_upd[i], hipEventDisableTiming));
+    }
+    hipGraph_t graph = nullptr;
+    int rc = DDRL_OK;
+    DDRL_HIP_CHECK(hipStreamBeginCapture(main_s, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipEventRecord(e_fork, main_s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, e_fork, 0);  // fork
+    // Measured on MI355X: with the sampler on a forked branch an update takes 99 us, inline 93 us — a
+    // kernel that starts or ends on the other branch perturbs the running GEMM (cache invalidate /
+    // write-back at every kernel boundary), which costs more than the 7 us sampler it hides.  The
+    // fork therefore is opt-in (DDRL_LOOP_FORK=1); results are bit-identical either way.
+    const bool fork = getenv("DDRL_LOOP_FORK") != nullptr;
+    for (int i = 0; i < n && rc == DDRL_OK && e == hipSuccess; ++i) {
+        const int set = i & 1;
+        hipStream_t ss = fork ? side : main_s;
+        // set `set` was last read by update i-2: the sampler must not overwrite it earlier
+        if (fork && i >= 2) e = hipStreamWaitEvent(side, e_upd[i - 2], 0);
+        if (e == hipSuccess) rc = sample_into(h, set, (void *)ss);
+        if (fork && e == hipSuccess && rc == DDRL_OK) e = hipEventRecord(e_smp[i], side);
+        if (fork && e == hipSuccess) e = hipStreamWaitEvent(main_s, e_smp[i], 0);
+        if (e == hipSuccess && rc == DDRL_OK) rc = update_from(h, set, (void *)main_s);
+        if (e == hipSuccess && rc == DDRL_OK) e = hipEventRecord(e_upd[i], main_s);
+    }
+    // every side-branch node is an ancestor of a main-stream node: the branch is joined
+    hipError_t e2 = hipStreamEndCapture(main_s, &graph);
+    for (int i = 0; i < n; ++i) { (void)hipEventDestroy(e_smp[i]); (void)hipEventDestroy(e_upd[i]); }
+    (void)hipEventDestroy(e_fork);
+    (void)hipStreamDestroy(side);
+    if (rc != DDRL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || e2 != hipSuccess) {
+        ddrl::set_error("graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        if (graph) (void)hipGraphDestroy(graph);
+        return DDRL_ERR_HIP;
+    }
+    DDRL_HIP_CHECK(hipGraphInstantiate(&h->exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    h->captured = true;
+    return DDRL_OK;
 }
 
 extern "C" {
@@ -35,8 +104,9 @@ int ddrl_loop_create(ddrl_loop_t **out, ddrl_sac1_t *learner, ddrl_replay_t *rep
     DDRL_REQUIRE(updates_per_graph >= 0 && updates_per_graph <= 4096, "updates_per_graph must be in [0, 4096]");
     ddrl_loop *h = new ddrl_loop();
     h->learner = learner; h->replay = replay; h->per_graph = updates_per_graph; h->seed = noise_seed;
-    h->exec = nullptr; h->captured = false;
-    int rc = ddrl_sac1_input_buffers(learner, h->buf);
+    h->exec = nullptr; h->captured = false; h->parity = 0;
+    int rc = ddrl_sac1_input_buffers(learner, 0, h->buf[0]);
+    if (rc == DDRL_OK) rc = ddrl_sac1_input_buffers(learner, 1, h->buf[1]);
     if (rc != DDRL_OK) { delete h; return rc; }
     h->batch = ddrl_sac1_batch(learner);
     *out = h;
@@ -50,9 +120,7 @@ int ddrl_loop_destroy(ddrl_loop_t *h) {
     return DDRL_OK;
 }
 
-}  // extern "C"
-
-extern "C" int ddrl_loop_run(ddrl_loop_t *h, int64_t n_updates, void *stream) {
+int ddrl_loop_run(ddrl_loop_t *h, int64_t n_updates, void *stream) {
     DDRL_REQUIRE(h != nullptr && n_updates >= 0, "bad handle / n_updates");
     hipStream_t s = ddrl::as_stream(stream);
     int64_t left = n_updates;
@@ -62,24 +130,15 @@ extern "C" int ddrl_loop_run(ddrl_loop_t *h, int64_t n_updates, void *stream) {
             int rc = one_update(h, stream);
             if (rc != DDRL_OK) return rc;
             left -= 1;
-            hipStream_t cs = s;
-            hipStream_t own = nullptr;
+            hipStream_t cs = s, own = nullptr;
             if (cs == nullptr) {  // the legacy null stream cannot be captured
                 DDRL_HIP_CHECK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
                 DDRL_HIP_CHECK(hipDeviceSynchronize());
                 cs = own;
             }
-            hipGraph_t graph = nullptr;
-            DDRL_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            int rc2 = DDRL_OK;
-            for (int i = 0; i < h->per_graph && rc2 == DDRL_OK; ++i) rc2 = one_update(h, (void *)cs);
-            hipError_t e = hipStreamEndCapture(cs, &graph);
+            rc = capture(h, cs);
             if (own) (void)hipStreamDestroy(own);
-            if (rc2 != DDRL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc2; }
-            if (e != hipSuccess) { ddrl::set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DDRL_ERR_HIP; }
-            DDRL_HIP_CHECK(hipGraphInstantiate(&h->exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            h->captured = true;
+            if (rc != DDRL_OK) return rc;
         }
         while (left >= h->per_graph) {
             DDRL_HIP_CHECK(hipGraphLaunch(h->exec, s));
@@ -92,3 +151,5 @@ extern "C" int ddrl_loop_run(ddrl_loop_t *h, int64_t n_updates, void *stream) {
     }
     return DDRL_OK;
 }
+
+}  // extern "C"

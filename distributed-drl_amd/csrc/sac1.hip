@@ -47,10 +47,29 @@ struct GemmJob {
     int b_kc;  // 1: B(k,j) = B[j*ldb + k]   0: B(k,j) = B[k*ldb + j]
     int relu;
     int fast;  // operands 16-B aligned with row strides % 4 == 0 (and K % 4 == 0 for K-contiguous ones)
+    // optional fused layer-1 wgrad of the SAME network (dgrad jobs): the tile's rows of C = dZ1 are
+    // contracted with the layer-1 input rows [X | 1] and written as per-row-tile partials
+    //   part[mt][k][j] = sum_{r in row tile mt} X1[r][k] * C[r][j],  k < part_nk
+    // which the Adam kernel sums over mt in a fixed order (deterministic, no extra launch).
+    const float *part_x;
+    float *part;
+    int part_nk, part_ldx;
     int tiles_n, tile_start, ntiles;
 };
 constexpr int MAX_GEMM_JOBS = 8;
+#ifdef DDRL_STAMPS
+#define STAMP(i) do { if (st) st[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define STAMP_ARG , long long *st
+#define STAMP_PASS , st
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_ARG
+#define STAMP_PASS
+#endif
 struct GemmJobs {
+#ifdef DDRL_STAMPS
+    long long *stamps;  // diagnostic builds only (tools/gemm_bench.hip): [grid][32] cycle stamps of wave 0
+#endif
     int njobs, total_tiles;
     int tile_start[MAX_GEMM_JOBS];  // flat copy: the job lookup is one scalar load, not a pointer chase
     GemmJob job[MAX_GEMM_JOBS];
@@ -60,10 +79,18 @@ struct L1Job {  // H1 = relu([in0 | in1] * W1 + b1); optionally also writes the 
     const float *in0, *in1, *W, *b;
     float *out, *aug_out;
     int d0, d1, rows, h1, ldo, aug_ld;
+    int pre_only;  // 1: out = in0 * W1[0:d0] + b1 WITHOUT relu: the observation part of a Q layer 1 whose
+                   //    action part is added by k_rows_a once the action exists (second-phase evaluations)
 };
-constexpr int MAX_L1_JOBS = 5;
+constexpr int MAX_L1_JOBS = 8;
+struct OptState;
 struct L1Jobs {
     int njobs;
+    // tf.random_normal stand-in, generated here (job 0's row blocks) instead of by a kernel of its own
+    int noise_on, act, n_each;
+    uint32_t noise_seed;
+    float *e0, *e1, *e2;
+    const OptState *opt;
     L1Job job[MAX_L1_JOBS];
 };
 
@@ -84,11 +111,18 @@ struct OptState {  // device-resident Adam bookkeeping (running beta powers like
 // ------------------------------------------------------------------------------------------
 constexpr int L1_ROWS = 16;
 constexpr int L1_MAXD = 40;
+__device__ __forceinline__ float normal_at(uint32_t seed, unsigned long long c) {  // == ddrl_normal_fill element c
+    const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+    const uint32_t h1 = ddrl::hash3(seed, lo, 2u * hi), h2 = ddrl::hash3(seed, lo, 2u * hi + 1u);
+    const float u1 = (float)((h1 >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float u2 = ddrl::u01(h2);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
 __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
     const L1Job &jb = jobs.job[blockIdx.z];
     __shared__ float s_in[L1_ROWS][L1_MAXD];
     __shared__ float s_w[L1_MAXD][256];
-    const int din = jb.d0 + jb.d1;
+    const int din = jb.pre_only ? jb.d0 : jb.d0 + jb.d1;
     const int r0 = blockIdx.y * L1_ROWS;
     if (r0 >= jb.rows) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -103,6 +137,21 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
         s_in[rr][k] = v;
         if (jb.aug_out && blockIdx.x == 0 && r < jb.rows) jb.aug_out[(long long)r * jb.aug_ld + k] = v;  // [x | a] rows for the layer-1 wgrad
     }
+    if (jobs.noise_on && blockIdx.z == 0 && blockIdx.x == 0) {
+        // eps_x, eps_x2, eps_t for this block's rows; element index as in one flat [3][B*act] fill
+        const unsigned long long base = jobs.opt->noise_ctr;
+        const int per_row = 3 * jobs.act;
+        for (int e = threadIdx.x; e < L1_ROWS * per_row; e += 256) {
+            const int rr = e / per_row, q = e - rr * per_row;
+            const int wch = q / jobs.act, c = q - wch * jobs.act;
+            const int r = r0 + rr;
+            if (r < jb.rows) {
+                const int k = r * jobs.act + c;
+                (wch == 0 ? jobs.e0 : (wch == 1 ? jobs.e1 : jobs.e2))[k] =
+                    normal_at(jobs.noise_seed, base + (unsigned long long)wch * jobs.n_each + k);
+            }
+        }
+    }
     __syncthreads();
     float acc[L1_ROWS];
 #pragma unroll
@@ -116,7 +165,8 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
 #pragma unroll
         for (int rr = 0; rr < L1_ROWS; ++rr) {
             const int r = r0 + rr;
-            if (r < jb.rows) jb.out[(long long)r * jb.ldo + j] = fmaxf(acc[rr] + bj, 0.f);
+            const float v = acc[rr] + bj;
+            if (r < jb.rows) jb.out[(long long)r * jb.ldo + j] = jb.pre_only ? v : fmaxf(v, 0.f);
         }
     }
 }
@@ -240,7 +290,7 @@ __device__ __forceinline__ void rd_tile(const float *__restrict__ s, int l31, in
 // straight-line code (fwd: A along K, B along N; dgrad: both along K; wgrad: both along M/N).
 template <bool AKC, bool BKC, bool FAST>
 __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *sB, int m0, int n0, int k0, int k1, int nsub,
-                                           int lane, floatx16 &acc) {
+                                           int lane, floatx16 &acc STAMP_ARG) {
     const int l31 = lane & 31, h = lane >> 5;
     float4 pa[4], pb[4];
     if (FAST) {
@@ -250,9 +300,11 @@ __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *
         ld_tile_slow<AKC>(jb.A, jb.lda, m0, jb.M, k0, k1, lane, pa);
         ld_tile_slow<BKC>(jb.B, jb.ldb, n0, jb.N, k0, k1, lane, pb);
     }
+    STAMP(2);
     for (int sub = 0; sub < nsub; ++sub) {
         const int kb = k0 + sub * KS;
         __syncthreads();  // WAR: the previous sub-chunk's LDS reads are done
+        STAMP(3 + sub * 5);
         if (FAST) {
             st_tile_fast<AKC>(sA, m0, jb.M, kb, k1, lane, pa);
             st_tile_fast<BKC>(sB, n0, jb.N, kb, k1, lane, pb);
@@ -260,7 +312,9 @@ __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *
             st_tile_slow<AKC>(sA, lane, pa);
             st_tile_slow<BKC>(sB, lane, pb);
         }
+        STAMP(4 + sub * 5);
         __syncthreads();
+        STAMP(5 + sub * 5);
         float ax[8], ay[8], bx[8], by[8];
         rd_tile<AKC>(sA, l31, h, ax, ay);
         rd_tile<BKC>(sB, l31, h, bx, by);
@@ -273,6 +327,7 @@ __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *
                 ld_tile_slow<BKC>(jb.B, jb.ldb, n0, jb.N, kb + KS, k1, lane, pb);
             }
         }
+        STAMP(6 + sub * 5);
         const int nc = (k1 - kb + 3) >> 2;  // valid 4-k groups of this sub-chunk (scalar)
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -281,17 +336,30 @@ __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[c], by[c], acc, 0, 0, 0);
             }
         }
+        STAMP(7 + sub * 5);
     }
 }
 
 __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 2 * OP_LDS];  // per wave: A tile, B tile; reused for the split-K combine
-    int t = blockIdx.x, ji = 0;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, whose L2s
+    // are private and cold after every kernel boundary.  Give each XCD a CONTIGUOUS run of tiles,
+#ifdef DDRL_STAMPS
+    const long long t0_stamp = (long long)__builtin_readcyclecounter();
+#endif
+    // and order tiles panel-major (all M-tiles of one N-panel of one job are consecutive), so that a
+    // W2 / dZ panel and an activation matrix are fetched by one or two L2s instead of all eight.
+    int t, ji = 0;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
 #pragma unroll
     for (int i = 1; i < MAX_GEMM_JOBS; ++i) ji += (t >= jobs.tile_start[i]) ? 1 : 0;
     const GemmJob &jb = jobs.job[ji];
     t -= jb.tile_start;
-    const int m0 = (t / jb.tiles_n) * 32, n0 = (t % jb.tiles_n) * 32;
+    const int tiles_m = jb.ntiles / jb.tiles_n;
+    const int m0 = (t % tiles_m) * 32, n0 = (t / tiles_m) * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: K range and loop guards stay scalar
     const int l31 = lane & 31, h = lane >> 5;
@@ -301,35 +369,60 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
     const int nsub = (chunk + KS - 1) / KS;  // same for the four waves (barriers in the K loop)
     float *sA = smem + (w * 2 + 0) * OP_LDS, *sB = smem + (w * 2 + 1) * OP_LDS;
+#ifdef DDRL_STAMPS
+    long long *st = (jobs.stamps && lane == 0 && w == 0) ? jobs.stamps + (long long)blockIdx.x * 32 : nullptr;
+    if (st) st[0] = t0_stamp;
+#endif
+    STAMP(1);
+    // epilogue operands first: their latency hides behind the whole K loop
+    __shared__ float s_px[32][13];
+    if (jb.part) {
+        for (int idx = tid; idx < 32 * 12; idx += 256) {
+            const int rr = idx / 12, k = idx - rr * 12;
+            const int gi = m0 + rr;
+            const bool ok = gi < jb.M && k < jb.part_nk;
+            const float v = jb.part_x[(long long)(ok ? gi : 0) * jb.part_ldx + (ok ? k : 0)];
+            s_px[rr][k] = ok ? v : 0.f;
+        }
+    }
+    float biasv[4], maskv[4];
+    bool okv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+        okv[q] = gi < jb.M && gj < jb.N;
+        const int gic = okv[q] ? gi : 0, gjc = okv[q] ? gj : 0;
+        biasv[q] = jb.bias ? jb.bias[gjc] : 0.f;
+        maskv[q] = jb.mask ? jb.mask[(long long)gic * jb.ldmask + gjc] : 1.f;
+    }
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // (A variant that fetched a wave's whole K range up front was measured: no faster for the
+    // forward launches, 40 % slower for the 592-tile backward launch — the CU's fetch rate, not the
+    // prefetch distance, is the limit; the one-sub-chunk-ahead streaming loop stays.)
     const int variant = (jb.fast ? 4 : 0) + (jb.a_kc ? 2 : 0) + (jb.b_kc ? 1 : 0);
     switch (variant) {
-        case 4 + 2 + 0: gemm_kloop<true, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;   // fwd
-        case 4 + 2 + 1: gemm_kloop<true, true, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;    // dgrad
-        case 4 + 0 + 0: gemm_kloop<false, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;  // wgrad
-        case 2 + 0: gemm_kloop<true, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;
-        case 2 + 1: gemm_kloop<true, true, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;
-        default: gemm_kloop<false, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc); break;
+        case 4 + 2 + 0: gemm_kloop<true, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;   // fwd
+        case 4 + 2 + 1: gemm_kloop<true, true, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;    // dgrad
+        case 4 + 0 + 0: gemm_kloop<false, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;  // wgrad
+        case 2 + 0: gemm_kloop<true, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
+        case 2 + 1: gemm_kloop<true, true, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
+        default: gemm_kloop<false, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
     }
     // split-K combine.  D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    STAMP(28);
     __syncthreads();
     float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
     __syncthreads();
-    float outv[4], biasv[4], maskv[4];
-    bool okv[4];
+    float outv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // issue the epilogue's loads together
+    for (int q = 0; q < 4; ++q) {
         const int o = tid + 256 * q;
         const int row = o >> 5, col = o & 31;
-        const int gi = m0 + row, gj = n0 + col;
-        okv[q] = gi < jb.M && gj < jb.N;
-        const int gic = okv[q] ? gi : 0, gjc = okv[q] ? gj : 0;
-        biasv[q] = jb.bias ? jb.bias[gjc] : 0.f;
-        maskv[q] = jb.mask ? jb.mask[(long long)gic * jb.ldmask + gjc] : 1.f;
         outv[q] = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
     }
 #pragma unroll
@@ -341,7 +434,26 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
         if (jb.relu) v = fmaxf(v, 0.f);
         v = maskv[q] > 0.f ? v : 0.f;
         if (okv[q]) jb.C[(long long)gi * jb.ldc + gj] = v;
+        outv[q] = okv[q] ? v : 0.f;
     }
+    if (jb.part) {  // block-uniform
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = tid + 256 * q;
+            red[0][o >> 5][o & 31] = outv[q];
+        }
+        __syncthreads();
+        const int mt = m0 >> 5;
+        for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
+            const int k = idx >> 5, col = idx & 31;
+            float sacc = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 32; ++rr) sacc = fmaf(s_px[rr][k], red[0][rr][col], sacc);
+            if (n0 + col < jb.N) jb.part[((long long)mt * jb.part_nk + k) * jb.N + n0 + col] = sacc;
+        }
+    }
+    STAMP(29);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -435,9 +547,38 @@ struct RowsA {
     NetQ q1, q2;
     const float *e0, *e1, *e2;
     float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o;
-    int B, h2, ldh2, act;
+    // second-phase layer 1 (Q at the freshly sampled actions): slots 5, 6, 7 of H1 hold the
+    // observation part x*W1[:obs] + b1 (k_l1, pre_only); this kernel adds act*W1[obs:] and the relu
+    float *H1;                           // [NEVAL][B][ldh1]
+    const float *Wa_q1, *Wa_q1t, *Wa_q2t;  // action rows W1[obs:obs+act, :] of main q1, target q1, target q2
+    int B, h2, ldh2, act, h1, ldh1;
     float scale;
 };
+__device__ __forceinline__ void finish_l1(float *hx, int h1, int act, const float *__restrict__ Wa, float act_lane, int lane) {
+    // hx[j] = relu(hx[j] + sum_c act[c] * Wa[c*h1 + j]); first two action dims fetched together
+    float v[RV], w0[RV], w1[RV];
+    const int cB = act > 1 ? 1 : 0;
+    load_row(hx, h1, lane, v);
+    load_row(Wa, h1, lane, w0);
+    load_row(Wa + (long long)cB * h1, h1, lane, w1);
+    const float a0 = __shfl(act_lane, 0), a1 = act > 1 ? __shfl(act_lane, 1) : 0.f;
+#pragma unroll
+    for (int i = 0; i < RV; ++i) v[i] = fmaf(a1, w1[i], fmaf(a0, w0[i], v[i]));
+#pragma unroll
+    for (int c = 2; c < MAXA; ++c)
+        if (c < act) {
+            float w[RV];
+            load_row(Wa + (long long)c * h1, h1, lane, w);
+            const float ac = __shfl(act_lane, c);
+#pragma unroll
+            for (int i = 0; i < RV; ++i) v[i] = fmaf(ac, w[i], v[i]);
+        }
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < h1) hx[j] = fmaxf(v[i], 0.f);
+    }
+}
 __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -451,16 +592,20 @@ __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
         const float el = eps[lane < a.act ? lane : 0];
         mask_row(hrow, a.h2, lane);
         const HeadOut o = policy_head(hrow, a.h2, a.act, p, el, a.scale, lane);
+        const long long BH1 = (long long)a.B * a.ldh1;
         if (e == 0) {
             if (lane < a.act) {
                 a.act0[r * a.act + lane] = o.act;
                 *reinterpret_cast<float4 *>(a.save0 + ((long long)r * a.act + lane) * 4) = make_float4(o.a, o.std, o.t, o.eps);
             }
             if (lane == 0) a.logp0[r] = o.logp;
+            finish_l1(a.H1 + 5 * BH1 + (long long)r * a.ldh1, a.h1, a.act, a.Wa_q1, o.act, lane);   // q1(x, pi)
         } else if (e == 1) {
             if (lane == 0) a.logp1[r] = o.logp;
-        } else if (lane < a.act) {
-            a.act2[r * a.act + lane] = o.act;
+        } else {
+            if (lane < a.act) a.act2[r * a.act + lane] = o.act;
+            finish_l1(a.H1 + 6 * BH1 + (long long)r * a.ldh1, a.h1, a.act, a.Wa_q1t, o.act, lane);  // q1T(x2, piT)
+            finish_l1(a.H1 + 7 * BH1 + (long long)r * a.ldh1, a.h1, a.act, a.Wa_q2t, o.act, lane);  // q2T(x2, piT)
         }
     } else {
         const NetQ &q = (e == 3) ? a.q1 : a.q2;
@@ -654,10 +799,16 @@ __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
 // ------------------------------------------------------------------------------------------
 struct AdamArgs {
     float *p, *t, *m, *v;
-    const float *g;
+    float *g;
     OptState *opt;
     long long n, n_pi;
     float lr, b1, b2, eps, pk, pk1;
+    // fused pi layer-1 wgrad: gradient of float4 elements [part_off4, part_off4 + part_n4) is the sum of
+    // `nparts` row-tile partials written by the pi dgrad tiles (k_gemm epilogue), summed in tile order
+    const float *part;
+    long long part_off4, part_n4, part_stride4;
+    int nparts;
+    unsigned int noise_adv;  // noise elements consumed by this update (advances the device counter)
 };
 __device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, float &t, float omb1, float omb2, float al,
                                       float eps, float pk, float pk1) {
@@ -673,8 +824,19 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     float4 *M = reinterpret_cast<float4 *>(a.m), *V = reinterpret_cast<float4 *>(a.v);
     const float4 *G = reinterpret_cast<const float4 *>(a.g);
     const long long ic = i < n4 ? i : 0;
-    const float4 g = G[ic];  // all loads of the kernel issued together
+    const bool from_parts = a.nparts > 0 && i >= a.part_off4 && i < a.part_off4 + a.part_n4;
+    float4 g = G[ic];  // all loads of the kernel issued together
     float4 m = M[ic], v = V[ic], p = P[ic], t = T[ic];
+    if (from_parts) {
+        const float4 *PP = reinterpret_cast<const float4 *>(a.part) + (i - a.part_off4);
+        float4 sacc = PP[0];
+        for (int q = 1; q < a.nparts; ++q) {
+            const float4 u = PP[(long long)q * a.part_stride4];
+            sacc.x += u.x; sacc.y += u.y; sacc.z += u.z; sacc.w += u.w;
+        }
+        g = sacc;
+        reinterpret_cast<float4 *>(a.g)[i] = g;  // keep the gradient buffer complete (export / all-reduce)
+    }
     const float b1p_pi = a.opt->b1p_pi, b2p_pi = a.opt->b2p_pi, b1p_q = a.opt->b1p_q, b2p_q = a.opt->b2p_q;
     const float one = 1.0f;
     const float al_pi = a.lr * sqrtf(one - b2p_pi) / (one - b1p_pi);
@@ -694,6 +856,7 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
         if (tk == gridDim.x - 1) {  // every block has read the powers before taking its ticket
             a.opt->b1p_pi = b1p_pi * a.b1; a.opt->b2p_pi = b2p_pi * a.b2; a.opt->b1p_q = b1p_q * a.b1; a.opt->b2p_q = b2p_q * a.b2;
             a.opt->t_pi += 1; a.opt->t_q += 1;
+            a.opt->noise_ctr += a.noise_adv;
             a.opt->ticket_adam = 0;
         }
     }
@@ -726,25 +889,6 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs a) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[w]; i += gridDim.x * 256) a.dst[w][i] = a.src[w][i];
 }
 
-// N(0,1) for the three noise buffers from a device-resident counter; one workgroup so that the
-// counter update needs no cross-block ordering.  Same generator as ddrl_normal_fill /
-// oracle/noise_oracle.normal_fill.
-__global__ void __launch_bounds__(256) k_noise3(float *e0, float *e1, float *e2, int n_each, uint32_t seed, OptState *opt) {
-    const unsigned long long base = opt->noise_ctr;
-    for (int i = threadIdx.x; i < 3 * n_each; i += 256) {
-        const unsigned long long c = base + (unsigned long long)i;
-        const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
-        const uint32_t h1 = ddrl::hash3(seed, lo, 2u * hi), h2 = ddrl::hash3(seed, lo, 2u * hi + 1u);
-        const float u1 = (float)((h1 >> 8) + 1u) * (1.0f / 16777216.0f);
-        const float u2 = ddrl::u01(h2);
-        const float v = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-        const int w = i / n_each, k = i - w * n_each;
-        (w == 0 ? e0 : (w == 1 ? e1 : e2))[k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) opt->noise_ctr = base + (unsigned long long)(3 * n_each);
-}
-
 __global__ void k_copy3(const float *a, const float *b, const float *c, float *oa, float *ob, float *oc, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
@@ -752,6 +896,16 @@ __global__ void k_copy3(const float *a, const float *b, const float *c, float *o
         if (ob) ob[i] = b[i];
         if (oc) oc[i] = c[i];
     }
+}
+
+// gradient of the fused pi layer-1 wgrad = sum of the row-tile partials (same order as in Adam)
+__global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, float *__restrict__ g, long long n, long long stride,
+                                                      int nparts) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float sacc = part[i];
+    for (int q = 1; q < nparts; ++q) sacc += part[(long long)q * stride + i];
+    g[i] = sacc;
 }
 
 __global__ void k_fill_col(float *p, long long rows, int ld, int col, float v) {
@@ -900,19 +1054,27 @@ struct ddrl_sac1 {
     Layout L;
     float *slab;
     float *main_p, *target_p, *m, *v, *grad;
-    float *x, *x2, *a, *r, *d, *e0, *e1, *e2;
-    float *H1, *H2, *dZ2, *dZ1, *xa, *xp;
+    // two sets of input buffers: the sampler may fill set s^1 while an update reads set s
+    // (order inside a set: obs1 obs2 acts rews done eps_x eps_x2 eps_t)
+    float *in[2][8];
+    float *H1, *H2, *dZ2, *dZ1, *xa, *xp, *part;
     float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o, *dq4, *dhead, *loss_part, *losses;
     int ldh1, ldh2, ldxa, ldxp, ldd;
     OptState *opt;
     Seg *segs_d;
-    L1Jobs l1a, l1b;
+    L1Jobs l1a[2];
     GemmJobs g_fa, g_fb, g_bq, g_bpi, g_last;
-    RowsA ra;
-    RowsB rb;
+    RowsA ra[2];
+    RowsB rb[2];
     RowsC rc;
     AdamArgs ad;
     int rows_b_blocks;
+    bool fused_l1_wgrad;  // pi layer-1 wgrad via dgrad-epilogue partials + Adam (needs hidden1 % 4 == 0)
+    // set by ddrl_sac1_fill_noise, consumed by the next compute_grads / apply_grads
+    bool noise_armed;
+    uint32_t noise_seed;
+    unsigned int noise_pending;
+    bool grad_imported;  // the gradient buffer was overwritten by import(GRAD): Adam must not re-sum partials
 };
 
 static int sac1_free(ddrl_sac1 *h) {
@@ -967,8 +1129,11 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     h->ldh1 = (int)pad4(h1 + 1); h->ldh2 = (int)pad4(h2 + 1);
     h->ldxa = (int)pad4(o + a + 1); h->ldxp = (int)pad4(o + 1); h->ldd = (int)pad4(2 * a);
     ALLOC(main_p, NT); ALLOC(target_p, NT); ALLOC(m, NT); ALLOC(v, NT); ALLOC(grad, NT);
-    ALLOC(x, B * o); ALLOC(x2, B * o); ALLOC(a, B * a); ALLOC(r, B); ALLOC(d, B);
-    ALLOC(e0, B * a); ALLOC(e1, B * a); ALLOC(e2, B * a);
+    for (int st = 0; st < 2; ++st) {
+        const size_t cnt[8] = {(size_t)B * o, (size_t)B * o, (size_t)B * a, (size_t)B, (size_t)B, (size_t)B * a, (size_t)B * a, (size_t)B * a};
+        for (int i = 0; i < 8; ++i) items.push_back(Item{&h->in[st][i], reserve(cnt[i])});
+    }
+    ALLOC(part, (size_t)((B + 31) / 32) * (o + 1) * h1);
     ALLOC(H1, (size_t)NEVAL * B * h->ldh1); ALLOC(H2, (size_t)NEVAL * B * h->ldh2);
     ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1);
     ALLOC(xa, (size_t)B * h->ldxa); ALLOC(xp, (size_t)B * h->ldxp);
@@ -978,6 +1143,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
 #undef ALLOC
     const size_t opt_off = reserve((sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((L.segs.size() * sizeof(Seg) + 3) / 4);
+    (void)reserve(2048);  // readable guard behind the last buffer (unclamped tile loads, see OpPre)
     hipError_t e = hipMalloc((void **)&h->slab, slab_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->slab, 0, slab_floats * sizeof(float));
     if (e != hipSuccess) {
@@ -1003,22 +1169,28 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     const float *Pm = h->main_p, *Pt = h->target_p;
     const int ldh1 = h->ldh1, ldh2 = h->ldh2;
     const long long BH1 = (long long)B * ldh1, BH2 = (long long)B * ldh2, BZ1 = (long long)B * h1, BZ2 = (long long)B * h2;
-    // ---- layer-1 jobs.  evals: 0 pi(x) 1 pi(x2) 2 piT(x2) 3 q1(x,a) 4 q2(x,a) | 5 q1(x,pi) 6 q1T(x2,piT) 7 q2T(x2,piT)
-    auto l1 = [&](const float *in0, int d0, const float *in1, int d1, const float *W, const float *b, int ev) {
-        return L1Job{in0, in1, W, b, h->H1 + ev * BH1, nullptr, d0, d1, B, h1, ldh1, 0};
-    };
-    h->l1a.njobs = 5;
-    h->l1a.job[0] = l1(h->x, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 0);
-    h->l1a.job[1] = l1(h->x2, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 1);
-    h->l1a.job[2] = l1(h->x2, o, nullptr, 0, Pt + L.pi_W1, Pt + L.pi_b1, 2);
-    h->l1a.job[3] = l1(h->x, o, h->a, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 3);
-    h->l1a.job[4] = l1(h->x, o, h->a, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 4);
-    h->l1a.job[0].aug_out = h->xp; h->l1a.job[0].aug_ld = h->ldxp;  // [x | 1]      : A operand of the pi layer-1 wgrad
-    h->l1a.job[3].aug_out = h->xa; h->l1a.job[3].aug_ld = h->ldxa;  // [x | a | 1]  : A operand of the Q layer-1 wgrads
-    h->l1b.njobs = 3;
-    h->l1b.job[0] = l1(h->x, o, h->act0, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 5);
-    h->l1b.job[1] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[0], Pt + L.q_b1[0], 6);
-    h->l1b.job[2] = l1(h->x2, o, h->act2, a, Pt + L.q_W1[1], Pt + L.q_b1[1], 7);
+    // ---- layer-1 jobs (one table per input set).  evals: 0 pi(x) 1 pi(x2) 2 piT(x2) 3 q1(x,a) 4 q2(x,a) |
+    // 5 q1(x,pi) 6 q1T(x2,piT) 7 q2T(x2,piT): observation part only here, finished by k_rows_a
+    for (int st = 0; st < 2; ++st) {
+        float *x = h->in[st][0], *x2 = h->in[st][1], *ac = h->in[st][2];
+        auto l1 = [&](const float *in0, int d0, const float *in1, int d1, const float *W, const float *b, int ev, int pre) {
+            return L1Job{in0, in1, W, b, h->H1 + ev * BH1, nullptr, d0, d1, B, h1, ldh1, 0, pre};
+        };
+        L1Jobs &J = h->l1a[st];
+        J.njobs = 8;
+        J.noise_on = 0; J.act = a; J.n_each = B * a; J.noise_seed = 0;
+        J.e0 = h->in[st][5]; J.e1 = h->in[st][6]; J.e2 = h->in[st][7]; J.opt = h->opt;
+        J.job[0] = l1(x, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 0, 0);
+        J.job[1] = l1(x2, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 1, 0);
+        J.job[2] = l1(x2, o, nullptr, 0, Pt + L.pi_W1, Pt + L.pi_b1, 2, 0);
+        J.job[3] = l1(x, o, ac, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 3, 0);
+        J.job[4] = l1(x, o, ac, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 4, 0);
+        J.job[5] = l1(x, o, nullptr, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 5, 1);
+        J.job[6] = l1(x2, o, nullptr, a, Pt + L.q_W1[0], Pt + L.q_b1[0], 6, 1);
+        J.job[7] = l1(x2, o, nullptr, a, Pt + L.q_W1[1], Pt + L.q_b1[1], 7, 1);
+        J.job[0].aug_out = h->xp; J.job[0].aug_ld = h->ldxp;  // [x | 1]      : A operand of the pi layer-1 wgrad
+        J.job[3].aug_out = h->xa; J.job[3].aug_ld = h->ldxa;  // [x | a | 1]  : A operand of the Q layer-1 wgrads
+    }
     // ---- forward layer-2 GEMMs
     auto fwd = [&](const float *P, long long W2, long long b2, int ev) {
         return gemm_fwd(h->H1 + ev * BH1, ldh1, P + W2, P + b2, h->H2 + ev * BH2, ldh2, B, h1, h2);
@@ -1043,27 +1215,40 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         gemm_add(h->g_bq, gemm_wgrad(h->H2 + (3 + q) * BH2, ldh2, h2, h->dq4 + (long long)q * B * 4, 4, 1, G + L.q_W3[q], 1, B));  // W3, b3
     }
     // launch "bwd pi": needs dZ2[3], dhead (k_rows_c) and dZ1[0..1] (launch above)
-    gemm_add(h->g_bpi, gemm_dgrad(h->dZ2 + 3 * BZ2, Pm + L.pi_W2, h->H1 + 0 * BH1, ldh1, h->dZ1 + 3 * BZ1, B, h1, h2));
+    {
+        GemmJob j = gemm_dgrad(h->dZ2 + 3 * BZ2, Pm + L.pi_W2, h->H1 + 0 * BH1, ldh1, h->dZ1 + 3 * BZ1, B, h1, h2);
+        h->fused_l1_wgrad = (h1 % 4 == 0) && (o + 1 <= 12) && (L.pi_W1 % 4 == 0);
+        if (h->fused_l1_wgrad) { j.part_x = h->xp; j.part = h->part; j.part_nk = o + 1; j.part_ldx = h->ldxp; }
+        gemm_add(h->g_bpi, j);
+    }
     gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, ldh1, h1, h->dZ2 + 3 * BZ2, h2, h2, G + L.pi_W2, h2, B));     // W2, b2
     gemm_add(h->g_bpi, gemm_wgrad(h->H2, ldh2, h2, h->dhead, h->ldd, a, G + L.pi_Wmu, a, B));                      // Wmu, bmu
     gemm_add(h->g_bpi, gemm_wgrad(h->H2, ldh2, h2, h->dhead + a, h->ldd, a, G + L.pi_Wls, a, B));                  // Wls, bls
     for (int q = 0; q < 2; ++q)
         gemm_add(h->g_bpi, gemm_wgrad(h->xa, h->ldxa, o + a, h->dZ1 + q * BZ1, h1, h1, G + L.q_W1[q], h1, B));    // Q W1, b1
-    // launch "last": needs dZ1[3]
-    gemm_add(h->g_last, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 3 * BZ1, h1, h1, G + L.pi_W1, h1, B));               // pi W1, b1
+    // launch "last" (only when the fused form is unavailable): needs dZ1[3]
+    if (!h->fused_l1_wgrad) gemm_add(h->g_last, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 3 * BZ1, h1, h1, G + L.pi_W1, h1, B));               // pi W1, b1
 
     // ---- row kernels
-    h->ra = RowsA{h->H2, net_pi(Pm, L), net_pi(Pt, L), net_q(Pm, L, 0), net_q(Pm, L, 1), h->e0, h->e1, h->e2,
-                  h->act0, h->act2, h->logp0, h->logp1, h->save0, h->q1o, h->q2o, B, h2, ldh2, a, (float)cfg->act_scale};
-    h->rb = RowsB{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_q(Pt, L, 0), net_q(Pt, L, 1), h->r, h->d, h->logp0,
-                  h->logp1, h->q1o, h->q2o, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
-                  (float)cfg->alpha, (float)cfg->gamma};
+    for (int st = 0; st < 2; ++st) {
+        h->ra[st] = RowsA{h->H2, net_pi(Pm, L), net_pi(Pt, L), net_q(Pm, L, 0), net_q(Pm, L, 1),
+                          h->in[st][5], h->in[st][6], h->in[st][7],
+                          h->act0, h->act2, h->logp0, h->logp1, h->save0, h->q1o, h->q2o,
+                          h->H1, Pm + L.q_W1[0] + (long long)o * h1, Pt + L.q_W1[0] + (long long)o * h1,
+                          Pt + L.q_W1[1] + (long long)o * h1, B, h2, ldh2, a, h1, ldh1, (float)cfg->act_scale};
+        h->rb[st] = RowsB{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_q(Pt, L, 0), net_q(Pt, L, 1), h->in[st][3], h->in[st][4],
+                          h->logp0, h->logp1, h->q1o, h->q2o, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
+                          (float)cfg->alpha, (float)cfg->gamma};
+    }
     h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 3 * BZ2,
                   h->loss_part, h->losses, B, h1, h2, ldh2, o, a, h->ldd, h->rows_b_blocks, (float)cfg->alpha,
                   (float)cfg->act_scale};
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, L.total_int, L.n_pi_int,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
-                     (float)cfg->polyak, (float)(1.0 - cfg->polyak)};
+                     (float)cfg->polyak, (float)(1.0 - cfg->polyak),
+                     h->part, L.pi_W1 / 4, (long long)(o + 1) * h1 / 4, (long long)(o + 1) * h1 / 4,
+                     h->fused_l1_wgrad ? (B + 31) / 32 : 0, 0u};
+    h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
     *out = h;
     return DDRL_OK;
 }
@@ -1090,6 +1275,11 @@ int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream) {
     float *buf = which_buf(h, which);
     DDRL_REQUIRE(buf != nullptr, "unknown buffer id");
     ddrl::DeviceGuard g(h->device);
+    if (which == DDRL_SAC1_GRAD && h->fused_l1_wgrad && !h->grad_imported) {
+        // the pi layer-1 gradient exists only as row-tile partials until Adam runs: materialise it
+        const long long n = (long long)(h->cfg.obs_dim + 1) * h->cfg.hidden1;
+        k_reduce_parts<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->part, h->grad + h->L.pi_W1, n, n, h->ad.nparts);
+    }
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, buf, flat_d, nullptr, 0);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
@@ -1102,6 +1292,7 @@ int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *strea
     ddrl::DeviceGuard g(h->device);
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_d, buf, nullptr, 1);
     DDRL_LAUNCH_CHECK();
+    if (which == DDRL_SAC1_GRAD) h->grad_imported = true;
     return DDRL_OK;
 }
 
@@ -1131,28 +1322,27 @@ int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *s
     return DDRL_OK;
 }
 
-// One stage of the update.  Stage ids as documented for ddrl_sac1_stage_time in include/ddrl.h.
-static void launch_stage(ddrl_sac1 *h, int stage, hipStream_t s) {
+// One stage of the update (input set `st`).  Stage ids as documented for ddrl_sac1_stage_time.
+static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const ddrl_sac1_config_t &c = h->cfg;
     const int B = c.batch;
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
     switch (stage) {
-        case 1: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a.njobs), 256, 0, s>>>(h->l1a); break;
+        case 1: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
         case 2: k_gemm<<<h->g_fa.total_tiles, 256, 0, s>>>(h->g_fa); break;
-        case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra); break;
-        case 4: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1b.njobs), 256, 0, s>>>(h->l1b); break;
+        case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]); break;
         case 5: k_gemm<<<h->g_fb.total_tiles, 256, 0, s>>>(h->g_fb); break;
-        case 6: k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb); break;
+        case 6: k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb[st]); break;
         case 7: k_gemm<<<h->g_bq.total_tiles, 256, 0, s>>>(h->g_bq); break;
         case 8: k_rows_c<<<(B + 3) / 4, 256, 0, s>>>(h->rc); break;
         case 9: k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi); break;
-        case 10: k_gemm<<<h->g_last.total_tiles, 256, 0, s>>>(h->g_last); break;
+        case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, 0, s>>>(h->g_last); break;
         case 11: {
             const long long blocks = (h->L.total_int / 4 + 255) / 256;
             k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
             break;
         }
-        default: break;
+        default: break;  // 4: folded into stage 3
     }
 }
 
@@ -1162,16 +1352,25 @@ static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, cons
     const ddrl_sac1_config_t &c = h->cfg;
     const int B = c.batch;
     const float *src[8] = {obs1, obs2, acts, rews, done, e0, e1, e2};
-    float *dst[8] = {h->x, h->x2, h->a, h->r, h->d, h->e0, h->e1, h->e2};
-    bool in_place = true;
-    for (int i = 0; i < 8; ++i) in_place = in_place && (src[i] == dst[i]);
-    if (!in_place) {  // callers that gather straight into ddrl_sac1_input_buffers skip this copy (stage 0)
-        StageArgs st{};
-        const int n[8] = {B * c.obs_dim, B * c.obs_dim, B * c.act_dim, B, B, B * c.act_dim, B * c.act_dim, B * c.act_dim};
-        for (int i = 0; i < 8; ++i) { st.src[i] = src[i]; st.dst[i] = dst[i]; st.n[i] = n[i]; }
-        k_stage<<<dim3((unsigned)((B * c.obs_dim + 255) / 256), 8), 256, 0, s>>>(st);
+    int st = -1;  // which input set the caller's pointers are (zero-copy), if any
+    for (int cand = 0; cand < 2 && st < 0; ++cand) {
+        bool same = true;
+        for (int i = 0; i < 8; ++i) same = same && (src[i] == h->in[cand][i]);
+        if (same) st = cand;
     }
-    for (int stage = 1; stage <= 10; ++stage) launch_stage(h, stage, s);
+    if (st < 0) {  // stage 0: copy the caller's batch into set 0
+        st = 0;
+        StageArgs sa{};
+        const int n[8] = {B * c.obs_dim, B * c.obs_dim, B * c.act_dim, B, B, B * c.act_dim, B * c.act_dim, B * c.act_dim};
+        for (int i = 0; i < 8; ++i) { sa.src[i] = src[i]; sa.dst[i] = h->in[0][i]; sa.n[i] = n[i]; }
+        k_stage<<<dim3((unsigned)((B * c.obs_dim + 255) / 256), 8), 256, 0, s>>>(sa);
+    }
+    h->l1a[st].noise_on = h->noise_armed ? 1 : 0;
+    h->l1a[st].noise_seed = h->noise_seed;
+    h->noise_pending = h->noise_armed ? (unsigned)(3 * B * c.act_dim) : 0u;
+    h->noise_armed = false;
+    h->grad_imported = false;
+    for (int stage = 1; stage <= 10; ++stage) launch_stage(h, stage, st, s);
     DDRL_LAUNCH_CHECK();
     if (losses_d) DDRL_HIP_CHECK(hipMemcpyAsync(losses_d, h->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (q1_d || q2_d || logp_d) {
@@ -1182,25 +1381,31 @@ static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, cons
 }
 
 static int launch_apply(ddrl_sac1 *h, hipStream_t s) {
-    launch_stage(h, 11, s);
+    h->ad.noise_adv = h->noise_pending;
+    h->noise_pending = 0;
+    const int nparts = h->ad.nparts;
+    if (h->grad_imported) h->ad.nparts = 0;  // use the imported (e.g. all-reduced) gradient as is
+    launch_stage(h, 11, 0, s);
+    h->ad.nparts = nparts;
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
 
-int ddrl_sac1_input_buffers(ddrl_sac1_t *h, float **bufs_h) {
-    DDRL_REQUIRE(h != nullptr && bufs_h != nullptr, "NULL pointer");
-    float *b[8] = {h->x, h->x2, h->a, h->r, h->d, h->e0, h->e1, h->e2};
-    for (int i = 0; i < 8; ++i) bufs_h[i] = b[i];
+int ddrl_sac1_input_buffers(ddrl_sac1_t *h, int set, float **bufs_h) {
+    DDRL_REQUIRE(h != nullptr && bufs_h != nullptr && (set == 0 || set == 1), "NULL pointer or set not in {0,1}");
+    for (int i = 0; i < 8; ++i) bufs_h[i] = h->in[set][i];
     return DDRL_OK;
 }
 
 int ddrl_sac1_batch(ddrl_sac1_t *h) { return h ? h->cfg.batch : DDRL_ERR_BAD_ARG; }
 
 int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream) {
+    // No kernel of its own: the next compute_grads / step generates eps_x, eps_x2, eps_t inside its
+    // first kernel (k_l1) from hash(seed, device counter + i) and its Adam kernel advances the counter.
     DDRL_REQUIRE(h != nullptr, "handle is NULL");
-    ddrl::DeviceGuard g(h->device);
-    k_noise3<<<1, 256, 0, ddrl::as_stream(stream)>>>(h->e0, h->e1, h->e2, h->cfg.batch * h->cfg.act_dim, seed, h->opt);
-    DDRL_LAUNCH_CHECK();
+    (void)stream;
+    h->noise_armed = true;
+    h->noise_seed = seed;
     return DDRL_OK;
 }
 
@@ -1212,9 +1417,9 @@ int ddrl_sac1_stage_time(ddrl_sac1_t *h, int stage, int reps, float *ms_per_laun
     hipEvent_t e0, e1;
     DDRL_HIP_CHECK(hipEventCreate(&e0));
     DDRL_HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch_stage(h, stage, s);
+    for (int i = 0; i < 3; ++i) launch_stage(h, stage, 0, s);
     DDRL_HIP_CHECK(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) launch_stage(h, stage, s);
+    for (int i = 0; i < reps; ++i) launch_stage(h, stage, 0, s);
     DDRL_HIP_CHECK(hipEventRecord(e1, s));
     DDRL_LAUNCH_CHECK();
     DDRL_HIP_CHECK(hipStreamSynchronize(s));
@@ -1279,10 +1484,11 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
     h->device = device; h->cfg = *cfg; h->max_rows = max_rows;
     h->L = make_layout(*cfg, true);
     h->pi_p = h->H1 = h->H2 = nullptr; h->segs_d = nullptr;
-    hipError_t e = dev_alloc(&h->pi_p, (size_t)h->L.total_int);
+    const size_t guard = 2048;  // floats of readable memory behind every GEMM operand (unclamped tile loads)
+    hipError_t e = dev_alloc(&h->pi_p, (size_t)h->L.total_int + guard);
     h->ldh1 = (int)pad4(cfg->hidden1); h->ldh2 = (int)pad4(cfg->hidden2);
-    if (e == hipSuccess) e = dev_alloc(&h->H1, (size_t)max_rows * h->ldh1);
-    if (e == hipSuccess) e = dev_alloc(&h->H2, (size_t)max_rows * h->ldh2);
+    if (e == hipSuccess) e = dev_alloc(&h->H1, (size_t)max_rows * h->ldh1 + guard);
+    if (e == hipSuccess) e = dev_alloc(&h->H2, (size_t)max_rows * h->ldh2 + guard);
     if (e == hipSuccess) e = dev_alloc(&h->segs_d, h->L.segs.size());
     if (e != hipSuccess) {
         ddrl::set_error("hipMalloc failed in ddrl_actor_create: %s", hipGetErrorString(e));
@@ -1329,7 +1535,7 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     const Layout &L = h->L;
     L1Jobs l1{};
     l1.njobs = 1;
-    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, nullptr, c.obs_dim, 0, (int)n, c.hidden1, h->ldh1, 0};
+    l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, nullptr, c.obs_dim, 0, (int)n, c.hidden1, h->ldh1, 0, 0};
     k_l1<<<dim3((c.hidden1 + 255) / 256, (unsigned)((n + L1_ROWS - 1) / L1_ROWS), 1), 256, 0, s>>>(l1);
     GemmJobs gj{};
     gemm_add(gj, gemm_fwd(h->H1, h->ldh1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, h->ldh2, (int)n, c.hidden1, c.hidden2));

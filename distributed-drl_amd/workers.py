@@ -271,6 +271,7 @@ class TrainDevice:
         self._lib, self._libmod = _lib.load(), _lib
         h = ctypes.c_void_p()
         seed = (int(getattr(opt, "seed", 0)) * 2654435761 + 97 * int(learner_index) + 1) & 0xFFFFFFFF
+        self.noise_seed = seed
         _lib.check(self._lib.ddrl_loop_create(ctypes.byref(h), self.agent._h, replay_buffer._h, int(updates_per_graph), seed))
         self._h = h
 

@@ -201,22 +201,27 @@ int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream);
 
 /* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
  * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of
- * device pointers).  Passing exactly these pointers to ddrl_sac1_step / compute_grads skips the
- * staging copy, so ddrl_replay_sample can gather straight into the learner (zero-copy). */
-int ddrl_sac1_input_buffers(ddrl_sac1_t *h, float **bufs_h);
+ * device pointers).  There are two sets (set = 0 or 1) so that a sampler can fill one set while an
+ * update reads the other.  Passing exactly the eight pointers of one set to ddrl_sac1_step /
+ * compute_grads skips the staging copy: ddrl_replay_sample gathers straight into the learner. */
+int ddrl_sac1_input_buffers(ddrl_sac1_t *h, int set, float **bufs_h);
 /* The batch size the learner was created with. */
 int ddrl_sac1_batch(ddrl_sac1_t *h);
-/* Fill the three internal noise buffers with N(0,1) from the counter generator
- * (hash(seed, counter+i)); the counter lives on the device and advances by 3*B*act per call, so
- * the call can be captured in a hipGraph.  Stand-in for tf.random_normal (core.py:77). */
+/* Arm noise generation for the NEXT ddrl_sac1_step / compute_grads: its first kernel fills the
+ * three noise buffers of the input set in use with N(0,1) from the counter generator
+ * (hash(seed, counter+i), same values as ddrl_normal_fill over a flat [3][B*act] buffer); the
+ * counter lives on the device and advances by 3*B*act in that update's Adam kernel, so the
+ * sequence can be captured in a hipGraph.  Stand-in for tf.random_normal (core.py:77).  No device
+ * work is enqueued by this call itself. */
 int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream);
 /* Roofline accounting (bench.py): launch one stage of the update `reps` times back to back on
  * `stream` between two HIP events (after 3 untimed launches) and return the mean milliseconds
  * per launch (host output); synchronises `stream`.  The stages read the buffers left by the last
  * ddrl_sac1_step and are idempotent.  Stage ids (launch order of one update):
- * 1 layer1(A: 5 nets) 2 gemm fwd(A) 3 heads(A) 4 layer1(B: 3 nets) 5 gemm fwd(B) 6 heads(B)+losses
- * 7 gemm bwd(Q: 3 dgrad + 4 wgrad) 8 policy-head bwd 9 gemm bwd(pi: 1 dgrad + 5 wgrad)
- * 10 gemm (pi layer-1 wgrad).  [0 = input staging copy, 11 = adam+polyak: not idempotent] */
+ * 1 layer1 (8 nets; + noise) 2 gemm fwd(A: 5 nets) 3 heads(A) + 2nd-phase layer1 4 (folded into 3)
+ * 5 gemm fwd(B: 3 nets) 6 heads(B)+losses 7 gemm bwd(Q: 3 dgrad + 4 wgrad) 8 policy-head bwd
+ * 9 gemm bwd(pi: 1 dgrad [+ fused layer-1 wgrad partials] + 5 wgrad) 10 (pi layer-1 wgrad; only
+ * when the fused form is unavailable).  [0 = input staging copy, 11 = adam+polyak: not idempotent] */
 #define DDRL_SAC1_STAGES 12
 int ddrl_sac1_stage_time(ddrl_sac1_t *h, int stage, int reps, float *ms_per_launch_h, void *stream);
 
@@ -224,10 +229,13 @@ int ddrl_sac1_stage_time(ddrl_sac1_t *h, int stage, int reps, float *ms_per_laun
 /* Learner hot loop — replaces the body of worker_train                                    */
 /*   `while True: batch = sample_batch(B); agent.train(batch)`                              */
 /*   (algos/sac1/sac1.py:146-148; example/dsac.py:142-144 + example/model.py:92-101)        */
-/* sample (MT19937 indices + gather, straight into the learner's buffers) -> noise -> update, */
-/* n times, with no host work per update: the sequence for `updates_per_graph` updates is   */
-/* captured once into a hipGraph (all cursors, RNG state and Adam state are device-resident) */
-/* and replayed.                                                                            */
+/* sample (MT19937 indices + gather, straight into the learner's buffers) -> update, n times, */
+/* with no host work per update: the sequence for `updates_per_graph` updates is captured     */
+/* once into a hipGraph (all cursors, RNG state and Adam state are device-resident) and       */
+/* replayed.  Consecutive updates alternate between the learner's two input sets; with         */
+/* DDRL_LOOP_FORK=1 the sampler runs on a forked graph branch so that sample(u+1) overlaps      */
+/* update(u) — the role of the reference's `Cache` prefetch process (sac1.py:103-130); measured */
+/* slower than inline on MI355X, hence opt-in.                                      */
 /* ===================================================================================== */
 typedef struct ddrl_loop ddrl_loop_t;
 int ddrl_loop_create(ddrl_loop_t **out, ddrl_sac1_t *learner, ddrl_replay_t *replay, int32_t updates_per_graph,

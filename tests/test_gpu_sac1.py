@@ -190,3 +190,50 @@ def test_actor_matches_oracle(ddrl):
     a1 = actor.get_action(obs[0], eps=eps[:1])
     assert a1.shape == (2,) and a1.dtype == np.float32
     np.testing.assert_array_equal(a1, actor.get_actions(obs[:1], eps=eps[:1]).cpu().numpy()[0])
+
+
+def test_graph_loop_equals_eager_sample_noise_train(ddrl):
+    """ddrl_loop_run (hipGraph, sampler on a forked branch into the alternate input set, noise
+    generated inside the first kernel from the device counter) == the same updates issued one by
+    one through the public surface with ddrl_normal_fill noise — bit for bit."""
+    import ctypes
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    from distributed_drl_amd.workers import TrainDevice
+    lib = _lib.load()
+    opt = HyperParameters()
+    opt.seed, opt.batch_size, opt.push_freq = 3, 256, 7
+    rs = np.random.RandomState(0)
+    n = 5000
+    data = [rs.randn(n, 8).astype(np.float32), rs.uniform(-1, 1, (n, 2)).astype(np.float32), rs.randn(n).astype(np.float32),
+            rs.randn(n, 8).astype(np.float32), (rs.rand(n) < 0.05).astype(np.float32)]
+    rbs = []
+    for _ in range(2):
+        rb = ddrl.ReplayBufferSAC1(8, 2, 8192, seed=11)
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in data))
+        rbs.append(rb)
+    keys, vals = Learner(opt).get_weights()
+    ps = ddrl.ParameterServer(keys, vals)
+    td = TrainDevice(ps, rbs[0], opt, updates_per_graph=4)
+    v0 = ps.version
+    n_upd = 23
+    td.run(n_upd)          # 1 eager + 5 graph replays of 4 + 2 eager; pushes after updates 7, 14, 21
+    ref = Learner(opt)
+    B, a = 256, 2
+    pushed = None
+    for u in range(n_upd):
+        batch = rbs[1].sample_batch_device(B)
+        e = torch.empty(3 * B * a, device="cuda")
+        _lib.check(lib.ddrl_normal_fill(_lib.dptr(e), e.numel(), td.noise_seed, u * 3 * B * a, _lib.stream_ptr()))
+        e = e.view(3, B, a)
+        ref.train(batch, eps=(e[0], e[1], e[2]))
+        if (u + 1) % 7 == 0:
+            pushed = ref.get_weights_flat().clone()
+    for which in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V):
+        assert torch.equal(td.agent.export(which), ref.export(which)), which
+    assert td.agent.opt_steps() == (n_upd, n_upd)
+    assert rbs[0].get_counts() == rbs[1].get_counts()
+    k0, p0 = rbs[0].mt_state()
+    k1, p1 = rbs[1].mt_state()
+    assert p0 == p1 and (k0 == k1).all()
+    assert ps.version == v0 + 3 and torch.equal(ps.pull_flat(0, td.agent.n_params), pushed)
