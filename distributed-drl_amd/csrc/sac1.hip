@@ -127,8 +127,15 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
     if (r0 >= jb.rows) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int jc = j < jb.h1 ? j : jb.h1 - 1;
-    for (int k = 0; k < din; ++k) s_w[k][threadIdx.x] = jb.W[(long long)k * jb.h1 + jc];  // independent loads, stores only
     const float bj = jb.b[jc];
+    for (int k0 = 0; k0 < din; k0 += 16) {  // 16 loads in flight per round trip (din <= 16: one trip)
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = jb.W[(long long)(k0 + u < din ? k0 + u : 0) * jb.h1 + jc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (k0 + u < din) s_w[k0 + u][threadIdx.x] = wv[u];
+    }
     for (int e = threadIdx.x; e < L1_ROWS * din; e += 256) {
         const int rr = e / din, k = e - rr * din;
         const int r = r0 + rr;
@@ -706,11 +713,26 @@ struct RowsC {
 };
 __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x < 3) {  // reduce_mean over the batch, fixed order
-        float s = 0.f;
-        for (int b = 0; b < a.loss_blocks; ++b) s += a.loss_part[b * 3 + threadIdx.x];
-        const float mean = s / (float)a.B;
-        a.losses[threadIdx.x] = threadIdx.x == 0 ? mean : 0.5f * mean;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
+        // reduce_mean over the batch: the extra last block's 4th wave sums the block partials of
+        // k_rows_b in a fixed order (lane-strided partial sums, then the xor-shuffle tree)
+        const int ln = threadIdx.x - 192;
+        float s3[3] = {0.f, 0.f, 0.f};
+        for (int b0 = 0; b0 < a.loss_blocks; b0 += 64) {
+            const int b = b0 + ln;
+            const bool ok = b < a.loss_blocks;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = a.loss_part[(ok ? b : 0) * 3 + c];
+                s3[c] += ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float tot = wave_sum(s3[c]);
+            const float mean = tot / (float)a.B;
+            if (ln == 0) a.losses[c] = c == 0 ? mean : 0.5f * mean;
+        }
     }
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.B) return;
@@ -829,10 +851,14 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     float4 m = M[ic], v = V[ic], p = P[ic], t = T[ic];
     if (from_parts) {
         const float4 *PP = reinterpret_cast<const float4 *>(a.part) + (i - a.part_off4);
-        float4 sacc = PP[0];
-        for (int q = 1; q < a.nparts; ++q) {
-            const float4 u = PP[(long long)q * a.part_stride4];
-            sacc.x += u.x; sacc.y += u.y; sacc.z += u.z; sacc.w += u.w;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q0 = 0; q0 < a.nparts; q0 += 8) {  // 8 partials per round trip, summed in tile order
+            float4 u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = PP[(long long)(q0 + q < a.nparts ? q0 + q : 0) * a.part_stride4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q0 + q < a.nparts) { sacc.x += u[q].x; sacc.y += u[q].y; sacc.z += u[q].z; sacc.w += u[q].w; }
         }
         g = sacc;
         reinterpret_cast<float4 *>(a.g)[i] = g;  // keep the gradient buffer complete (export / all-reduce)
@@ -903,8 +929,8 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
                                                       int nparts) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float sacc = part[i];
-    for (int q = 1; q < nparts; ++q) sacc += part[(long long)q * stride + i];
+    float sacc = 0.f;  // same order of additions as k_adam_polyak
+    for (int q = 0; q < nparts; ++q) sacc += part[(long long)q * stride + i];
     g[i] = sacc;
 }
 
@@ -1334,7 +1360,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
         case 5: k_gemm<<<h->g_fb.total_tiles, 256, 0, s>>>(h->g_fb); break;
         case 6: k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb[st]); break;
         case 7: k_gemm<<<h->g_bq.total_tiles, 256, 0, s>>>(h->g_bq); break;
-        case 8: k_rows_c<<<(B + 3) / 4, 256, 0, s>>>(h->rc); break;
+        case 8: k_rows_c<<<(B + 3) / 4 + 1, 256, 0, s>>>(h->rc); break;  // +1: the loss-reduction block
         case 9: k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi); break;
         case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, 0, s>>>(h->g_last); break;
         case 11: {
