@@ -5,8 +5,9 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + '/*/*counter_collection.csv')
-rows = list(csv.DictReader(open(f[0])))
+import os
+f = sorted(glob.glob(sys.argv[1] + '/*/*counter_collection.csv'), key=os.path.getmtime)
+rows = list(csv.DictReader(open(f[-1])))  # newest run in the directory
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for r in rows:

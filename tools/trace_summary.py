@@ -5,7 +5,8 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+import os
+f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)[-1]  # newest run
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
