@@ -12,6 +12,7 @@
 #include "ddrl_common.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 struct ddrl_loop {
@@ -46,42 +47,72 @@ static int one_update(ddrl_loop *h, void *stream) {
     return update_from(h, set, stream);
 }
 
-// Capture `per_graph` updates with the sampler on a forked branch.
+static int grads_from(ddrl_loop *h, int set, void *stream) {
+    float **b = h->buf[set];
+    int rc = ddrl_sac1_fill_noise(h->learner, h->seed, stream);
+    if (rc != DDRL_OK) return rc;
+    return ddrl_sac1_compute_grads(h->learner, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr,
+                                   stream);
+}
+
+// Capture `per_graph` updates.  Default: everything inline on one branch (81.5 us/update).
+// Experimental overlap modes (bit-identical results, both measured SLOWER on MI355X — a kernel
+// starting or ending on another branch costs the kernel running beside it more than it hides):
+//   DDRL_LOOP_FORK=adam  sampler of update u+1 beside the Adam/polyak kernel of update u (105 us)
+//   DDRL_LOOP_FORK=all   sampler of update u+1 anywhere beside update u (99 us)
 static int capture(ddrl_loop *h, hipStream_t main_s) {
+    const char *fk = getenv("DDRL_LOOP_FORK");
+    const int mode = !fk ? 0 : (strcmp(fk, "all") == 0 ? 2 : 1);
     hipStream_t side = nullptr;
     DDRL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     const int n = h->per_graph;
-    std::vector<hipEvent_t> e_smp(n), e_upd(n);
+    std::vector<hipEvent_t> e_smp(n + 1), e_upd(n + 1), e_grad(n + 1);
     hipEvent_t e_fork;
     DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i <= n; ++i) {
         DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_smp[i], hipEventDisableTiming));
         DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_upd[i], hipEventDisableTiming));
+        DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_grad[i], hipEventDisableTiming));
     }
     hipGraph_t graph = nullptr;
     int rc = DDRL_OK;
     DDRL_HIP_CHECK(hipStreamBeginCapture(main_s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipEventRecord(e_fork, main_s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side, e_fork, 0);  // fork
-    // Measured on MI355X: with the sampler on a forked branch an update takes 99 us, inline 93 us — a
-    // kernel that starts or ends on the other branch perturbs the running GEMM (cache invalidate /
-    // write-back at every kernel boundary), which costs more than the 7 us sampler it hides.  The
-    // fork therefore is opt-in (DDRL_LOOP_FORK=1); results are bit-identical either way.
-    const bool fork = getenv("DDRL_LOOP_FORK") != nullptr;
-    for (int i = 0; i < n && rc == DDRL_OK && e == hipSuccess; ++i) {
-        const int set = i & 1;
-        hipStream_t ss = fork ? side : main_s;
-        // set `set` was last read by update i-2: the sampler must not overwrite it earlier
-        if (fork && i >= 2) e = hipStreamWaitEvent(side, e_upd[i - 2], 0);
-        if (e == hipSuccess) rc = sample_into(h, set, (void *)ss);
-        if (fork && e == hipSuccess && rc == DDRL_OK) e = hipEventRecord(e_smp[i], side);
-        if (fork && e == hipSuccess) e = hipStreamWaitEvent(main_s, e_smp[i], 0);
-        if (e == hipSuccess && rc == DDRL_OK) rc = update_from(h, set, (void *)main_s);
-        if (e == hipSuccess && rc == DDRL_OK) e = hipEventRecord(e_upd[i], main_s);
+    hipError_t e = hipSuccess;
+#define HE(x) do { if (e == hipSuccess && rc == DDRL_OK) e = (x); } while (0)
+#define RC(x) do { if (e == hipSuccess && rc == DDRL_OK) rc = (x); } while (0)
+    if (mode == 0) {
+        for (int i = 0; i < n; ++i) { RC(sample_into(h, i & 1, (void *)main_s)); RC(update_from(h, i & 1, (void *)main_s)); }
+    } else if (mode == 2) {
+        HE(hipEventRecord(e_fork, main_s));
+        HE(hipStreamWaitEvent(side, e_fork, 0));
+        for (int i = 0; i < n; ++i) {
+            if (i >= 2) HE(hipStreamWaitEvent(side, e_upd[i - 2], 0));  // set i&1 was last read by update i-2
+            RC(sample_into(h, i & 1, (void *)side));
+            HE(hipEventRecord(e_smp[i], side));
+            HE(hipStreamWaitEvent(main_s, e_smp[i], 0));
+            RC(update_from(h, i & 1, (void *)main_s));
+            HE(hipEventRecord(e_upd[i], main_s));
+        }
+    } else {
+        // sample(0) inline; then for each update: grads(i) -> [fork: sample(i+1)] || apply(i) -> join
+        RC(sample_into(h, 0, (void *)main_s));
+        for (int i = 0; i < n; ++i) {
+            RC(grads_from(h, i & 1, (void *)main_s));
+            if (i + 1 < n) {
+                HE(hipEventRecord(e_grad[i], main_s));
+                HE(hipStreamWaitEvent(side, e_grad[i], 0));
+                RC(sample_into(h, (i + 1) & 1, (void *)side));
+                HE(hipEventRecord(e_smp[i + 1], side));
+            }
+            RC(ddrl_sac1_apply_grads(h->learner, (void *)main_s));
+            if (i + 1 < n) HE(hipStreamWaitEvent(main_s, e_smp[i + 1], 0));
+        }
     }
+#undef HE
+#undef RC
     // every side-branch node is an ancestor of a main-stream node: the branch is joined
     hipError_t e2 = hipStreamEndCapture(main_s, &graph);
-    for (int i = 0; i < n; ++i) { (void)hipEventDestroy(e_smp[i]); (void)hipEventDestroy(e_upd[i]); }
+    for (int i = 0; i <= n; ++i) { (void)hipEventDestroy(e_smp[i]); (void)hipEventDestroy(e_upd[i]); (void)hipEventDestroy(e_grad[i]); }
     (void)hipEventDestroy(e_fork);
     (void)hipStreamDestroy(side);
     if (rc != DDRL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
