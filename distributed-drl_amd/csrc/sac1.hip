@@ -71,6 +71,8 @@ struct GemmJobs {
     long long *stamps;  // diagnostic builds only (tools/gemm_bench.hip): [grid][32] cycle stamps of wave 0
 #endif
     int njobs, total_tiles;
+    int ks_max;   // deepest sub-chunk of any job in this launch (two-chunk loop): sizes the LDS tiles
+    int op_lds;   // floats per operand tile = max(32 * (ks_max + 2), ks_max * 36, 32 * 36)
     int tile_start[MAX_GEMM_JOBS];  // flat copy: the job lookup is one scalar load, not a pointer chase
     GemmJob job[MAX_GEMM_JOBS];
 };
@@ -197,8 +199,9 @@ __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
 // Jobs whose operands are not 16-B aligned / stride % 4 (odd layer sizes) take a slow path with
 // per-element guards.
 // ------------------------------------------------------------------------------------------
-constexpr int KS = 32;
-constexpr int OP_LDS = 32 * 36;  // floats per operand tile
+constexpr int KS = 32;             // sub-chunk depth of the streaming (slow-path) loop
+constexpr int KS2 = 64;            // maximum sub-chunk depth of the two-chunk loop
+constexpr int RED_LDS = 4 * 32 * 33; // floats of the split-K combine buffer (aliases the operand tiles)
 
 __device__ __forceinline__ float4 sel4(bool c0, bool c1, bool c2, bool c3, float4 t) {
     return make_float4(c0 ? t.x : 0.f, c1 ? t.y : 0.f, c2 ? t.z : 0.f, c3 ? t.w : 0.f);
@@ -293,6 +296,144 @@ __device__ __forceinline__ void rd_tile(const float *__restrict__ s, int l31, in
     }
 }
 
+// ---- two-chunk K loop (fast path) ----------------------------------------------------------------
+// A wave's K range (<= 128) is processed as exactly TWO balanced sub-chunks of depth ks <= 64
+// (K/4 = 100 -> 52 + 48, 76 -> 40 + 36, 64 -> 32 + 32): cutting it into fixed 32-deep pieces left a
+// nearly empty last piece that still paid the full stage/read overhead.  The LDS tiles are
+// wave-private, so no workgroup barrier is needed inside the loop — only wave-level ordering of the
+// wave's own LDS writes and reads (the LDS queue of a wave is in-order; the fence keeps the compiler
+// and the counters honest).  The second chunk's global loads are issued as soon as the first chunk
+// has been staged, i.e. they fly during the first chunk's LDS reads and 2 x 13 MFMAs.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // s_waitcnt lgkmcnt(0): this wave's LDS ops are done
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool KC>
+struct Op2 {
+    const float4 *p[8];  // per-lane source of instruction i in chunk 0
+    bool okr[8];         // KC: row (idx) valid            NC: unused
+    bool okc[4];         // NC: column idx + e valid        KC: unused
+    int kk;              // KC: k offset of this lane's float4 inside a chunk (c4)   NC: unused
+    int krow[8];         // NC: k row of instruction i inside a chunk               KC: unused
+    __device__ __forceinline__ void init(const float *base, int ld, int idx0, int nidx, int k0, int lane) {
+        if (KC) {  // image [32 idx][64 k]: 16 float4 per row, 4 rows per instruction
+            const int r4 = lane >> 4;
+            kk = (lane & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = idx0 + i * 4 + r4;
+                okr[i] = row < nidx;
+                p[i] = reinterpret_cast<const float4 *>(base + ((okr[i] ? row : 0) * ld + k0 + kk));
+            }
+        } else {   // image [64 k][32 idx]: 8 float4 per k row, 8 rows per instruction
+            const int r8 = lane >> 3, c4 = (lane & 7) * 4, col = idx0 + c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) okc[e] = col + e < nidx;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                krow[i] = i * 8 + r8;
+                p[i] = reinterpret_cast<const float4 *>(base + ((k0 + krow[i]) * ld + (okc[0] ? col : 0)));
+            }
+        }
+    }
+    // chunk `ch` (0/1) starts ks0 elements after k0 and is `ks` deep; loads outside it are skipped
+    __device__ __forceinline__ void load(int ch, int ks0, int ks, int ld, float4 (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (KC) {
+                const bool ok = kk < ks;
+                v[i] = ok ? p[i][(ch ? ks0 : 0) >> 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (i * 8 < ks) {  // uniform skip of instructions wholly beyond the chunk
+                const bool ok = krow[i] < ks;
+                v[i] = ok ? p[i][(long long)(ch ? ks0 : 0) * ld >> 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    // kcs = row stride of the K-contiguous image (ks_max + 2, even)
+    __device__ __forceinline__ void store(float *__restrict__ s, int ks, int kcs, int lane, const float4 (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (KC) {
+                if (kk < ks) {  // lanes beyond the chunk have nothing to stage (their columns are never read)
+                    const bool ok = okr[i];
+                    float *d = s + (i * 4 + (lane >> 4)) * kcs + kk;
+                    *reinterpret_cast<float2 *>(d) = make_float2(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f);
+                    *reinterpret_cast<float2 *>(d + 2) = make_float2(ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
+                }
+            } else if (krow[i] < ks) {  // rows beyond the chunk are never read (and would overflow the tile)
+                *reinterpret_cast<float4 *>(s + krow[i] * 36 + (lane & 7) * 4) =
+                    make_float4(okc[0] ? v[i].x : 0.f, okc[1] ? v[i].y : 0.f, okc[2] ? v[i].z : 0.f, okc[3] ? v[i].w : 0.f);
+            }
+        }
+    }
+};
+
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void mfma_chunk(const float *__restrict__ sA, const float *__restrict__ sB, int ks, int kcs, int l31, int h,
+                                           floatx16 &acc) {
+    const int ng = (ks + 3) >> 2;  // 4-k groups in this chunk (scalar, <= 16)
+#pragma unroll
+    for (int c0 = 0; c0 < 16; c0 += 4) {
+        if (c0 < ng) {
+            float ax[4], ay[4], bx[4], by[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * (c0 + u) + 2 * h;
+                if (AKC) { const float2 t = *reinterpret_cast<const float2 *>(sA + l31 * kcs + k); ax[u] = t.x; ay[u] = t.y; }
+                else { ax[u] = sA[k * 36 + l31]; ay[u] = sA[(k + 1) * 36 + l31]; }
+                if (BKC) { const float2 t = *reinterpret_cast<const float2 *>(sB + l31 * kcs + k); bx[u] = t.x; by[u] = t.y; }
+                else { bx[u] = sB[k * 36 + l31]; by[u] = sB[(k + 1) * 36 + l31]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u < ng) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[u], bx[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[u], by[u], acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_kloop2(const GemmJob &jb, float *sA, float *sB, int kcs, int m0, int n0, int k0, int k1, int lane,
+                                            floatx16 &acc STAMP_ARG) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int kw = k1 > k0 ? k1 - k0 : 0;                 // this wave's K range (multiple of 4 on the fast path)
+    const int half = ((kw + 7) >> 3) << 2;
+    const int ks_a = half < kw ? half : kw;               // first chunk: half, rounded up to a multiple of 4
+    const int ks_b = kw - ks_a;                           // second chunk
+    Op2<AKC> oa;
+    Op2<BKC> ob;
+    oa.init(jb.A, jb.lda, m0, jb.M, k0, lane);
+    ob.init(jb.B, jb.ldb, n0, jb.N, k0, lane);
+    float4 pa[8], pb[8];
+    oa.load(0, 0, ks_a, jb.lda, pa);
+    ob.load(0, 0, ks_a, jb.ldb, pb);
+    STAMP(2);
+    oa.store(sA, ks_a, kcs, lane, pa);
+    ob.store(sB, ks_a, kcs, lane, pb);
+    STAMP(3);
+    if (ks_b > 0) {  // wave-uniform
+        oa.load(1, ks_a, ks_b, jb.lda, pa);
+        ob.load(1, ks_a, ks_b, jb.ldb, pb);
+    }
+    wave_lds_sync();
+    STAMP(4);
+    mfma_chunk<AKC, BKC>(sA, sB, ks_a, kcs, l31, h, acc);
+    STAMP(5);
+    if (ks_b > 0) {
+        wave_lds_sync();  // chunk 0's LDS reads are complete before the tile is overwritten
+        oa.store(sA, ks_b, kcs, lane, pa);
+        ob.store(sB, ks_b, kcs, lane, pb);
+        wave_lds_sync();
+        STAMP(6);
+        mfma_chunk<AKC, BKC>(sA, sB, ks_b, kcs, l31, h, acc);
+        STAMP(7);
+    }
+}
+
 // K loop of one wave for one tile; specialised on the operand layouts so that every variant is
 // straight-line code (fwd: A along K, B along N; dgrad: both along K; wgrad: both along M/N).
 template <bool AKC, bool BKC, bool FAST>
@@ -348,7 +489,7 @@ __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *
 }
 
 __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * OP_LDS];  // per wave: A tile, B tile; reused for the split-K combine
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x (A tile, B tile) of jobs.op_lds floats; reused for the split-K combine
     // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, whose L2s
     // are private and cold after every kernel boundary.  Give each XCD a CONTIGUOUS run of tiles,
 #ifdef DDRL_STAMPS
@@ -375,7 +516,8 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     const int k0 = w * chunk;
     const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
     const int nsub = (chunk + KS - 1) / KS;  // same for the four waves (barriers in the K loop)
-    float *sA = smem + (w * 2 + 0) * OP_LDS, *sB = smem + (w * 2 + 1) * OP_LDS;
+    float *sA = smem + (w * 2 + 0) * jobs.op_lds, *sB = smem + (w * 2 + 1) * jobs.op_lds;
+    const int kcs = jobs.ks_max + 2;
 #ifdef DDRL_STAMPS
     long long *st = (jobs.stamps && lane == 0 && w == 0) ? jobs.stamps + (long long)blockIdx.x * 32 : nullptr;
     if (st) st[0] = t0_stamp;
@@ -409,11 +551,14 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     // (A variant that fetched a wave's whole K range up front was measured: no faster for the
     // forward launches, 40 % slower for the 592-tile backward launch — the CU's fetch rate, not the
     // prefetch distance, is the limit; the one-sub-chunk-ahead streaming loop stays.)
-    const int variant = (jb.fast ? 4 : 0) + (jb.a_kc ? 2 : 0) + (jb.b_kc ? 1 : 0);
+    const int variant = (jb.fast ? (chunk <= 2 * KS2 ? 8 : 4) : 0) + (jb.a_kc ? 2 : 0) + (jb.b_kc ? 1 : 0);
     switch (variant) {
-        case 4 + 2 + 0: gemm_kloop<true, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;   // fwd
-        case 4 + 2 + 1: gemm_kloop<true, true, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;    // dgrad
-        case 4 + 0 + 0: gemm_kloop<false, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;  // wgrad
+        case 8 + 2 + 0: gemm_kloop2<true, false>(jb, sA, sB, kcs, m0, n0, k0, k1, lane, acc STAMP_PASS); break;   // fwd
+        case 8 + 2 + 1: gemm_kloop2<true, true>(jb, sA, sB, kcs, m0, n0, k0, k1, lane, acc STAMP_PASS); break;    // dgrad
+        case 8 + 0 + 0: gemm_kloop2<false, false>(jb, sA, sB, kcs, m0, n0, k0, k1, lane, acc STAMP_PASS); break;  // wgrad
+        case 4 + 2 + 0: gemm_kloop<true, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;   // K > 512
+        case 4 + 2 + 1: gemm_kloop<true, true, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
+        case 4 + 0 + 0: gemm_kloop<false, false, true>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
         case 2 + 0: gemm_kloop<true, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
         case 2 + 1: gemm_kloop<true, true, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
         default: gemm_kloop<false, false, false>(jb, sA, sB, m0, n0, k0, k1, nsub, lane, acc STAMP_PASS); break;
@@ -1012,6 +1157,10 @@ static NetQ net_q(const float *base, const Layout &L, int q) {
     return NetQ{base + L.q_W1[q], base + L.q_b1[q], base + L.q_W2[q], base + L.q_b2[q], base + L.q_W3[q], base + L.q_b3[q]};
 }
 
+static size_t gemm_smem(const GemmJobs &js) {
+    const size_t a = (size_t)4 * 2 * js.op_lds * sizeof(float), b = (size_t)RED_LDS * sizeof(float);
+    return a > b ? a : b;
+}
 static void gemm_add(GemmJobs &js, GemmJob j) {
     j.tiles_n = (j.N + 31) / 32;
     j.ntiles = ((j.M + 31) / 32) * j.tiles_n;
@@ -1020,6 +1169,16 @@ static void gemm_add(GemmJobs &js, GemmJob j) {
     for (int i = js.njobs; i < MAX_GEMM_JOBS; ++i) js.tile_start[i] = 0x7fffffff;
     js.tile_start[js.njobs] = j.tile_start;
     js.job[js.njobs++] = j;
+    {   // LDS tile geometry of the launch
+        const int chunk = ((j.K + 15) >> 4) << 2;
+        int half = ((chunk + 7) >> 3) << 2;
+        if (half > chunk) half = chunk;
+        if (!j.fast || chunk > 2 * KS2) half = KS;  // streaming loop: 32-deep tiles
+        if (half > js.ks_max) js.ks_max = half;
+        if (js.ks_max < KS) js.ks_max = KS;
+        const int a = 32 * (js.ks_max + 2), b = js.ks_max * 36;
+        js.op_lds = a > b ? a : b;
+    }
 }
 static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 static void set_fast(GemmJob &j) {
@@ -1355,14 +1514,14 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
     switch (stage) {
         case 1: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
-        case 2: k_gemm<<<h->g_fa.total_tiles, 256, 0, s>>>(h->g_fa); break;
+        case 2: k_gemm<<<h->g_fa.total_tiles, 256, gemm_smem(h->g_fa), s>>>(h->g_fa); break;
         case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]); break;
-        case 5: k_gemm<<<h->g_fb.total_tiles, 256, 0, s>>>(h->g_fb); break;
+        case 5: k_gemm<<<h->g_fb.total_tiles, 256, gemm_smem(h->g_fb), s>>>(h->g_fb); break;
         case 6: k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb[st]); break;
-        case 7: k_gemm<<<h->g_bq.total_tiles, 256, 0, s>>>(h->g_bq); break;
+        case 7: k_gemm<<<h->g_bq.total_tiles, 256, gemm_smem(h->g_bq), s>>>(h->g_bq); break;
         case 8: k_rows_c<<<(B + 3) / 4 + 1, 256, 0, s>>>(h->rc); break;  // +1: the loss-reduction block
-        case 9: k_gemm<<<h->g_bpi.total_tiles, 256, 0, s>>>(h->g_bpi); break;
-        case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, 0, s>>>(h->g_last); break;
+        case 9: k_gemm<<<h->g_bpi.total_tiles, 256, gemm_smem(h->g_bpi), s>>>(h->g_bpi); break;
+        case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, gemm_smem(h->g_last), s>>>(h->g_last); break;
         case 11: {
             const long long blocks = (h->L.total_int / 4 + 255) / 256;
             k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
@@ -1565,7 +1724,7 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     k_l1<<<dim3((c.hidden1 + 255) / 256, (unsigned)((n + L1_ROWS - 1) / L1_ROWS), 1), 256, 0, s>>>(l1);
     GemmJobs gj{};
     gemm_add(gj, gemm_fwd(h->H1, h->ldh1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, h->ldh2, (int)n, c.hidden1, c.hidden2));
-    k_gemm<<<gj.total_tiles, 256, 0, s>>>(gj);
+    k_gemm<<<gj.total_tiles, 256, gemm_smem(gj), s>>>(gj);
     ActArgs aa{h->H2, net_pi(h->pi_p, L), eps_d, act_d, (int)n, c.hidden2, h->ldh2, c.act_dim, deterministic, (float)c.act_scale};
     k_rows_act<<<(unsigned)((n + 3) / 4), 256, 0, s>>>(aa);
     DDRL_LAUNCH_CHECK();
