@@ -31,7 +31,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DDRL_DIST_BACKEND=gloo lets several ranks share ONE GPU for functional checks
+            # (RCCL refuses duplicate devices); production = "nccl" (RCCL over xGMI)
+            backend = os.environ.get("DDRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

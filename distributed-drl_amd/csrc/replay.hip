@@ -60,26 +60,34 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, con
         case 3: src = rew; dst = ring.rews; width = 1; break;
         default: src = done; dst = ring.done; width = 1; break;
     }
+    // rows [skip, n) land on distinct ring rows; ptr < cap and i - skip < cap, so one conditional
+    // subtraction replaces the modulo.  32-bit index arithmetic whenever the batch allows it
+    // (64-bit div/mod per element made this kernel 10x slower than the copy it is).
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((width & 3) == 0) {
-        const int w4 = width >> 2;
-        const long long total = (n - skip) * w4;
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (long long e = t0; e < total; e += stride) {
-            const long long i = skip + e / w4;
-            const int c = (int)(e % w4);
-            const long long row = (ptr + i) % cap;
-            d4[row * w4 + c] = s4[i * w4 + c];
+    const bool v4 = (width & 3) == 0;
+    const int wv = v4 ? width >> 2 : width;  // row width in vector elements
+    const long long total = (n - skip) * wv;
+    const long long base_row = ptr + skip;   // ring row of source row `skip` before wrapping (< 2 * cap)
+    if (total < 0x7fffffffll) {
+        const unsigned tot = (unsigned)total, uw = (unsigned)wv, ustride = (unsigned)stride;
+        for (unsigned e = (unsigned)t0; e < tot; e += ustride) {
+            const unsigned ri = e / uw, c = e - ri * uw;
+            long long row = base_row + ri;
+            if (row >= cap) row -= cap;
+            if (row >= cap) row -= cap;
+            const long long so = (long long)(skip + ri) * wv + c, dof = row * wv + c;
+            if (v4) reinterpret_cast<float4 *>(dst)[dof] = reinterpret_cast<const float4 *>(src)[so];
+            else dst[dof] = src[so];
         }
     } else {
-        const long long total = (n - skip) * width;
         for (long long e = t0; e < total; e += stride) {
-            const long long i = skip + e / width;
-            const int c = (int)(e % width);
-            const long long row = (ptr + i) % cap;
-            dst[row * width + c] = src[i * width + c];
+            const long long ri = e / wv;
+            const int c = (int)(e - ri * wv);
+            const long long row = (base_row + ri) % cap;
+            const long long so = (skip + ri) * wv + c, dof = row * wv + c;
+            if (v4) reinterpret_cast<float4 *>(dst)[dof] = reinterpret_cast<const float4 *>(src)[so];
+            else dst[dof] = src[so];
         }
     }
     // last block to finish advances the cursor (every block has read st->ptr before its ticket)
