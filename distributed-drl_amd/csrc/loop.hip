@@ -55,7 +55,8 @@ static int grads_from(ddrl_loop *h, int set, void *stream) {
                                    stream);
 }
 
-// Capture `per_graph` updates.  Default: everything inline on one branch (81.5 us/update).
+// Capture `per_graph` updates.  Default: one branch; the sampler of update u+1 is an extra workgroup
+// of update u's Adam kernel (ddrl_sac1_apply_grads_and_sample).
 // Experimental overlap modes (bit-identical results, both measured SLOWER on MI355X — a kernel
 // starting or ending on another branch costs the kernel running beside it more than it hides):
 //   DDRL_LOOP_FORK=adam  sampler of update u+1 beside the Adam/polyak kernel of update u (105 us)
@@ -81,7 +82,14 @@ static int capture(ddrl_loop *h, hipStream_t main_s) {
 #define HE(x) do { if (e == hipSuccess && rc == DDRL_OK) e = (x); } while (0)
 #define RC(x) do { if (e == hipSuccess && rc == DDRL_OK) rc = (x); } while (0)
     if (mode == 0) {
-        for (int i = 0; i < n; ++i) { RC(sample_into(h, i & 1, (void *)main_s)); RC(update_from(h, i & 1, (void *)main_s)); }
+        // sample(0) as a kernel; sample(i+1) rides inside the Adam kernel of update i.  No store can
+        // interleave inside one graph, so this equals the sequential sample -> update order.
+        RC(sample_into(h, 0, (void *)main_s));
+        for (int i = 0; i < n; ++i) {
+            RC(grads_from(h, i & 1, (void *)main_s));
+            if (i + 1 < n) RC(ddrl_sac1_apply_grads_and_sample(h->learner, h->replay, (i + 1) & 1, (void *)main_s));
+            else RC(ddrl_sac1_apply_grads(h->learner, (void *)main_s));
+        }
     } else if (mode == 2) {
         HE(hipEventRecord(e_fork, main_s));
         HE(hipStreamWaitEvent(side, e_fork, 0));

@@ -1,0 +1,183 @@
+// Device-side pieces of the replay sampler shared by replay.hip (k_sample) and sac1.hip (the
+// Adam/polyak kernel can run the NEXT update's sampler as one extra workgroup, see
+// ddrl_sac1_apply_grads_and_sample).  Internal to libddrl_hip.so — not part of the C-ABI.
+#pragma once
+#include "ddrl_common.h"
+
+namespace ddrl_replay_dev {
+
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+constexpr int SAMPLE_THREADS = 256;
+constexpr int MAX_FUSED_BATCH = 4096;          // idx staged in LDS for the fused sample+gather
+constexpr long long MAX_FUSED_BYTES = 1 << 18;  // fuse the gather when the whole batch is <= 256 KiB
+
+struct RingState {
+    long long ptr, size, steps, sample_times;
+    unsigned int done_counter;  // last-block-done ticket for the store kernel
+    int error;                  // sticky device-side error (sample from empty ring)
+    int mt_pos;
+    int pad;
+    uint32_t mt_key[MT_N];
+};
+
+struct RingPtrs {
+    float *obs1, *obs2, *acts, *rews, *done;
+    long long capacity;
+    int obs_dim, act_dim;  // act_dim == row width of acts (1 for the 1-D dqn shape)
+};
+
+struct BatchPtrs {
+    float *obs1, *obs2, *acts, *rews, *done;
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Regenerate all 624 words in LDS.  The recurrence mt[k] <- f(mt[k], mt[k+1], mt[(k+397)%624])
+// has lag 397, so it splits into three segments whose inputs are all available in parallel:
+// [0,227) reads only old words; [227,454) reads new words of segment 1; [454,624) reads new
+// words of segment 2 (and new mt[0] for k = 623).
+__device__ __forceinline__ void mt_twist_lds(uint32_t *mt, int tid) {
+    uint32_t v = 0;
+    if (tid < MT_N - MT_M) v = mt_mix(mt[tid], mt[tid + 1], mt[tid + MT_M]);
+    __syncthreads();
+    if (tid < MT_N - MT_M) mt[tid] = v;
+    __syncthreads();
+    const int k2 = (MT_N - MT_M) + tid;  // 227..453
+    if (tid < MT_N - MT_M) v = mt_mix(mt[k2], mt[k2 + 1], mt[k2 - (MT_N - MT_M)]);
+    __syncthreads();
+    if (tid < MT_N - MT_M) mt[k2] = v;
+    __syncthreads();
+    const int k3 = 2 * (MT_N - MT_M) + tid;  // 454..623
+    if (k3 < MT_N) v = mt_mix(mt[k3], mt[k3 == MT_N - 1 ? 0 : k3 + 1], mt[k3 - (MT_N - MT_M)]);
+    __syncthreads();
+    if (k3 < MT_N) mt[k3] = v;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void gather_rows(const float *__restrict__ ring, float *__restrict__ out,
+                                            const unsigned *s_idx, int B, int width, int tid, int nthreads) {
+    if ((width & 3) == 0) {
+        const int w4 = width >> 2;
+        const float4 *r4 = reinterpret_cast<const float4 *>(ring);
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (int e = tid; e < B * w4; e += nthreads) {
+            const int b = e / w4, c = e - b * w4;
+            o4[e] = r4[(long long)s_idx[b] * w4 + c];
+        }
+    } else {
+        for (int e = tid; e < B * width; e += nthreads) {
+            const int b = e / width, c = e - b * width;
+            out[e] = ring[(long long)s_idx[b] * width + c];
+        }
+    }
+}
+
+// idxs = np.random.randint(0, size, B) (masked rejection on 32-bit draws), optionally fused with
+// the five gathers when the batch is small (the SAC1 shape: 256 x 80 B).  One workgroup: the
+// accept/reject compaction is a wave ballot + prefix count, the stream position advances by
+// exactly the number of words NumPy would have consumed.
+__device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring, const BatchPtrs &out, int B,
+                                             long long *idx_out, int fuse_gather) {
+    __shared__ uint32_t mt[MT_N];
+    __shared__ int s_wave_tot[SAMPLE_THREADS / 64];
+    __shared__ int s_consumed;
+    __shared__ unsigned s_idx[MAX_FUSED_BATCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long size = st->size;
+    if (size <= 0) {  // reference: ValueError("high <= 0"); the host wrapper reports it
+        if (tid == 0) st->error = DDRL_ERR_EMPTY_BUFFER;
+        return;
+    }
+    const uint32_t rng = (uint32_t)(size - 1);
+    if (rng == 0) {
+        // NumPy fills with `low` and consumes no draw
+        for (int i = tid; i < B; i += SAMPLE_THREADS) {
+            if (idx_out) idx_out[i] = 0;
+            if (fuse_gather) s_idx[i] = 0;
+        }
+    } else {
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        for (int i = tid; i < MT_N; i += SAMPLE_THREADS) mt[i] = st->mt_key[i];
+        int pos = st->mt_pos;
+        bool dirty = false;
+        int produced = 0;
+        __syncthreads();
+        while (produced < B) {
+            if (pos >= MT_N) {
+                mt_twist_lds(mt, tid);
+                pos = 0;
+                dirty = true;
+            }
+            const int w = pos + tid;
+            const bool valid = w < MT_N;
+            const uint32_t v = valid ? (mt_temper(mt[w]) & mask) : 0xffffffffu;
+            const bool acc = valid && v <= rng;
+            const unsigned long long bal = __ballot(acc);
+            const int rank_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave_tot[wave] = __popcll(bal);
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < SAMPLE_THREADS / 64; ++i) {
+                const int t = s_wave_tot[i];
+                if (i < wave) off += t;
+                tot += t;
+            }
+            const int rank = off + rank_in_wave;
+            const int need = B - produced;
+            if (acc && rank < need) {
+                if (idx_out) idx_out[produced + rank] = (long long)v;
+                if (fuse_gather) s_idx[produced + rank] = v;
+                if (rank == need - 1) s_consumed = tid + 1;  // words consumed up to the last accepted draw
+            }
+            __syncthreads();
+            if (tot >= need) {
+                pos += s_consumed;
+                produced = B;
+            } else {
+                pos += (MT_N - pos < SAMPLE_THREADS) ? (MT_N - pos) : SAMPLE_THREADS;
+                produced += tot;
+            }
+            __syncthreads();
+        }
+        if (dirty)
+            for (int i = tid; i < MT_N; i += SAMPLE_THREADS) st->mt_key[i] = mt[i];
+        if (tid == 0) st->mt_pos = pos;
+    }
+    if (tid == 0) st->sample_times += 1;
+    if (fuse_gather) {
+        __syncthreads();
+        gather_rows(ring.obs1, out.obs1, s_idx, B, ring.obs_dim, tid, SAMPLE_THREADS);
+        gather_rows(ring.obs2, out.obs2, s_idx, B, ring.obs_dim, tid, SAMPLE_THREADS);
+        gather_rows(ring.acts, out.acts, s_idx, B, ring.act_dim, tid, SAMPLE_THREADS);
+        gather_rows(ring.rews, out.rews, s_idx, B, 1, tid, SAMPLE_THREADS);
+        gather_rows(ring.done, out.done, s_idx, B, 1, tid, SAMPLE_THREADS);
+    }
+}
+
+
+// What another kernel needs to run sample_block for a replay handle.
+struct SamplerView {
+    RingState *state;
+    RingPtrs ring;
+};
+
+}  // namespace ddrl_replay_dev
+
+// defined in replay.hip
+ddrl_replay_dev::SamplerView ddrl_replay_sampler_view(ddrl_replay_t *h);
+bool ddrl_replay_can_fuse(ddrl_replay_t *h, int64_t batch);
+void ddrl_replay_note_sample(ddrl_replay_t *h);  // host mirror bookkeeping for a sample issued by another kernel

@@ -17,6 +17,7 @@
 // catastrophic cancellation that makes the literal float32 form noisy at the 1e-5 level
 // (DESIGN.md §numerics).
 #include "ddrl_common.h"
+#include "replay_device.h"
 
 #include <vector>
 
@@ -976,6 +977,11 @@ struct AdamArgs {
     long long part_off4, part_n4, part_stride4;
     int nparts;
     unsigned int noise_adv;  // noise elements consumed by this update (advances the device counter)
+    // optional: one extra workgroup samples the NEXT update's batch (ddrl_sac1_apply_grads_and_sample)
+    int adam_blocks, do_sample, sample_batch;
+    ddrl_replay_dev::RingState *rs;
+    ddrl_replay_dev::RingPtrs ring;
+    ddrl_replay_dev::BatchPtrs sout;
 };
 __device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, float &t, float omb1, float omb2, float al,
                                       float eps, float pk, float pk1) {
@@ -985,6 +991,14 @@ __device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, flo
     t = pk * t + pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
 }
 __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
+    if (a.do_sample && (int)blockIdx.x == a.adam_blocks) {
+        // Rides along: `idxs = np.random.randint(0, size, B)` + the five gathers of the NEXT update
+        // (example/dsac.py:39-45) into the learner's other input set.  Adam touches no input set and
+        // the sampler touches no parameter, so the two are independent; this takes the 6.6 us
+        // single-workgroup sampler kernel off the dependent chain.
+        ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
+        return;
+    }
     const long long n4 = a.n >> 2, npi4 = a.n_pi >> 2;  // both buffers are padded to multiples of 4
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // grid covers n4 exactly once
     float4 *P = reinterpret_cast<float4 *>(a.p), *T = reinterpret_cast<float4 *>(a.t);
@@ -1024,7 +1038,7 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned tk = atomicAdd(&a.opt->ticket_adam, 1u);
-        if (tk == gridDim.x - 1) {  // every block has read the powers before taking its ticket
+        if (tk == (unsigned)a.adam_blocks - 1) {  // every Adam block has read the powers before taking its ticket
             a.opt->b1p_pi = b1p_pi * a.b1; a.opt->b2p_pi = b2p_pi * a.b2; a.opt->b1p_q = b1p_q * a.b1; a.opt->b2p_q = b2p_q * a.b2;
             a.opt->t_pi += 1; a.opt->t_q += 1;
             a.opt->noise_ctr += a.noise_adv;
@@ -1524,7 +1538,8 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
         case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, gemm_smem(h->g_last), s>>>(h->g_last); break;
         case 11: {
             const long long blocks = (h->L.total_int / 4 + 255) / 256;
-            k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
+            h->ad.adam_blocks = (int)blocks;
+            k_adam_polyak<<<(unsigned)(blocks + (h->ad.do_sample ? 1 : 0)), 256, 0, s>>>(h->ad);
             break;
         }
         default: break;  // 4: folded into stage 3
@@ -1630,6 +1645,28 @@ int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream) {
     DDRL_REQUIRE(h != nullptr, "handle is NULL");
     ddrl::DeviceGuard g(h->device);
     return launch_apply(h, ddrl::as_stream(stream));
+}
+
+int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int set, void *stream) {
+    DDRL_REQUIRE(h != nullptr && replay != nullptr && (set == 0 || set == 1), "NULL pointer or set not in {0,1}");
+    ddrl::DeviceGuard g(h->device);
+    const ddrl_replay_dev::SamplerView v = ddrl_replay_sampler_view(replay);
+    DDRL_REQUIRE(v.ring.obs_dim == h->cfg.obs_dim && v.ring.act_dim == h->cfg.act_dim, "replay row shape differs from the learner's");
+    if (!ddrl_replay_can_fuse(replay, h->cfg.batch)) {  // empty ring (host view) or rows too large for the one-workgroup sampler
+        float **b = h->in[set];
+        int rc = launch_apply(h, ddrl::as_stream(stream));
+        if (rc != DDRL_OK) return rc;
+        return ddrl_replay_sample(replay, h->cfg.batch, b[0], b[1], b[2], b[3], b[4], nullptr, stream);
+    }
+    h->ad.do_sample = 1;
+    h->ad.sample_batch = h->cfg.batch;
+    h->ad.rs = v.state;
+    h->ad.ring = v.ring;
+    h->ad.sout = ddrl_replay_dev::BatchPtrs{h->in[set][0], h->in[set][1], h->in[set][2], h->in[set][3], h->in[set][4]};
+    const int rc = launch_apply(h, ddrl::as_stream(stream));
+    h->ad.do_sample = 0;
+    if (rc == DDRL_OK) ddrl_replay_note_sample(replay);
+    return rc;
 }
 
 int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,

@@ -198,6 +198,11 @@ int ddrl_sac1_compute_grads(ddrl_sac1_t *h, const float *obs1_d, const float *ob
                             float *losses_d, float *q1_d, float *q2_d, float *logp_pi_d,
                             void *stream);
 int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream);
+/* apply_grads fused with the sampler of the NEXT update: equivalent to ddrl_sac1_apply_grads(h)
+ * followed by ddrl_replay_sample(replay, B, <input set `set` of h>...), but the sampler runs as one
+ * extra workgroup of the Adam/polyak kernel instead of as a kernel of its own (it writes an input
+ * set the Adam kernel does not touch).  Same results, same MT19937 stream, same counters. */
+int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int set, void *stream);
 
 /* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
  * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of
