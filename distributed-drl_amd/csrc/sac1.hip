@@ -785,10 +785,10 @@ struct RowsB {
     int B, h2, ldh2;
     float alpha, gamma;
 };
-__global__ void __launch_bounds__(256) k_rows_b(RowsB a) {
-    __shared__ float s_part[4][3];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wv;
+__global__ void __launch_bounds__(64) k_rows_b(RowsB a) {
+    // one wave = one row = one workgroup: 256 workgroups spread the row fetches over all CUs
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
     float lpi = 0.f, l1 = 0.f, l2 = 0.f;
     if (r < a.B) {
         const long long BH = (long long)a.B * a.ldh2, BZ = (long long)a.B * a.h2;
@@ -832,13 +832,11 @@ __global__ void __launch_bounds__(256) k_rows_b(RowsB a) {
             }
         }
     }
-    if (lane == 0) { s_part[wv][0] = lpi; s_part[wv][1] = l1; s_part[wv][2] = l2; }
-    __syncthreads();
-    // fixed-order block partials; the final sum over blocks is done by the next row kernel
+    // per-row loss terms; the sum over rows is done in a fixed order by the next row kernel
     // (k_rows_c), after the kernel boundary has made them visible — no in-kernel fence needed
-    if (threadIdx.x < 3)
-        a.loss_part[blockIdx.x * 3 + threadIdx.x] =
-            ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
+    if (lane == 0 && r < a.B) {
+        a.loss_part[r * 3 + 0] = lpi; a.loss_part[r * 3 + 1] = l1; a.loss_part[r * 3 + 2] = l2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -857,12 +855,12 @@ struct RowsC {
     int B, h1, h2, ldh2, obs, act, ldd, loss_blocks;
     float alpha, scale;
 };
-__global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
-    const int lane = threadIdx.x & 63;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
-        // reduce_mean over the batch: the extra last block's 4th wave sums the block partials of
-        // k_rows_b in a fixed order (lane-strided partial sums, then the xor-shuffle tree)
-        const int ln = threadIdx.x - 192;
+__global__ void __launch_bounds__(64) k_rows_c(RowsC a) {
+    const int lane = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        // reduce_mean over the batch: the extra last workgroup sums the per-row terms of k_rows_b in
+        // a fixed order (lane-strided partial sums, then the xor-shuffle tree)
+        const int ln = lane;
         float s3[3] = {0.f, 0.f, 0.f};
         for (int b0 = 0; b0 < a.loss_blocks; b0 += 64) {
             const int b = b0 + ln;
@@ -879,8 +877,9 @@ __global__ void __launch_bounds__(256) k_rows_c(RowsC a) {
             const float mean = tot / (float)a.B;
             if (ln == 0) a.losses[c] = c == 0 ? mean : 0.5f * mean;
         }
+        return;
     }
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.x;
     if (r >= a.B) return;
     // everything this wave needs for the first two action dims, in one burst
     float dz[RV], hrow[RV], wq0[RV], wq1[RV], wm0[RV], wl0[RV], wm1[RV], wl1[RV];
@@ -1318,7 +1317,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     // ONE slab for every buffer of the learner (parameters, optimizer state, activations, job
     // tables): a single large allocation is mapped with large page fragments, so the ~30 buffers a
     // stage touches share a handful of TLB entries instead of missing on one 4 KB page each.
-    h->rows_b_blocks = (B + 3) / 4;
+    h->rows_b_blocks = B;  // per-row loss terms
     size_t slab_floats = 0;
     auto reserve = [&](size_t cnt) { size_t off = slab_floats; slab_floats += (cnt + 63) & ~(size_t)63; return off; };  // 256-B aligned
     struct Item { float **p; size_t off; };
@@ -1531,9 +1530,9 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
         case 2: k_gemm<<<h->g_fa.total_tiles, 256, gemm_smem(h->g_fa), s>>>(h->g_fa); break;
         case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]); break;
         case 5: k_gemm<<<h->g_fb.total_tiles, 256, gemm_smem(h->g_fb), s>>>(h->g_fb); break;
-        case 6: k_rows_b<<<h->rows_b_blocks, 256, 0, s>>>(h->rb[st]); break;
+        case 6: k_rows_b<<<h->cfg.batch, 64, 0, s>>>(h->rb[st]); break;
         case 7: k_gemm<<<h->g_bq.total_tiles, 256, gemm_smem(h->g_bq), s>>>(h->g_bq); break;
-        case 8: k_rows_c<<<(B + 3) / 4 + 1, 256, 0, s>>>(h->rc); break;  // +1: the loss-reduction block
+        case 8: k_rows_c<<<B + 1, 64, 0, s>>>(h->rc); break;  // +1: the loss-reduction workgroup
         case 9: k_gemm<<<h->g_bpi.total_tiles, 256, gemm_smem(h->g_bpi), s>>>(h->g_bpi); break;
         case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, gemm_smem(h->g_last), s>>>(h->g_last); break;
         case 11: {
