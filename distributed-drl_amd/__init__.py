@@ -21,7 +21,7 @@ def __getattr__(name):
     # heavy submodules import torch; load them on first use
     import importlib
     table = {
-        "ReplayBuffer": "replay", "ReplayBufferSAC1": "replay", "ReplayBufferDQN": "replay",
+        "ReplayBuffer": "replay", "ReplayBufferSAC1": "replay", "ReplayBufferDQN": "replay", "ReplayBufferNStep": "replay",
         "ParameterServer": "ps",
         "Learner": "agent", "Actor": "agent", "HyperParameters": "agent",
         "VecLunarLander": "env",

@@ -18,25 +18,19 @@ namespace {
 // grid = (blocks, 5 arrays).  Rows i < n - capacity would be overwritten later in the same
 // batch, so they are skipped; every remaining destination row is unique.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, const float *obs, const float *act,
-                                               const float *rew, const float *obs2, const float *done,
-                                               long long n) {
+struct StoreSrc {
+    const float *a[MAX_ARRAYS];
+};
+__global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, StoreSrc srcs, long long n) {
     __shared__ long long s_ptr;
     if (threadIdx.x == 0) s_ptr = st->ptr;
     __syncthreads();
     const long long ptr = s_ptr, cap = ring.capacity;
     const long long skip = n > cap ? n - cap : 0;
     const int which = blockIdx.y;
-    const float *src;
-    float *dst;
-    int width;
-    switch (which) {
-        case 0: src = obs; dst = ring.obs1; width = ring.obs_dim; break;
-        case 1: src = obs2; dst = ring.obs2; width = ring.obs_dim; break;
-        case 2: src = act; dst = ring.acts; width = ring.act_dim; break;
-        case 3: src = rew; dst = ring.rews; width = 1; break;
-        default: src = done; dst = ring.done; width = 1; break;
-    }
+    const float *src = srcs.a[which];
+    float *dst = ring.a[which];
+    const int width = ring.w[which];
     // rows [skip, n) land on distinct ring rows; ptr < cap and i - skip < cap, so one conditional
     // subtraction replaces the modulo.  32-bit index arithmetic whenever the batch allows it
     // (64-bit div/mod per element made this kernel 10x slower than the copy it is).
@@ -76,7 +70,7 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, con
             st->ptr = (ptr + n) % cap;
             const long long sz = st->size + n;
             st->size = sz > cap ? cap : sz;
-            st->steps += n;
+            st->steps += n * ring.steps_inc;
             st->done_counter = 0;
         }
     }
@@ -104,37 +98,28 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) k_sample(RingState *st, RingPt
 }
 
 // Stand-alone gather for large rows (the dqn pixel shape: 2 x 112 896 B per index): one
-// workgroup per (row, array-slot) so that >= B*3 workgroups fill the chip; each lane keeps four
+// workgroup per (row, array) so that >= B * n_arr workgroups fill the chip; each lane keeps four
 // independent 16-B loads in flight (HBM-bound random-row gather).
 __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, const long long *__restrict__ idx,
                                                 int B) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, j = blockIdx.y;
     const long long row = idx[b];
     const int tid = threadIdx.x;
-    if (blockIdx.y < 2) {
-        const float *src = (blockIdx.y == 0 ? ring.obs1 : ring.obs2) + row * ring.obs_dim;
-        float *dst = (blockIdx.y == 0 ? out.obs1 : out.obs2) + (long long)b * ring.obs_dim;
-        const int width = ring.obs_dim;
-        if ((width & 3) == 0) {
-            const int w4 = width >> 2;
-            const float4 *s4 = reinterpret_cast<const float4 *>(src);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
-            int e = tid;
-            for (; e + 3 * 256 < w4; e += 4 * 256) {
-                const float4 a0 = s4[e], a1 = s4[e + 256], a2 = s4[e + 512], a3 = s4[e + 768];
-                d4[e] = a0; d4[e + 256] = a1; d4[e + 512] = a2; d4[e + 768] = a3;
-            }
-            for (; e < w4; e += 256) d4[e] = s4[e];
-        } else {
-            for (int e = tid; e < width; e += 256) dst[e] = src[e];
+    const int width = ring.w[j];
+    const float *src = ring.a[j] + row * width;
+    float *dst = out.a[j] + (long long)b * width;
+    if ((width & 3) == 0) {
+        const int w4 = width >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        int e = tid;
+        for (; e + 3 * 256 < w4; e += 4 * 256) {
+            const float4 a0 = s4[e], a1 = s4[e + 256], a2 = s4[e + 512], a3 = s4[e + 768];
+            d4[e] = a0; d4[e + 256] = a1; d4[e + 512] = a2; d4[e + 768] = a3;
         }
+        for (; e < w4; e += 256) d4[e] = s4[e];
     } else {
-        for (int e = tid; e < ring.act_dim; e += 256)
-            out.acts[(long long)b * ring.act_dim + e] = ring.acts[row * ring.act_dim + e];
-        if (tid == 0) {
-            out.rews[b] = ring.rews[row];
-            out.done[b] = ring.done[row];
-        }
+        for (int e = tid; e < width; e += 256) dst[e] = src[e];
     }
 }
 
@@ -166,52 +151,51 @@ static int refresh_counts(ddrl_replay *h, hipStream_t s) {
 }
 
 ddrl_replay_dev::SamplerView ddrl_replay_sampler_view(ddrl_replay_t *h) { return ddrl_replay_dev::SamplerView{h->state, h->ring}; }
+static long long row_floats(const ddrl_replay *h) {
+    long long t = 0;
+    for (int j = 0; j < h->ring.n_arr; ++j) t += h->ring.w[j];
+    return t;
+}
 bool ddrl_replay_can_fuse(ddrl_replay_t *h, int64_t batch) {
-    const long long bytes = batch * (2ll * h->ring.obs_dim + h->ring.act_dim + 2) * (long long)sizeof(float);
+    const long long bytes = batch * row_floats(h) * (long long)sizeof(float);
     return batch <= MAX_FUSED_BATCH && bytes <= MAX_FUSED_BYTES && h->h_size > 0;
 }
-void ddrl_replay_note_sample(ddrl_replay_t *h) { h->h_samples += 1; }
+void ddrl_replay_note_sample(ddrl_replay_t *h) { h->h_samples += h->ring.samples_inc; }
 
 extern "C" {
 
-int ddrl_replay_create(ddrl_replay_t **out, int device, int64_t capacity, int obs_dim, int act_dim,
-                       uint32_t flags) {
-    DDRL_REQUIRE(out != nullptr, "out is NULL");
+int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays, const int32_t *widths_h,
+                          int64_t steps_inc, int64_t samples_inc) {
+    DDRL_REQUIRE(out != nullptr && widths_h != nullptr, "NULL pointer");
     DDRL_REQUIRE(capacity > 0 && capacity <= 0xFFFFFFFFll, "capacity must be in [1, 2^32-1]");
-    DDRL_REQUIRE(obs_dim > 0 && act_dim > 0, "obs_dim/act_dim must be positive");
-    DDRL_REQUIRE(!(flags & DDRL_REPLAY_ACTS_1D) || act_dim == 1, "ACTS_1D needs act_dim == 1");
+    DDRL_REQUIRE(n_arrays >= 1 && n_arrays <= MAX_ARRAYS, "n_arrays must be in [1, 6]");
+    for (int j = 0; j < n_arrays; ++j) DDRL_REQUIRE(widths_h[j] > 0, "row widths must be positive");
     ddrl::DeviceGuard g(device);
     if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
     ddrl_replay *h = new ddrl_replay();
     memset(h, 0, sizeof(*h));
     h->device = device;
-    h->flags = flags;
     h->ring.capacity = capacity;
-    h->ring.obs_dim = obs_dim;
-    h->ring.act_dim = act_dim;
-    const size_t no = (size_t)capacity * obs_dim * sizeof(float), na = (size_t)capacity * act_dim * sizeof(float),
-                 n1 = (size_t)capacity * sizeof(float);
+    h->ring.n_arr = n_arrays;
+    h->ring.steps_inc = steps_inc > 0 ? steps_inc : 1;
+    h->ring.samples_inc = samples_inc > 0 ? samples_inc : 1;
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = hipMalloc(&h->ring.obs1, no);
-    if (e == hipSuccess) e = hipMalloc(&h->ring.obs2, no);
-    if (e == hipSuccess) e = hipMalloc(&h->ring.acts, na);
-    if (e == hipSuccess) e = hipMalloc(&h->ring.rews, n1);
-    if (e == hipSuccess) e = hipMalloc(&h->ring.done, n1);
+    for (int j = 0; j < n_arrays && e == hipSuccess; ++j) {
+        h->ring.w[j] = widths_h[j];
+        e = hipMalloc(&h->ring.a[j], (size_t)capacity * widths_h[j] * sizeof(float));
+    }
     if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(RingState));
     h->idx_cap = 1 << 16;
     if (e == hipSuccess) e = hipMalloc(&h->idx_buf, h->idx_cap * sizeof(long long));
     if (e != hipSuccess) {
-        ddrl::set_error("hipMalloc failed for replay of %lld x (%d,%d): %s", (long long)capacity, obs_dim, act_dim,
+        ddrl::set_error("hipMalloc failed for a ring of %lld rows x %lld floats: %s", (long long)capacity, row_floats(h),
                         hipGetErrorString(e));
         ddrl_replay_destroy(h);
         return DDRL_ERR_NOMEM;
     }
-    // np.zeros for the five rings (example/dsac.py:21-25)
-    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.obs1, 0, no, nullptr));
-    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.obs2, 0, no, nullptr));
-    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.acts, 0, na, nullptr));
-    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.rews, 0, n1, nullptr));
-    DDRL_HIP_CHECK(hipMemsetAsync(h->ring.done, 0, n1, nullptr));
+    // np.zeros for every ring (example/dsac.py:21-25)
+    for (int j = 0; j < n_arrays; ++j)
+        DDRL_HIP_CHECK(hipMemsetAsync(h->ring.a[j], 0, (size_t)capacity * widths_h[j] * sizeof(float), nullptr));
     DDRL_HIP_CHECK(hipMemsetAsync(h->state, 0, sizeof(RingState), nullptr));
     k_mt_seed<<<1, 64, 0, nullptr>>>(h->state, 0u);
     DDRL_LAUNCH_CHECK();
@@ -220,11 +204,21 @@ int ddrl_replay_create(ddrl_replay_t **out, int device, int64_t capacity, int ob
     return DDRL_OK;
 }
 
+int ddrl_replay_create(ddrl_replay_t **out, int device, int64_t capacity, int obs_dim, int act_dim,
+                       uint32_t flags) {
+    DDRL_REQUIRE(obs_dim > 0 && act_dim > 0, "obs_dim/act_dim must be positive");
+    DDRL_REQUIRE(!(flags & DDRL_REPLAY_ACTS_1D) || act_dim == 1, "ACTS_1D needs act_dim == 1");
+    const int32_t widths[5] = {obs_dim, obs_dim, act_dim, 1, 1};  // obs1 obs2 acts rews done
+    const int rc = ddrl_replay_create_ex(out, device, capacity, 5, widths, 1, 1);
+    if (rc == DDRL_OK) (*out)->flags = flags;
+    return rc;
+}
+
 int ddrl_replay_destroy(ddrl_replay_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
-    (void)hipFree(h->ring.obs1); (void)hipFree(h->ring.obs2); (void)hipFree(h->ring.acts);
-    (void)hipFree(h->ring.rews); (void)hipFree(h->ring.done); (void)hipFree(h->state); (void)hipFree(h->idx_buf);
+    for (int j = 0; j < MAX_ARRAYS; ++j) (void)hipFree(h->ring.a[j]);
+    (void)hipFree(h->state); (void)hipFree(h->idx_buf);
     delete h;
     return DDRL_OK;
 }
@@ -237,38 +231,52 @@ int ddrl_replay_seed(ddrl_replay_t *h, uint32_t seed, void *stream) {
     return DDRL_OK;
 }
 
-int ddrl_replay_store(ddrl_replay_t *h, const float *obs_d, const float *act_d, const float *rew_d,
-                      const float *obs2_d, const float *done_d, int64_t n, void *stream) {
-    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n, void *stream) {
+    DDRL_REQUIRE(h != nullptr && src_h != nullptr, "NULL pointer");
     DDRL_REQUIRE(n >= 0, "n must be >= 0");
     if (n == 0) return DDRL_OK;
-    DDRL_REQUIRE(obs_d && act_d && rew_d && obs2_d && done_d, "NULL transition pointer");
+    StoreSrc srcs{};
+    int widest = 1;
+    for (int j = 0; j < h->ring.n_arr; ++j) {
+        DDRL_REQUIRE(src_h[j] != nullptr, "NULL source array");
+        srcs.a[j] = src_h[j];
+        const int wv = (h->ring.w[j] & 3) == 0 ? h->ring.w[j] / 4 : h->ring.w[j];
+        if (wv > widest) widest = wv;
+    }
     ddrl::DeviceGuard g(h->device);
     const long long rows = n > h->ring.capacity ? h->ring.capacity : n;
-    const long long widest = rows * ((h->ring.obs_dim & 3) == 0 ? h->ring.obs_dim / 4 : h->ring.obs_dim);
-    long long blocks = (widest + 255) / 256;
+    long long blocks = (rows * widest + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    k_store<<<dim3((unsigned)blocks, 5), 256, 0, ddrl::as_stream(stream)>>>(h->state, h->ring, obs_d, act_d, rew_d,
-                                                                            obs2_d, done_d, n);
+    k_store<<<dim3((unsigned)blocks, (unsigned)h->ring.n_arr), 256, 0, ddrl::as_stream(stream)>>>(h->state, h->ring, srcs, n);
     DDRL_LAUNCH_CHECK();
     h->h_ptr = (h->h_ptr + n) % h->ring.capacity;
     h->h_size = (h->h_size + n > h->ring.capacity) ? h->ring.capacity : h->h_size + n;
-    h->h_steps += n;
+    h->h_steps += n * h->ring.steps_inc;
     return DDRL_OK;
 }
 
+int ddrl_replay_store(ddrl_replay_t *h, const float *obs_d, const float *act_d, const float *rew_d,
+                      const float *obs2_d, const float *done_d, int64_t n, void *stream) {
+    DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");
+    const float *src[5] = {obs_d, obs2_d, act_d, rew_d, done_d};
+    return ddrl_replay_store_ex(h, src, n, stream);
+}
+
 static int launch_gather(ddrl_replay *h, const long long *idx, int64_t B, BatchPtrs out, hipStream_t s) {
-    k_gather<<<dim3((unsigned)B, 3), 256, 0, s>>>(h->ring, out, idx, (int)B);
+    k_gather<<<dim3((unsigned)B, (unsigned)h->ring.n_arr), 256, 0, s>>>(h->ring, out, idx, (int)B);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
 
-int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *obs2_d, float *acts_d,
-                       float *rews_d, float *done_d, int64_t *idx_d, void *stream) {
-    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, int64_t *idx_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && out_h != nullptr, "NULL pointer");
     DDRL_REQUIRE(batch > 0 && batch <= (1 << 24), "batch must be in [1, 2^24]");
-    DDRL_REQUIRE(obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL output pointer");
+    BatchPtrs out{};
+    for (int j = 0; j < h->ring.n_arr; ++j) {
+        DDRL_REQUIRE(out_h[j] != nullptr, "NULL output pointer");
+        out.a[j] = out_h[j];
+    }
     ddrl::DeviceGuard g(h->device);
     hipStream_t s = ddrl::as_stream(stream);
     if (h->h_size <= 0) {
@@ -280,9 +288,7 @@ int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *ob
             return DDRL_ERR_EMPTY_BUFFER;
         }
     }
-    BatchPtrs out{obs1_d, obs2_d, acts_d, rews_d, done_d};
-    const long long bytes = batch * (2ll * h->ring.obs_dim + h->ring.act_dim + 2) * (long long)sizeof(float);
-    const int fuse = (batch <= MAX_FUSED_BATCH && bytes <= MAX_FUSED_BYTES) ? 1 : 0;
+    const int fuse = ddrl_replay_can_fuse(h, batch) ? 1 : 0;
     long long *idx = reinterpret_cast<long long *>(idx_d);
     if (!fuse && !idx) {
         if (batch > h->idx_cap) {
@@ -295,19 +301,35 @@ int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *ob
     }
     k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, out, (int)batch, idx, fuse);
     DDRL_LAUNCH_CHECK();
-    h->h_samples += 1;
+    h->h_samples += h->ring.samples_inc;
     if (!fuse) return launch_gather(h, idx, batch, out, s);
     return DDRL_OK;
 }
 
+int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *obs2_d, float *acts_d,
+                       float *rews_d, float *done_d, int64_t *idx_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");
+    float *out[5] = {obs1_d, obs2_d, acts_d, rews_d, done_d};
+    return ddrl_replay_sample_ex(h, batch, out, idx_d, stream);
+}
+
+int ddrl_replay_gather_ex(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *const *out_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr && idx_d != nullptr && out_h != nullptr, "NULL handle, index or output pointer");
+    DDRL_REQUIRE(batch > 0 && batch <= (1 << 24), "batch must be in [1, 2^24]");
+    BatchPtrs out{};
+    for (int j = 0; j < h->ring.n_arr; ++j) {
+        DDRL_REQUIRE(out_h[j] != nullptr, "NULL output pointer");
+        out.a[j] = out_h[j];
+    }
+    ddrl::DeviceGuard g(h->device);
+    return launch_gather(h, reinterpret_cast<const long long *>(idx_d), batch, out, ddrl::as_stream(stream));
+}
+
 int ddrl_replay_gather(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *obs1_d, float *obs2_d,
                        float *acts_d, float *rews_d, float *done_d, void *stream) {
-    DDRL_REQUIRE(h != nullptr && idx_d != nullptr, "NULL handle or index pointer");
-    DDRL_REQUIRE(batch > 0 && batch <= (1 << 24), "batch must be in [1, 2^24]");
-    DDRL_REQUIRE(obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL output pointer");
-    ddrl::DeviceGuard g(h->device);
-    BatchPtrs out{obs1_d, obs2_d, acts_d, rews_d, done_d};
-    return launch_gather(h, reinterpret_cast<const long long *>(idx_d), batch, out, ddrl::as_stream(stream));
+    DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");
+    float *out[5] = {obs1_d, obs2_d, acts_d, rews_d, done_d};
+    return ddrl_replay_gather_ex(h, idx_d, batch, out, stream);
 }
 
 int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_t *steps_h,
@@ -323,14 +345,24 @@ int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_
     return DDRL_OK;
 }
 
+int ddrl_replay_buffers_ex(ddrl_replay_t *h, float **arrays_h, int32_t *widths_h, int32_t *n_arrays_h) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    for (int j = 0; j < h->ring.n_arr; ++j) {
+        if (arrays_h) arrays_h[j] = h->ring.a[j];
+        if (widths_h) widths_h[j] = h->ring.w[j];
+    }
+    if (n_arrays_h) *n_arrays_h = h->ring.n_arr;
+    return DDRL_OK;
+}
+
 int ddrl_replay_buffers(ddrl_replay_t *h, float **obs1_d, float **obs2_d, float **acts_d, float **rews_d,
                         float **done_d) {
-    DDRL_REQUIRE(h != nullptr, "handle is NULL");
-    if (obs1_d) *obs1_d = h->ring.obs1;
-    if (obs2_d) *obs2_d = h->ring.obs2;
-    if (acts_d) *acts_d = h->ring.acts;
-    if (rews_d) *rews_d = h->ring.rews;
-    if (done_d) *done_d = h->ring.done;
+    DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");
+    if (obs1_d) *obs1_d = h->ring.a[0];
+    if (obs2_d) *obs2_d = h->ring.a[1];
+    if (acts_d) *acts_d = h->ring.a[2];
+    if (rews_d) *rews_d = h->ring.a[3];
+    if (done_d) *done_d = h->ring.a[4];
     return DDRL_OK;
 }
 

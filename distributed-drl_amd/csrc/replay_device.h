@@ -21,14 +21,22 @@ struct RingState {
     uint32_t mt_key[MT_N];
 };
 
+constexpr int MAX_ARRAYS = 6;
+
+// A ring is a set of float32 struct-of-arrays rings that share one cursor: array j is
+// [capacity][w[j]] row-major.  The SAC layouts (example/dsac.py:20-27) are the instance
+// {obs1[obs], obs2[obs], acts[act], rews[1], done[1]}; the n-step window buffer of
+// algos/sac1/sac_ray.py:40-51 is {buffer_o[(Ln+1)*obs], buffer_a[Ln*act], buffer_r[Ln], buffer_d[Ln]}.
 struct RingPtrs {
-    float *obs1, *obs2, *acts, *rews, *done;
+    float *a[MAX_ARRAYS];
+    int w[MAX_ARRAYS];
+    int n_arr;
     long long capacity;
-    int obs_dim, act_dim;  // act_dim == row width of acts (1 for the 1-D dqn shape)
+    long long steps_inc, samples_inc;  // counter increments per store / per sample (sac_ray.py:68,75: num_buffers)
 };
 
 struct BatchPtrs {
-    float *obs1, *obs2, *acts, *rews, *done;
+    float *a[MAX_ARRAYS];
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -157,14 +165,12 @@ __device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring
             for (int i = tid; i < MT_N; i += SAMPLE_THREADS) st->mt_key[i] = mt[i];
         if (tid == 0) st->mt_pos = pos;
     }
-    if (tid == 0) st->sample_times += 1;
+    if (tid == 0) st->sample_times += ring.samples_inc;
     if (fuse_gather) {
         __syncthreads();
-        gather_rows(ring.obs1, out.obs1, s_idx, B, ring.obs_dim, tid, SAMPLE_THREADS);
-        gather_rows(ring.obs2, out.obs2, s_idx, B, ring.obs_dim, tid, SAMPLE_THREADS);
-        gather_rows(ring.acts, out.acts, s_idx, B, ring.act_dim, tid, SAMPLE_THREADS);
-        gather_rows(ring.rews, out.rews, s_idx, B, 1, tid, SAMPLE_THREADS);
-        gather_rows(ring.done, out.done, s_idx, B, 1, tid, SAMPLE_THREADS);
+#pragma unroll
+        for (int j = 0; j < MAX_ARRAYS; ++j)
+            if (j < ring.n_arr) gather_rows(ring.a[j], out.a[j], s_idx, B, ring.w[j], tid, SAMPLE_THREADS);
     }
 }
 

@@ -1650,7 +1650,9 @@ int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int 
     DDRL_REQUIRE(h != nullptr && replay != nullptr && (set == 0 || set == 1), "NULL pointer or set not in {0,1}");
     ddrl::DeviceGuard g(h->device);
     const ddrl_replay_dev::SamplerView v = ddrl_replay_sampler_view(replay);
-    DDRL_REQUIRE(v.ring.obs_dim == h->cfg.obs_dim && v.ring.act_dim == h->cfg.act_dim, "replay row shape differs from the learner's");
+    DDRL_REQUIRE(v.ring.n_arr == 5 && v.ring.w[0] == h->cfg.obs_dim && v.ring.w[1] == h->cfg.obs_dim && v.ring.w[2] == h->cfg.act_dim &&
+                     v.ring.w[3] == 1 && v.ring.w[4] == 1,
+                 "replay row shape differs from the learner's (obs1, obs2, acts, rews, done)");
     if (!ddrl_replay_can_fuse(replay, h->cfg.batch)) {  // empty ring (host view) or rows too large for the one-workgroup sampler
         float **b = h->in[set];
         int rc = launch_apply(h, ddrl::as_stream(stream));
@@ -1661,7 +1663,7 @@ int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int 
     h->ad.sample_batch = h->cfg.batch;
     h->ad.rs = v.state;
     h->ad.ring = v.ring;
-    h->ad.sout = ddrl_replay_dev::BatchPtrs{h->in[set][0], h->in[set][1], h->in[set][2], h->in[set][3], h->in[set][4]};
+    h->ad.sout = ddrl_replay_dev::BatchPtrs{{h->in[set][0], h->in[set][1], h->in[set][2], h->in[set][3], h->in[set][4], nullptr}};
     const int rc = launch_apply(h, ddrl::as_stream(stream));
     h->ad.do_sample = 0;
     if (rc == DDRL_OK) ddrl_replay_note_sample(replay);

@@ -200,6 +200,94 @@ class ReplayBufferDQN(ReplayBuffer):
                                                     int(infos[4]), _lib.stream_ptr()))
 
 
+class ReplayBufferNStep:
+    """The n-step window buffer of algos/sac1/sac_ray.py:34-82: `ReplayBuffer(opt)` with
+    opt.buffer_size slots, each holding (opt.Ln + 1) observation frames and opt.Ln (action, reward,
+    done) triples; `store(o_queue, a_r_d_queue, worker_index)` takes the rollout's two deques
+    (sac_ray.py:53-70), `sample_batch()` returns dict(obs, acts, rews, done) of whole windows
+    (sac_ray.py:72-80) and the counters advance by opt.num_buffers per call.  Float observations
+    only (the reference's packed-string CNN frames are out of scope)."""
+
+    def __init__(self, opt, device=None, seed=None):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self.opt = opt
+        self.Ln = int(opt.Ln)
+        self.obs_shape, self.act_shape = tuple(opt.obs_shape), tuple(opt.act_shape)
+        self.obs_dim = int(np.prod(self.obs_shape)) if self.obs_shape else 1
+        self.act_dim = int(np.prod(self.act_shape)) if self.act_shape else 1
+        self.max_size = int(opt.buffer_size)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.widths = [(self.Ln + 1) * self.obs_dim, self.Ln * self.act_dim, self.Ln, self.Ln]
+        self.shapes = [(self.Ln + 1,) + self.obs_shape, (self.Ln,) + self.act_shape, (self.Ln,), (self.Ln,)]
+        self.names = ["obs", "acts", "rews", "done"]
+        h = ctypes.c_void_p()
+        w = (ctypes.c_int32 * 4)(*self.widths)
+        nb = int(getattr(opt, "num_buffers", 1))
+        _lib.check(self._lib.ddrl_replay_create_ex(ctypes.byref(h), self.device.index, self.max_size, 4, w, nb, nb))
+        self._h = h
+        if seed is not None:
+            self.seed(seed)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_replay_destroy(h)
+
+    def seed(self, s):
+        _lib.check(self._lib.ddrl_replay_seed(self._h, int(s) & 0xFFFFFFFF, _lib.stream_ptr()))
+
+    def store(self, o_queue, a_r_d_queue, worker_index=None):
+        """One window (sac_ray.py:53-70): o_queue = Ln+1 tuples (o,), a_r_d_queue = Ln tuples (a, r, d)."""
+        obs = np.stack([np.asarray(q[0], dtype=np.float32) for q in o_queue], axis=0)
+        a = np.stack([np.asarray(q[0], dtype=np.float32) for q in a_r_d_queue], axis=0)
+        r = np.array([q[1] for q in a_r_d_queue], dtype=np.float32)
+        d = np.array([q[2] for q in a_r_d_queue], dtype=np.float32)
+        self.store_batch(*(torch.from_numpy(np.ascontiguousarray(x)).to(self.device).reshape(1, -1) for x in (obs, a, r, d)))
+
+    def store_batch(self, obs, acts, rews, done):
+        """n windows at once (device tensors [n, ...]) == n sequential store() calls."""
+        ts = [t.to(device=self.device, dtype=torch.float32).contiguous() for t in (obs, acts, rews, done)]
+        n = int(ts[2].shape[0])
+        for t, w in zip(ts, self.widths):
+            assert t.numel() == n * w
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+        _lib.check(self._lib.ddrl_replay_store_ex(self._h, ptrs, n, _lib.stream_ptr()))
+
+    def sample_batch_device(self, batch_size=None, with_indices=False):
+        B = int(self.opt.batch_size if batch_size is None else batch_size)
+        outs = [torch.empty((B,) + s, dtype=torch.float32, device=self.device) for s in self.shapes]
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in outs])
+        idx = torch.empty(B, dtype=torch.int64, device=self.device) if with_indices else None
+        _lib.check(self._lib.ddrl_replay_sample_ex(self._h, B, ptrs, _lib.dptr(idx), _lib.stream_ptr()))
+        d = dict(zip(self.names, outs))
+        if with_indices:
+            d["idxs"] = idx
+        return d
+
+    def sample_batch(self):
+        return {k: v.cpu().numpy() for k, v in self.sample_batch_device().items()}
+
+    def get_counts(self):
+        c = [ctypes.c_int64() for _ in range(4)]
+        _lib.check(self._lib.ddrl_replay_counts(self._h, *[ctypes.byref(x) for x in c], _lib.stream_ptr()))
+        ptr, size, steps, samples = (int(x.value) for x in c)
+        return samples, steps, size
+
+    def rings(self):
+        p = (ctypes.c_void_p * 6)()
+        _lib.check(self._lib.ddrl_replay_buffers_ex(self._h, p, None, None))
+        return {"buffer_" + n[0]: _view(p[j], (self.max_size,) + s, self.device)
+                for j, (n, s) in enumerate(zip(self.names, self.shapes))}
+
+    def mt_state(self):
+        key = np.empty(624, dtype=np.uint32)
+        pos = ctypes.c_int32()
+        _lib.check(self._lib.ddrl_replay_mt_state(self._h, ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos),
+                                                  _lib.stream_ptr()))
+        return key, int(pos.value)
+
+
 def _view(ptr, shape, device):
     """Wrap raw device memory owned by a handle as a float32 torch tensor (no copy)."""
     n = int(np.prod(shape))

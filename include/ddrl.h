@@ -93,6 +93,20 @@ int ddrl_replay_gather(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, fl
 int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_t *steps_h,
                        int64_t *sample_times_h, void *stream);
 
+/* ---- generalised ring: any set of 1..6 float32 struct-of-arrays rings sharing one cursor ----
+ * Replaces the n-step window buffer of algos/sac1/sac_ray.py:34-82 — class ReplayBuffer(opt) with
+ * buffer_o[N,(Ln+1),obs] buffer_a[N,Ln(,act)] buffer_r[N,Ln] buffer_d[N,Ln]; store() writes one
+ * (Ln+1)-frame window per slot and sample_batch() gathers whole windows; its counters advance by
+ * opt.num_buffers per call (sac_ray.py:68,75) — and any other row layout.  The five-array
+ * functions above are the instance widths = {obs, obs, act, 1, 1}.
+ * widths_h / src_h / out_h / arrays_h are HOST arrays (of ints / of device pointers), in ring order. */
+int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays,
+                          const int32_t *widths_h, int64_t steps_inc, int64_t samples_inc);
+int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n, void *stream);
+int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, int64_t *idx_d, void *stream);
+int ddrl_replay_gather_ex(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *const *out_h, void *stream);
+int ddrl_replay_buffers_ex(ddrl_replay_t *h, float **arrays_h, int32_t *widths_h, int32_t *n_arrays_h);
+
 /* Raw ring pointers (device) for checkpointing / inspection (algos/dqn/train.py:82-90 saves
  * exactly these five arrays + (ptr,size,max_size,steps,sample_times)). */
 int ddrl_replay_buffers(ddrl_replay_t *h, float **obs1_d, float **obs2_d, float **acts_d,

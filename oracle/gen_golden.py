@@ -331,6 +331,54 @@ def gen_worker_traces(dsac, sac1):
         json.dump(out, f, indent=0)
 
 
+def nstep_windows(n_store, Ln=4, obs_dim=115):
+    """The deque contents a sac_ray-style rollout hands to store(): yields (o_queue, a_r_d_queue)
+    snapshots (deques of (o,) tuples / (a, r, d) tuples), scalar actions (act_shape == ())."""
+    from collections import deque
+    o_queue, a_r_d_queue = deque([], maxlen=Ln + 1), deque([], maxlen=Ln)
+    rs = np.random.RandomState(n_store)
+    o_queue.append((rs.randn(obs_dim),))
+    t, stored = 1, 0
+    while stored < n_store:
+        a, r, d = float(rs.uniform(-1, 1)), float(rs.randn()), bool(rs.rand() < 0.2)
+        a_r_d_queue.append((a, r, d,))
+        o_queue.append((rs.randn(obs_dim),))
+        if t >= Ln:
+            yield deque(o_queue, maxlen=Ln + 1), deque(a_r_d_queue, maxlen=Ln)
+            stored += 1
+        t += 1
+
+
+def gen_nstep(sac_ray):
+    """n-step window buffer of algos/sac1/sac_ray.py:34-82: (Ln+1) observation frames and Ln
+    (action, reward, done) triples per slot; counters advance by num_buffers."""
+    class Opt:
+        pass
+    opt = Opt()
+    opt.obs_shape, opt.act_shape, opt.Ln, opt.buffer_size, opt.batch_size, opt.num_buffers = (115,), (), 4, 7, 5, 3
+    rec, meta = {}, []
+    for n_store in (5, 7, 10):
+        buf = sac_ray.ReplayBuffer(opt)
+        for oq, aq in nstep_windows(n_store, opt.Ln, 115):
+            buf.store(oq, aq, 0)
+        tag = "nstep_n%d" % n_store
+        for k in ("buffer_o", "buffer_a", "buffer_r", "buffer_d"):
+            rec[tag + "_" + k] = getattr(buf, k).copy()
+        np.random.seed(21)
+        batches = []
+        for it in range(2):
+            dct = buf.sample_batch()
+            for k, v in dct.items():
+                rec["%s_s%d_%s" % (tag, it, k)] = v
+            batches.append(_mt_fingerprint())
+        meta.append({"n_store": n_store, "ptr": int(buf.ptr), "size": int(buf.size), "counts": _jsonable(buf.get_counts()),
+                     "Ln": opt.Ln, "obs": 115, "cap": opt.buffer_size, "B": opt.batch_size, "num_buffers": opt.num_buffers,
+                     "seed": 21, "mt": batches})
+    np.savez_compressed(os.path.join(OUT, "nstep.npz"), **rec)
+    with open(os.path.join(OUT, "nstep.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference checkout not present; fixtures can only be regenerated in the build container")
@@ -350,6 +398,11 @@ def main():
     gen_ring_and_gather(dsac, sac1, dqn)
     gen_ps(dsac)
     gen_worker_traces(dsac, sac1)
+    sys.path.remove(os.path.join(REF, "algos", "dqn"))
+    for m in ("core", "hyperparams", "actor_learner", "trading_env"):
+        sys.modules.pop(m, None)
+    sac_ray = _load(os.path.join(REF, "algos", "sac1", "sac_ray.py"), "ref_sac_ray", os.path.join(REF, "algos", "sac1"))
+    gen_nstep(sac_ray)
     print("golden fixtures written to", OUT)
     for fn in sorted(os.listdir(OUT)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(OUT, fn))))

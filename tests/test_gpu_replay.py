@@ -224,3 +224,47 @@ def test_parameter_server_golden(ddrl, golden_dir, tmp_path):
     assert list(w.keys()) == log[2]["out"] and w[keys[1]].tolist() == [5.0, 5.0, 5.0]
     with pytest.raises(KeyError):
         ps.pull(["nope"])
+
+
+def test_nstep_window_buffer_golden(ddrl, golden_dir):
+    """N-step window ring (algos/sac1/sac_ray.py:34-82) on the generalised HIP ring: contents,
+    wrap-around, counters and sampled windows bit-exact vs the reference's own class."""
+    from oracle.gen_golden import nstep_windows
+    z = np.load(os.path.join(golden_dir, "nstep.npz"))
+    for m in json.load(open(os.path.join(golden_dir, "nstep.json"))):
+        class Opt:
+            obs_shape, act_shape, Ln = (m["obs"],), (), m["Ln"]
+            buffer_size, batch_size, num_buffers = m["cap"], m["B"], m["num_buffers"]
+        buf = ddrl.ReplayBufferNStep(Opt)
+        for oq, aq in nstep_windows(m["n_store"], m["Ln"], m["obs"]):
+            buf.store(oq, aq, 0)
+        tag = "nstep_n%d" % m["n_store"]
+        rings = buf.rings()
+        for k in ("buffer_o", "buffer_a", "buffer_r", "buffer_d"):
+            np.testing.assert_array_equal(rings[k].cpu().numpy(), z[tag + "_" + k], err_msg=k)
+        buf.seed(m["seed"])
+        for it in range(2):
+            d = buf.sample_batch()
+            for k, v in d.items():
+                assert v.dtype == np.float32
+                np.testing.assert_array_equal(v, z["%s_s%d_%s" % (tag, it, k)])
+            assert _fp(buf) == m["mt"][it]
+        assert list(buf.get_counts()) == m["counts"]
+    # batched window store == sequential stores, incl. wrap inside the batch
+    class Opt2:
+        obs_shape, act_shape, Ln, buffer_size, batch_size, num_buffers = (8,), (2,), 8, 50, 16, 1
+    b1, b2 = ddrl.ReplayBufferNStep(Opt2, seed=1), ddrl.ReplayBufferNStep(Opt2, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    o = torch.randn(70, 9, 8, device="cuda", generator=g)
+    a = torch.randn(70, 8, 2, device="cuda", generator=g)
+    r, dn = torch.randn(70, 8, device="cuda", generator=g), torch.zeros(70, 8, device="cuda")
+    b1.store_batch(o, a, r, dn)
+    for i in range(70):
+        b2.store_batch(o[i:i + 1], a[i:i + 1], r[i:i + 1], dn[i:i + 1])
+    for k, v in b1.rings().items():
+        assert torch.equal(v, b2.rings()[k]), k
+    s1, s2 = b1.sample_batch_device(with_indices=True), b2.sample_batch_device(with_indices=True)
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    assert s1["obs"].shape == (16, 9, 8) and s1["acts"].shape == (16, 8, 2)
+    assert b1.get_counts() == (1, 70, 50)
