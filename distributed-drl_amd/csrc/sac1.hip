@@ -778,7 +778,9 @@ __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
 struct RowsB {
     const float *H2;
     NetQ q1, q2, q1t, q2t;
-    const float *rew, *done, *logp0, *logp1, *q1o, *q2o;
+    const float *rew, *done, *logp0, *logp1;
+    float *q1o, *q2o;
+    int own_q;   // 1: Q(x,a) of both critics is computed here (fused forward path: no k_rows_a) and written to q1o/q2o
     float *dZ2;  // [4][B][h2]  slots: 0 = q1(x,a), 1 = q2(x,a), 2 = q1(x,pi), 3 = pi
     float *dq4;  // [2][B][4]   (column 0 used; padded so that it is a 16-B aligned GEMM operand)
     float *loss_part;
@@ -803,9 +805,16 @@ __global__ void __launch_bounds__(64) k_rows_b(RowsB a) {
         load_row(a.q2.W3, a.h2, lane, w2);
         load_row(a.q1t.W3, a.h2, lane, w1t);
         load_row(a.q2t.W3, a.h2, lane, w2t);
-        const float rew = a.rew[r], done = a.done[r], lp0 = a.logp0[r], lp1 = a.logp1[r], q1v = a.q1o[r], q2v = a.q2o[r];
-        const float b1 = a.q1.b3[0], b1t = a.q1t.b3[0], b2t = a.q2t.b3[0];
+        const float rew = a.rew[r], done = a.done[r], lp0 = a.logp0[r], lp1 = a.logp1[r];
+        float q1v = a.q1o[r], q2v = a.q2o[r];
+        const float b1 = a.q1.b3[0], b1t = a.q1t.b3[0], b2t = a.q2t.b3[0], b2 = a.q2.b3[0];
         mask_row(w1, a.h2, lane); mask_row(w1t, a.h2, lane); mask_row(w2t, a.h2, lane);
+        if (a.own_q) {  // kernel-uniform
+            mask_row(w2, a.h2, lane);
+            q1v = wave_sum(dot_rv(h3, w1)) + b1;
+            q2v = wave_sum(dot_rv(h4, w2)) + b2;
+            if (lane == 0) { a.q1o[r] = q1v; a.q2o[r] = q2v; }
+        }
         const float q1pi = wave_sum(dot_rv(h5, w1)) + b1;
         const float q1t = wave_sum(dot_rv(h6, w1t)) + b1t;
         const float q2t = wave_sum(dot_rv(h7, w2t)) + b2t;
@@ -959,6 +968,8 @@ __global__ void __launch_bounds__(64) k_rows_c(RowsC a) {
         if (j < a.h2) out[j] = hrow[i] > 0.f ? acc[i] : 0.f;
     }
 }
+
+#include "sac1_fused.h"
 
 // ------------------------------------------------------------------------------------------
 // K: Adam(pi) + Adam(q1,q2) + polyak, fused over the flat (padded) parameter buffer.
@@ -1243,6 +1254,14 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
     return DDRL_OK;
 }
 
+// Envelope of the fused forward stages (sac1_fused.h); everything else takes the generic kernels.
+static bool fused_ok(const ddrl_sac1_config_t &c, const Layout &L) {
+    const bool al = (L.pi_W2 % 4 == 0) && (L.q_W2[0] % 4 == 0) && (L.q_W2[1] % 4 == 0) && (L.pi_W1 % 4 == 0) && (L.q_W1[0] % 4 == 0) &&
+                    (L.q_W1[1] % 4 == 0);
+    return c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * F_MAXNT &&
+           c.obs_dim + c.act_dim <= FD && 2 * c.act_dim <= FH && c.act_dim <= 4 && c.batch % 32 == 0 && al;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1267,6 +1286,9 @@ struct ddrl_sac1 {
     RowsC rc;
     AdamArgs ad;
     int rows_b_blocks;
+    bool fused;          // fused forward stages (sac1_fused.h) instead of k_l1 / k_gemm / k_rows_a
+    FwdArgs f_a[2], f_b[2];
+    float *hp;           // head partials [NEVAL][FH][nt2][B]
     bool fused_l1_wgrad;  // pi layer-1 wgrad via dgrad-epilogue partials + Adam (needs hidden1 % 4 == 0)
     // set by ddrl_sac1_fill_noise, consumed by the next compute_grads / apply_grads
     bool noise_armed;
@@ -1338,6 +1360,8 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
     ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(dq4, (size_t)2 * B * 4); ALLOC(dhead, (size_t)B * h->ldd);
     ALLOC(loss_part, (size_t)h->rows_b_blocks * 3); ALLOC(losses, 4);
+    const int nt2 = (h2 + 31) / 32;
+    ALLOC(hp, (size_t)NEVAL * FH * nt2 * B);
 #undef ALLOC
     const size_t opt_off = reserve((sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((L.segs.size() * sizeof(Seg) + 3) / 4);
@@ -1427,6 +1451,65 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     // launch "last" (only when the fused form is unavailable): needs dZ1[3]
     if (!h->fused_l1_wgrad) gemm_add(h->g_last, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 3 * BZ1, h1, h1, G + L.pi_W1, h1, B));               // pi W1, b1
 
+    // ---- fused forward stages (sac1_fused.h)
+    h->fused = fused_ok(*cfg, L) && getenv("DDRL_SAC1_GENERIC") == nullptr;
+    for (int st = 0; st < 2 && h->fused; ++st) {
+        float *x = h->in[st][0], *x2 = h->in[st][1], *ac = h->in[st][2];
+        const long long HP = (long long)FH * nt2 * B;
+        auto base = [&](FwdArgs &F, int njobs) {
+            F = FwdArgs{};
+            F.njobs = njobs; F.tiles_n = nt2;
+            F.hd.pbase = h->slab; F.hd.tiles_m = B / 32; F.hd.tpj = (B / 32) * nt2; F.hd.h1 = h1; F.hd.h2 = h2;
+            {   // LDS tile geometry: sub-chunks of up to 64 (two 32-unit layer-1 blocks)
+                const int chunk = ((h1 + 15) >> 4) << 2;
+                F.ks_max = chunk < 64 ? (chunk < KS ? KS : chunk) : 64;
+                const int ta = 32 * (F.ks_max + 2), tb = F.ks_max * 36;
+                F.op_lds = ta > tb ? ta : tb;
+            }
+            F.B = B; F.ldh1 = ldh1; F.ldh2 = ldh2; F.act = a; F.nt2 = nt2;
+            F.scale = (float)cfg->act_scale;
+            F.act0 = h->act0; F.act2 = h->act2; F.logp0 = h->logp0; F.logp1 = h->logp1; F.save0 = h->save0;
+            F.php1 = h->hp + 1 * HP; F.pbmu1 = Pm + L.pi_bmu; F.pbls1 = Pm + L.pi_bls; F.peps1 = h->in[st][6];
+            F.noise_on = 0; F.n_each = B * a; F.noise_seed = 0;
+            F.e0 = h->in[st][5]; F.e1 = h->in[st][6]; F.e2 = h->in[st][7]; F.opt = h->opt;
+        };
+        auto pij = [&](const float *P, const float *in0, int ev, bool keep_h1) {
+            FwdJob j{};
+            j.in = FIn{in0, nullptr, P + L.pi_W1, P + L.pi_b1, o, 0};
+            j.W2 = P + L.pi_W2; j.b2 = P + L.pi_b2; j.H2 = h->H2 + ev * BH2; j.H1 = keep_h1 ? h->H1 + ev * BH1 : nullptr;
+            j.wh0 = P + L.pi_Wmu; j.wh1 = P + L.pi_Wls; j.nh = 2 * a; j.hsplit = a; j.hstride = a;
+            j.hp = h->hp + ev * HP;
+            return j;
+        };
+        auto qj = [&](const float *P, int q, const float *in0, const float *in1, int ev, bool keep_h1) {
+            FwdJob j{};
+            j.in = FIn{in0, in1, P + L.q_W1[q], P + L.q_b1[q], o, in1 ? a : 0};
+            j.W2 = P + L.q_W2[q]; j.b2 = P + L.q_b2[q]; j.H2 = h->H2 + ev * BH2; j.H1 = keep_h1 ? h->H1 + ev * BH1 : nullptr;
+            j.wh0 = P + L.q_W3[q]; j.wh1 = j.wh0; j.nh = 1; j.hsplit = 1; j.hstride = 1;
+            j.hp = h->hp + ev * HP;
+            return j;
+        };
+        FwdArgs &FA = h->f_a[st], &FB = h->f_b[st];
+        base(FA, 5);
+        FA.job[0] = pij(Pm, x, 0, true);   FA.job[0].aug = h->xp; FA.job[0].aug_ld = h->ldxp;
+        FA.job[1] = pij(Pm, x2, 1, false);
+        FA.job[2] = pij(Pt, x2, 2, false);
+        FA.job[3] = qj(Pm, 0, x, ac, 3, true); FA.job[3].aug = h->xa; FA.job[3].aug_ld = h->ldxa;
+        FA.job[4] = qj(Pm, 1, x, ac, 4, true);
+        auto offs = [&](FwdArgs &F) {
+            for (int i = 0; i < F.njobs; ++i) { F.hd.w2_off[i] = (int)(F.job[i].W2 - h->slab); F.hd.w1_off[i] = (int)(F.job[i].in.W1 - h->slab); }
+        };
+        offs(FA);
+        base(FB, 3);
+        auto from_pi = [&](FwdJob &j, int pev, const float *Ppi, const float *eps, int side) {
+            j.php = h->hp + pev * HP; j.pbmu = Ppi + L.pi_bmu; j.pbls = Ppi + L.pi_bls; j.peps = eps; j.side = side;
+        };
+        FB.job[0] = qj(Pm, 0, x, nullptr, 5, true);   from_pi(FB.job[0], 0, Pm, h->in[st][5], 1);
+        FB.job[1] = qj(Pt, 0, x2, nullptr, 6, false); from_pi(FB.job[1], 2, Pt, h->in[st][7], 2);
+        FB.job[2] = qj(Pt, 1, x2, nullptr, 7, false); from_pi(FB.job[2], 2, Pt, h->in[st][7], 0);
+        offs(FB);
+    }
+
     // ---- row kernels
     for (int st = 0; st < 2; ++st) {
         h->ra[st] = RowsA{h->H2, net_pi(Pm, L), net_pi(Pt, L), net_q(Pm, L, 0), net_q(Pm, L, 1),
@@ -1435,7 +1518,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                           h->H1, Pm + L.q_W1[0] + (long long)o * h1, Pt + L.q_W1[0] + (long long)o * h1,
                           Pt + L.q_W1[1] + (long long)o * h1, B, h2, ldh2, a, h1, ldh1, (float)cfg->act_scale};
         h->rb[st] = RowsB{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_q(Pt, L, 0), net_q(Pt, L, 1), h->in[st][3], h->in[st][4],
-                          h->logp0, h->logp1, h->q1o, h->q2o, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
+                          h->logp0, h->logp1, h->q1o, h->q2o, h->fused ? 1 : 0, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
                           (float)cfg->alpha, (float)cfg->gamma};
     }
     h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 3 * BZ2,
@@ -1525,6 +1608,14 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const ddrl_sac1_config_t &c = h->cfg;
     const int B = c.batch;
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
+    if (h->fused && stage <= 5) {
+        switch (stage) {
+            case 2: launch_fwd<0>(h->f_a[st], s); break;
+            case 5: launch_fwd<1>(h->f_b[st], s); break;
+            default: break;  // 1, 3: folded into the fused forward kernels
+        }
+        return;
+    }
     switch (stage) {
         case 1: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
         case 2: k_gemm<<<h->g_fa.total_tiles, 256, gemm_smem(h->g_fa), s>>>(h->g_fa); break;
@@ -1566,6 +1657,8 @@ static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, cons
     }
     h->l1a[st].noise_on = h->noise_armed ? 1 : 0;
     h->l1a[st].noise_seed = h->noise_seed;
+    h->f_a[st].noise_on = h->noise_armed ? 1 : 0;
+    h->f_a[st].noise_seed = h->noise_seed;
     h->noise_pending = h->noise_armed ? (unsigned)(3 * B * c.act_dim) : 0u;
     h->noise_armed = false;
     h->grad_imported = false;

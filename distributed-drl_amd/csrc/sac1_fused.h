@@ -1,0 +1,419 @@
+// Fused forward stages of the SAC1 update (included by sac1.hip, inside its anonymous namespace).
+//
+// Why: at batch 256 an update is a chain of dependent kernels and every kernel boundary costs
+// ~2.5 us (launch + cold L2 + the first round trips), more than the arithmetic of the small row
+// kernels between the GEMMs.  The fused path removes the boundaries instead of polishing them:
+//
+//   k_fwd<0>  = layer 1 of evaluations 0-4 generated straight into the GEMM's A operand in LDS
+//               (K = obs(+act) <= 12: 8-12 FMAs per element, cheaper than fetching the tile),
+//               the layer-2 GEMM, and the head dot products as per-column-tile partials
+//               hp[head][n-tile][row] (the 32x32 output tile is in LDS anyway);
+//   k_fwd<1>  = the same for evaluations 5-7, whose action input is computed in the prologue from
+//               the policy-head partials of k_fwd<0> (sum over n-tiles in a fixed order, tanh-squash,
+//               log-prob: core.py:49-87) — this is what k_rows_a + the second half of k_l1 did.
+//
+// The first-column-tile workgroups also write what later stages read from memory: X1 of the
+// evaluations that are differentiated (H1 slots 0,3,4,5), the augmented input rows [x|1], [x|a|1]
+// of the layer-1 wgrads, act0/act2/logp0/logp1/save0, and (phase 0) the generated noise.
+// Shapes outside the fused path's envelope (see fused_ok()) use the generic kernels of sac1.hip.
+
+constexpr int FD = 12;      // layer-1 input width handled by the generator (obs_dim + act_dim <= 12)
+constexpr int FH = 8;       // heads per evaluation: 2 * act_dim <= 8
+constexpr int F_MAXNT = 16; // column tiles of hidden2 (<= 512 / 32)
+
+struct FIn {  // X1 = relu([in0 | in1] * W1 + b1)
+    const float *in0, *in1;  // [B][d0], [B][d1]; phase 1: in1 = nullptr, the action comes from the policy heads
+    const float *W1, *b1;
+    int d0, d1;
+};
+
+struct FwdJob {
+    FIn in;
+    const float *W2, *b2;
+    float *H2;               // [B][ldh2]
+    float *H1;               // side output of the n-tile-0 workgroups: X1 rows [B][ldh1] (nullptr: not needed later)
+    float *aug;              // side output of the n-tile-0 workgroups: [in0 | in1] rows with row stride aug_ld (ones column is physical)
+    int aug_ld;
+    const float *wh0, *wh1;  // head kernels — policy: Wmu, Wls ([h2][act]); Q: W3 ([h2]), unused
+    int nh, hsplit, hstride; // heads; heads < hsplit come from wh0, the rest from wh1; element stride between rows of a head kernel
+    float *hp;               // head partials [nh][nt2][B]
+    // phase 1: the policy evaluation whose sampled action is this job's second input
+    const float *php;        // [2*act][nt2][B]
+    const float *pbmu, *pbls;
+    const float *peps;       // [B][act]
+    int side;                // n-tile-0 workgroups: 1 -> act0, logp0, save0   2 -> act2, and logp1 from the evaluation below
+};
+
+// What the first loads of k_fwd need (the W2 tile and the W1 columns) travels as leading SCALAR kernel
+// arguments: those are preloaded into SGPRs at wave launch (kernarg preload), whereas fields of a
+// by-value struct are fetched with s_load from the kernarg segment, which is cold after every kernel
+// boundary — the ISA showed three serialized round trips (gridDim, tile counts, pointers) = 2.5 k
+// cycles before the first vector load was issued.
+struct FwdHead {
+    const float *pbase;        // parameters are addressed as pbase + offset (main and target live in one slab)
+    int tiles_m, tpj, h1, h2;  // tpj = tiles_m * tiles_n: tiles per job
+    int w2_off[5], w1_off[5];  // per job
+};
+struct FwdArgs {
+    FwdHead hd;
+    int tiles_n, njobs, ks_max, op_lds;
+    int B, ldh1, ldh2, act, nt2;
+    float scale;
+    float *act0, *act2, *logp0, *logp1, *save0;
+    const float *php1, *pbmu1, *pbls1, *peps1;  // pi_main @ x2: only its log-prob is needed (actor_learner.py:62)
+    int noise_on, n_each;
+    uint32_t noise_seed;
+    float *e0, *e1, *e2;
+    const OptState *opt;
+    FwdJob job[5];
+#ifdef DDRL_STAMPS
+    long long *stamps;
+#endif
+};
+
+// One row of one policy evaluation, all action dims in one lane.  Same formulae and operation order
+// as policy_head() (core.py:49-87, 104-106); mu / log_std pre-activations arrive as sums of partials.
+struct PolRow {
+    float act[4], a[4], std[4], t[4];
+    float logp;
+};
+__device__ __forceinline__ PolRow policy_row(const float (&mu)[4], const float (&lsr)[4], const float (&eps)[4], int act, float scale) {
+    PolRow o;
+    float sp = 0.f, sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        o.act[c] = 0.f; o.a[c] = 0.f; o.std[c] = 0.f; o.t[c] = 0.f;
+        if (c < act) {
+            const float t = tanhf(lsr[c]);
+            const float log_std = -20.0f + 11.0f * (t + 1.0f);
+            const float std = expf(log_std);
+            const float e = eps[c];
+            const float u = mu[c] + e * std;
+            const float z = (e * std) / (std + STD_EPS);
+            const float pre = -0.5f * ((z * z + 2.0f * log_std) + LOG2PI);
+            const float a = tanhf(u);
+            const float om = 1.0f - a * a;
+            const float cl = fminf(fmaxf(om, 0.f), 1.f);
+            const float corr = logf(cl + 1e-6f);
+            sp += pre; sc += corr;
+            o.act[c] = a * scale; o.a[c] = a; o.std[c] = std; o.t[c] = t;
+        }
+    }
+    o.logp = sp - sc;
+    return o;
+}
+
+// Layer 1 on the matrix cores: X1[32 rows][32 units] = relu(in[32][D] * W1[D][32] + b1) is D/2
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMAs, input column ascending) per 32-unit block; the result
+// goes from the accumulator layout straight into the K-contiguous A image of the layer-2 GEMM.
+// (A VALU generator with the input tile broadcast from LDS was LDS-bandwidth bound: 8 waves x 1 KB
+// per ds_read_b128 -> 4.6 k cycles per sub-chunk; this form takes ~0.7 k.)
+struct L1Blk { float w[FD / 2]; float b; };  // lane (l31, h): W1[2j + h][unit], b1[unit] of one 32-unit block
+__device__ __forceinline__ void l1_block(const float (&av)[FD / 2], const L1Blk &wb, int D, floatx16 &x) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FD / 2; ++j)
+        if (2 * j < D) x = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wb.w[j], x, 0, 0, 0);  // wave-uniform guard
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = fmaxf(x[r] + wb.b, 0.f);
+}
+
+template <int PH>
+__global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, int tpj, int h1_, int h2_, int w2o0, int w2o1, int w2o2, int w2o3,
+                                             int w2o4, int w1o0, int w1o1, int w1o2, int w1o3, int w1o4, FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float s_in[FD][32];  // transposed input tile: [input column][row]
+    __shared__ float s_wh[FH][32];
+    __shared__ float s_hd[2][FH][32];
+#ifdef DDRL_STAMPS
+    long long *st = (a.stamps && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) ? a.stamps + (long long)blockIdx.x * 32 : nullptr;
+    STAMP(0);
+#endif
+    int t;
+    {   // XCD-aware, panel-major tile order (see k_gemm)
+        const int nwg = (PH == 0 ? 5 : 3) * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;  // == gridDim.x (a hidden-argument load)
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int ji = t / tpj;
+    t -= ji * tpj;
+    const int m0 = (t % tiles_m) * 32, nt = t / tiles_m, n0 = nt * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int K = h1_, B = a.B, H2N = h2_;
+    const int chunk = ((K + 15) >> 4) << 2;
+    const int k0 = w * chunk;
+    const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
+    const int kw = k1 > k0 ? k1 - k0 : 0;
+    const int ks_a = kw < 64 ? kw : 64, ks_b = kw - ks_a;  // sub-chunks aligned to the 32-unit layer-1 blocks
+    float *sA = smem + (w * 2 + 0) * a.op_lds, *sB = smem + (w * 2 + 1) * a.op_lds;
+    const int kcs = a.ks_max + 2;
+    const bool first_n = nt == 0;
+    STAMP(15);
+
+    // ---- every independent load of the kernel, up front --------------------------------------
+    // (1) + (2) need only the preloaded part of the arguments
+    const int w2o = ji == 0 ? w2o0 : (ji == 1 ? w2o1 : (ji == 2 ? w2o2 : (ji == 3 ? w2o3 : w2o4)));
+    const int w1o = ji == 0 ? w1o0 : (ji == 1 ? w1o1 : (ji == 2 ? w1o2 : (ji == 3 ? w1o3 : w1o4)));
+    const float *W2 = pbase + w2o, *W1 = pbase + w1o;
+    // (1) B operand = W2 rows of this wave's K range
+    Op2<false> ob;
+    ob.init(W2, H2N, n0, H2N, k0, lane);
+    float4 pb[8];
+    STAMP(16);
+    ob.load(0, 0, ks_a, H2N, pb);
+    STAMP(11);
+    // (2) W1 / b1 of the wave's (up to four) 32-unit blocks, directly in the MFMA B-operand layout;
+    // rows beyond the job's input width are fetched (they lie inside the parameter slab) and zeroed
+    // once the width is known.
+    // (Fetching [W1 ; b1] as six 1-KB row loads and redistributing through LDS was measured slower:
+    // 17.2 vs 14.0 us per launch — the extra LDS hop sits on the critical path before the first MFMA.)
+    L1Blk wb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kc = k0 + q * 32 + l31;
+        const int kcc = kc < k1 ? kc : 0;
+#pragma unroll
+        for (int j = 0; j < FD / 2; ++j) wb[q].w[j] = W1[(long long)(2 * j + h) * K + kcc];
+    }
+    STAMP(12);
+    const FwdJob &jb = a.job[ji];
+    const int d0 = jb.in.d0, d1 = PH == 0 ? jb.in.d1 : a.act, D = d0 + d1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wb[q].b = jb.in.b1[(k0 + q * 32 + l31 < k1) ? k0 + q * 32 + l31 : 0];
+    STAMP(13);
+    // (3) epilogue operands
+    const float biasv = jb.b2[(n0 + l31 < H2N) ? n0 + l31 : 0];
+    float whv = 0.f;
+    {
+        const int c = tid >> 5, col = n0 + (tid & 31);
+        const bool ok = c < jb.nh && col < H2N;
+        const float *p = c < jb.hsplit ? jb.wh0 : jb.wh1;
+        const int cc = c < jb.hsplit ? c : c - jb.hsplit;
+        const float v = p[ok ? (long long)col * jb.hstride + cc : 0];
+        whv = ok ? v : 0.f;
+    }
+    // (4) the 32 input rows of this tile
+    float inv[2];
+    bool inok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;           // 32 * FD = 384 slots
+        const int d = idx >> 5, r = idx & 31;
+        const int row = m0 + r;
+        const int lim = PH == 0 ? D : d0;        // phase 1: the action columns are computed below
+        inok[u] = idx < 32 * FD && d < lim;
+        const bool from0 = d < d0;
+        const float *p = (from0 || !inok[u]) ? jb.in.in0 : jb.in.in1;
+        const long long off = from0 ? (long long)row * d0 + d : (long long)row * d1 + (d - d0);
+        inv[u] = p[inok[u] ? off : 0];
+    }
+    STAMP(14);
+    // (5) phase 1: head partials of the policy evaluation(s), summed over the n-tiles in a fixed order
+    float hsum[2] = {0.f, 0.f};
+    float epsv[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool two = PH == 1 && jb.side == 2 && first_n;  // block-uniform
+    if (PH == 1) {
+        const int c = tid >> 5, r = tid & 31;
+        const bool okc = c < 2 * a.act;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 0 || two) {
+                const float *hp = e == 0 ? jb.php : a.php1;
+                float v[F_MAXNT];
+#pragma unroll
+                for (int q = 0; q < F_MAXNT; ++q)
+                    v[q] = hp[(okc && q < a.nt2) ? ((long long)c * a.nt2 + q) * B + m0 + r : 0];
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < F_MAXNT; ++q) s += (q < a.nt2) ? v[q] : 0.f;
+                hsum[e] = s;
+            }
+        }
+        if (w < 2) {  // wave 0: the action-giving evaluation; wave 1: pi_main @ x2 (side == 2)
+            const float *pe = w == 0 ? jb.peps : a.peps1;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) epsv[c2] = (w == 0 || two) ? pe[(long long)(m0 + l31) * a.act + (c2 < a.act ? c2 : 0)] : 0.f;
+        }
+    }
+
+    STAMP(1);
+    // ---- stage the shared inputs ------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < 32 * FD) {
+            const int d = idx >> 5, r = idx & 31;
+            const float v = inok[u] ? inv[u] : 0.f;
+            if (PH == 0 || d < d0 || d >= D) s_in[d][r] = v;
+            if (jb.aug && first_n && inok[u]) jb.aug[(long long)(m0 + r) * jb.aug_ld + d] = v;
+        }
+    }
+    s_wh[tid >> 5][tid & 31] = whv;
+
+    if (PH == 1) {
+        s_hd[0][tid >> 5][tid & 31] = hsum[0];
+        if (two) s_hd[1][tid >> 5][tid & 31] = hsum[1];
+    }
+    if (PH == 0 && a.noise_on && ji == 0 && first_n) {
+        // eps_x, eps_x2, eps_t of this tile's rows; element index as in one flat [3][B*act] fill
+        const unsigned long long base = a.opt->noise_ctr;
+        const int per_row = 3 * a.act;
+        for (int e = tid; e < 32 * per_row; e += 256) {
+            const int rr = e / per_row, q = e - rr * per_row;
+            const int wch = q / a.act, c = q - wch * a.act;
+            const int k = (m0 + rr) * a.act + c;
+            (wch == 0 ? a.e0 : (wch == 1 ? a.e1 : a.e2))[k] = normal_at(a.noise_seed, base + (unsigned long long)wch * a.n_each + k);
+        }
+    }
+    __syncthreads();
+    if (PH == 1) {
+        if (w == 0 || (w == 1 && two)) {  // wave-uniform
+            const int e = w;               // 0: action-giving evaluation, 1: pi_main @ x2
+            const float *bmu = e == 0 ? jb.pbmu : a.pbmu1, *bls = e == 0 ? jb.pbls : a.pbls1;
+            float mu[4], ls[4], ev[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cc = c < a.act ? c : 0;
+                mu[c] = s_hd[e][cc][l31] + bmu[cc];
+                ls[c] = s_hd[e][a.act + cc][l31] + bls[cc];
+                ev[c] = epsv[c];
+            }
+            const PolRow o = policy_row(mu, ls, ev, a.act, a.scale);
+            const int row = m0 + l31;
+            if (e == 0 && lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < a.act) s_in[d0 + c][l31] = o.act[c];
+            }
+            if (first_n && lane < 32) {
+                if (e == 0 && jb.side == 1) {
+                    a.logp0[row] = o.logp;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < a.act) {
+                            a.act0[row * a.act + c] = o.act[c];
+                            *reinterpret_cast<float4 *>(a.save0 + ((long long)row * a.act + c) * 4) = make_float4(o.a[c], o.std[c], o.t[c], ev[c]);
+                        }
+                } else if (e == 0 && jb.side == 2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < a.act) a.act2[row * a.act + c] = o.act[c];
+                } else if (e == 1) {
+                    a.logp1[row] = o.logp;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    STAMP(2);
+    // ---- K loop: A generated, B loaded -------------------------------------------------------
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float *h1row = (jb.H1 && first_n) ? jb.H1 + (long long)m0 * a.ldh1 : nullptr;
+    float av[FD / 2];  // A operand of the layer-1 MFMAs: in[row l31][2j + h]
+#pragma unroll
+    for (int j = 0; j < FD / 2; ++j) av[j] = s_in[2 * j + h][l31];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool okk = k0 + q * 32 + l31 < k1;
+#pragma unroll
+        for (int j = 0; j < FD / 2; ++j) wb[q].w[j] = (okk && 2 * j + h < D) ? wb[q].w[j] : 0.f;
+    }
+    // X1 of a sub-chunk (two 32-unit blocks) from the accumulator layout into the A image
+    auto put = [&](const floatx16 &x, int bb, int ks, int kbase) {
+        const int col = bb * 32 + l31;
+        if (bb * 32 < ks && col < ks) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[((r & 3) + 8 * (r >> 2) + 4 * h) * kcs + col] = x[r];
+            if (h1row) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1row[(long long)((r & 3) + 8 * (r >> 2) + 4 * h) * a.ldh1 + kbase + col] = x[r];
+            }
+        }
+    };
+    floatx16 xa0, xa1, xb0, xb1;
+    l1_block(av, wb[0], D, xa0);
+    if (32 < ks_a) l1_block(av, wb[1], D, xa1);
+    put(xa0, 0, ks_a, k0);
+    put(xa1, 1, ks_a, k0);
+    // the second sub-chunk's layer 1 runs on the matrix cores while the W2 tile is still in flight;
+    // only its LDS writes have to wait until the first sub-chunk's A image has been consumed
+    if (0 < ks_b) l1_block(av, wb[2], D, xb0);
+    if (32 < ks_b) l1_block(av, wb[3], D, xb1);
+    STAMP(3);
+    ob.store(sB, ks_a, kcs, lane, pb);
+    if (ks_b > 0) ob.load(1, ks_a, ks_b, H2N, pb);
+    wave_lds_sync();
+    STAMP(4);
+    mfma_chunk<true, false>(sA, sB, ks_a, kcs, l31, h, acc);
+    STAMP(5);
+    if (ks_b > 0) {
+        wave_lds_sync();
+        put(xb0, 0, ks_b, k0 + 64);
+        put(xb1, 1, ks_b, k0 + 64);
+        STAMP(6);
+        ob.store(sB, ks_b, kcs, lane, pb);
+        wave_lds_sync();
+        STAMP(7);
+        mfma_chunk<true, false>(sA, sB, ks_b, kcs, l31, h, acc);
+        STAMP(8);
+    }
+
+    // ---- split-K combine, bias + relu, H2 store, head partials -------------------------------
+    __syncthreads();
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+    __syncthreads();
+    float outv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int row = o >> 5, col = o & 31;
+        outv[q] = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+    }
+    const bool colok = n0 + (tid & 31) < H2N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+        float v = fmaxf(outv[q] + biasv, 0.f);
+        v = colok ? v : 0.f;
+        if (colok) jb.H2[(long long)gi * a.ldh2 + gj] = v;
+        outv[q] = v;
+    }
+    STAMP(9);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        red[0][o >> 5][o & 31] = outv[q];
+    }
+    __syncthreads();
+    {
+        const int c = tid >> 5, r = tid & 31;
+        if (c < jb.nh) {
+            float s = 0.f;
+#pragma unroll
+            for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
+            jb.hp[((long long)c * a.nt2 + nt) * B + m0 + r] = s;
+        }
+    }
+    STAMP(10);
+}
+
+static size_t fwd_smem(const FwdArgs &a) {
+    const size_t x = (size_t)4 * 2 * a.op_lds * sizeof(float), y = (size_t)RED_LDS * sizeof(float);
+    return x > y ? x : y;
+}
+
+template <int PH>
+static void launch_fwd(const FwdArgs &F, hipStream_t s) {
+    const FwdHead &d = F.hd;
+    k_fwd<PH><<<F.njobs * d.tpj, 256, fwd_smem(F), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.w2_off[0], d.w2_off[1], d.w2_off[2], d.w2_off[3],
+                                                        d.w2_off[4], d.w1_off[0], d.w1_off[1], d.w1_off[2], d.w1_off[3], d.w1_off[4], F);
+}
