@@ -57,7 +57,7 @@ struct GemmJob {
     int part_nk, part_ldx;
     int tiles_n, tile_start, ntiles;
 };
-constexpr int MAX_GEMM_JOBS = 8;
+constexpr int MAX_GEMM_JOBS = 12;
 #ifdef DDRL_STAMPS
 #define STAMP(i) do { if (st) st[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define STAMP_ARG , long long *st
@@ -362,9 +362,14 @@ struct Op2 {
                     *reinterpret_cast<float2 *>(d) = make_float2(ok ? v[i].x : 0.f, ok ? v[i].y : 0.f);
                     *reinterpret_cast<float2 *>(d + 2) = make_float2(ok ? v[i].z : 0.f, ok ? v[i].w : 0.f);
                 }
-            } else if (krow[i] < ks) {  // rows beyond the chunk are never read (and would overflow the tile)
+            } else if (krow[i] < ((ks + 3) & ~3)) {
+                // rows beyond the chunk's last 4-k group are never read (and would overflow the tile);
+                // rows inside that group but beyond ks ARE read by the MFMAs (K = batch need not be a
+                // multiple of 4 for the wgrads) and must be zero, not whatever the LDS held before
+                const bool in = krow[i] < ks;
                 *reinterpret_cast<float4 *>(s + krow[i] * 36 + (lane & 7) * 4) =
-                    make_float4(okc[0] ? v[i].x : 0.f, okc[1] ? v[i].y : 0.f, okc[2] ? v[i].z : 0.f, okc[3] ? v[i].w : 0.f);
+                    make_float4(in && okc[0] ? v[i].x : 0.f, in && okc[1] ? v[i].y : 0.f, in && okc[2] ? v[i].z : 0.f,
+                                in && okc[3] ? v[i].w : 0.f);
             }
         }
     }
@@ -1288,6 +1293,8 @@ struct ddrl_sac1 {
     int rows_b_blocks;
     bool fused;          // fused forward stages (sac1_fused.h) instead of k_l1 / k_gemm / k_rows_a
     FwdArgs f_a[2], f_b[2];
+    BqArgs bq[2];
+    GemmJobs g_bpi_f;    // fused path: the policy backward launch also carries the Q layer-2/head wgrads
     float *hp;           // head partials [NEVAL][FH][nt2][B]
     bool fused_l1_wgrad;  // pi layer-1 wgrad via dgrad-epilogue partials + Adam (needs hidden1 % 4 == 0)
     // set by ddrl_sac1_fill_noise, consumed by the next compute_grads / apply_grads
@@ -1508,6 +1515,34 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         FB.job[1] = qj(Pt, 0, x2, nullptr, 6, false); from_pi(FB.job[1], 2, Pt, h->in[st][7], 2);
         FB.job[2] = qj(Pt, 1, x2, nullptr, 7, false); from_pi(FB.job[2], 2, Pt, h->in[st][7], 0);
         offs(FB);
+        BqArgs &Q = h->bq[st];
+        Q = BqArgs{};
+        Q.hd.pbase = h->slab; Q.hd.tiles_m = B / 32; Q.tiles_n = (h1 + 31) / 32; Q.hd.tpj = Q.hd.tiles_m * Q.tiles_n; Q.hd.h1 = h1; Q.hd.h2 = h2;
+        {
+            const int chunk = ((h2 + 15) >> 4) << 2;
+            int half = ((chunk + 7) >> 3) << 2;
+            if (half > chunk) half = chunk;
+            Q.ks_max = half < KS ? KS : half;
+            const int ta = 32 * (Q.ks_max + 2), tb = Q.ks_max * 36;
+            Q.op_lds = ta > tb ? ta : tb;
+        }
+        Q.B = B; Q.ldh1 = ldh1; Q.ldh2 = ldh2; Q.nt2 = nt2; Q.hp = h->hp;
+        Q.b3q1 = Pm + L.q_b3[0]; Q.b3q2 = Pm + L.q_b3[1]; Q.b3q1t = Pt + L.q_b3[0]; Q.b3q2t = Pt + L.q_b3[1];
+        Q.rew = h->in[st][3]; Q.done = h->in[st][4]; Q.logp0 = h->logp0; Q.logp1 = h->logp1;
+        Q.q1o = h->q1o; Q.q2o = h->q2o; Q.dq4 = h->dq4; Q.loss_part = h->loss_part;
+        Q.alpha = (float)cfg->alpha; Q.gamma = (float)cfg->gamma;
+        // slot 2 first: its dZ1 is what k_rows_c waits for
+        Q.job[0] = BqJob{h->H2 + 5 * BH2, Pm + L.q_W3[0], Pm + L.q_W2[0], h->H1 + 5 * BH1, h->dZ1 + 2 * BZ1, nullptr, 2};
+        Q.job[1] = BqJob{h->H2 + 3 * BH2, Pm + L.q_W3[0], Pm + L.q_W2[0], h->H1 + 3 * BH1, h->dZ1 + 0 * BZ1, h->dZ2 + 0 * BZ2, 0};
+        Q.job[2] = BqJob{h->H2 + 4 * BH2, Pm + L.q_W3[1], Pm + L.q_W2[1], h->H1 + 4 * BH1, h->dZ1 + 1 * BZ1, h->dZ2 + 1 * BZ2, 1};
+        for (int i = 0; i < 3; ++i) { Q.hd.h2_off[i] = (int)(Q.job[i].H2 - h->slab); Q.hd.w2_off[i] = (int)(Q.job[i].W2 - h->slab); }
+    }
+    if (h->fused) {  // the policy backward launch + the Q wgrads whose B operands (dZ2, dq) k_bwdq wrote
+        h->g_bpi_f = h->g_bpi;
+        for (int q = 0; q < 2; ++q) {
+            gemm_add(h->g_bpi_f, gemm_wgrad(h->H1 + (3 + q) * BH1, ldh1, h1, h->dZ2 + q * BZ2, h2, h2, G + L.q_W2[q], h2, B));
+            gemm_add(h->g_bpi_f, gemm_wgrad(h->H2 + (3 + q) * BH2, ldh2, h2, h->dq4 + (long long)q * B * 4, 4, 1, G + L.q_W3[q], 1, B));
+        }
     }
 
     // ---- row kernels
@@ -1614,6 +1649,11 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
             case 5: launch_fwd<1>(h->f_b[st], s); break;
             default: break;  // 1, 3: folded into the fused forward kernels
         }
+        return;
+    }
+    if (h->fused && (stage == 6 || stage == 7 || stage == 9)) {
+        if (stage == 7) launch_bwdq(h->bq[st], s);  // 6 (k_rows_b) is folded into it
+        if (stage == 9) k_gemm<<<h->g_bpi_f.total_tiles, 256, gemm_smem(h->g_bpi_f), s>>>(h->g_bpi_f);
         return;
     }
     switch (stage) {

@@ -417,3 +417,200 @@ static void launch_fwd(const FwdArgs &F, hipStream_t s) {
     k_fwd<PH><<<F.njobs * d.tpj, 256, fwd_smem(F), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.w2_off[0], d.w2_off[1], d.w2_off[2], d.w2_off[3],
                                                         d.w2_off[4], d.w1_off[0], d.w1_off[1], d.w1_off[2], d.w1_off[3], d.w1_off[4], F);
 }
+
+// ==========================================================================================
+// k_bwdq: backward of the three Q evaluations through layer 2 (the dgrad GEMMs), with what
+// k_rows_b did folded in: the prologue turns the Q-head partials of the forward stages into
+// q1(x,a), q2(x,a), q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq
+// (actor_learner.py:58-69) for the 32 rows of the tile, and the A operand
+//     dZ2[i][k] = dq[i] * W3[k] * (H2[i][k] > 0)
+// is produced from the H2 tile while it is staged into LDS — dZ2 never makes a round trip through
+// memory on this path.  The n-tile-0 workgroups also write dZ2 / dq (B operands of the Q wgrads,
+// which run in the next launch), q1/q2 and the loss terms.
+// ==========================================================================================
+struct BqJob {
+    const float *H2;   // [B][ldh2] of the differentiated evaluation
+    const float *W3;   // [h2]
+    const float *W2;   // [h1][h2]
+    const float *H1;   // [B][ldh1]: relu mask of the dgrad output
+    float *dZ1;        // [B][h1]
+    float *dZ2;        // side output [B][h2] (nullptr: not needed)
+    int slot;          // 0: q1(x,a)   1: q2(x,a)   2: q1(x,pi)
+};
+struct BqHead {
+    const float *pbase;
+    int tiles_m, tpj, h1, h2;
+    int h2_off[3], w2_off[3];
+};
+struct BqArgs {
+    BqHead hd;
+    int tiles_n, ks_max, op_lds, B, ldh1, ldh2, nt2;
+    const float *hp;   // head partials [NEVAL][FH][nt2][B]
+    const float *b3q1, *b3q2, *b3q1t, *b3q2t;
+    const float *rew, *done, *logp0, *logp1;
+    float *q1o, *q2o, *dq4, *loss_part;
+    float alpha, gamma;
+    BqJob job[3];
+};
+
+__global__ void __launch_bounds__(256) k_bwdq(const float *pbase, int tiles_m, int tpj, int h1_, int h2_, int h2o0, int h2o1, int h2o2, int w2o0,
+                                              int w2o1, int w2o2, BqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float s_q[8][32];
+    __shared__ float s_g[32];
+    int t;
+    {
+        const int nwg = 3 * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int ji = t / tpj;
+    t -= ji * tpj;
+    const int m0 = (t % tiles_m) * 32, nt = t / tiles_m, n0 = nt * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int K = h2_, N = h1_, ldh2 = ((h2_ + 1) + 3) & ~3;
+    const int chunk = ((K + 15) >> 4) << 2;
+    const int k0 = w * chunk;
+    const int k1 = (k0 + chunk < K) ? (k0 + chunk) : K;
+    const int kw = k1 > k0 ? k1 - k0 : 0;
+    const int half = ((kw + 7) >> 3) << 2;
+    const int ks_a = half < kw ? half : kw, ks_b = kw - ks_a;
+    const bool first_n = nt == 0;
+
+    // ---- loads that need only the preloaded scalars: both operand tiles of the first sub-chunk
+    const float *H2 = pbase + (ji == 0 ? h2o0 : (ji == 1 ? h2o1 : h2o2));
+    const float *W2 = pbase + (ji == 0 ? w2o0 : (ji == 1 ? w2o1 : w2o2));
+    Op2<true> oa, ob;
+    oa.init(H2, ldh2, m0, 0x7fffffff, k0, lane);  // rows are always valid (B % 32 == 0)
+    ob.init(W2, K, n0, N, k0, lane);
+    float4 pa[8], pb[8];
+    oa.load(0, 0, ks_a, ldh2, pa);
+    ob.load(0, 0, ks_a, K, pb);
+    // ---- everything else (needs the argument record)
+    const BqJob &jb = a.job[ji];
+    const int slot = jb.slot, B = a.B;
+    float *sA = smem + (w * 2 + 0) * a.op_lds, *sB = smem + (w * 2 + 1) * a.op_lds;
+    const int kcs = a.ks_max + 2;
+    const int kk = (lane & 15) * 4;
+    // W3 of this lane's four k of each sub-chunk
+    const float4 w3a = *reinterpret_cast<const float4 *>(jb.W3 + ((kk < ks_a) ? k0 + kk : 0));
+    const float4 w3b = *reinterpret_cast<const float4 *>(jb.W3 + ((kk < ks_b) ? k0 + ks_a + kk : 0));
+    // epilogue mask
+    float maskv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+        maskv[q] = jb.H1[(long long)gi * a.ldh1 + (gj < N ? gj : 0)];
+    }
+    // Q-head partials of this tile's rows: c = 0..4 <-> evaluations 3,4,5,6,7
+    const bool need_q = slot != 2;  // block-uniform: the q1(x,pi) path has dq = -1/B
+    float qsum = 0.f;
+    float rew = 0.f, done = 0.f, lp0 = 0.f, lp1 = 0.f;
+    if (need_q) {
+        const int c = tid >> 5, r = tid & 31;
+        const bool okc = c < 5;
+        const long long HP = (long long)FH * a.nt2 * B;
+        const float *hp = a.hp + (3 + (okc ? c : 0)) * HP;
+        float v[F_MAXNT];
+#pragma unroll
+        for (int q = 0; q < F_MAXNT; ++q) v[q] = hp[(q < a.nt2) ? (long long)q * B + m0 + r : m0 + r];
+#pragma unroll
+        for (int q = 0; q < F_MAXNT; ++q) qsum += (q < a.nt2) ? v[q] : 0.f;
+        if (w == 0) { rew = a.rew[m0 + l31]; done = a.done[m0 + l31]; lp0 = a.logp0[m0 + l31]; lp1 = a.logp1[m0 + l31]; }
+    }
+    const float b3_1 = a.b3q1[0], b3_2 = a.b3q2[0], b3_1t = a.b3q1t[0], b3_2t = a.b3q2t[0];
+    if (need_q) {
+        s_q[tid >> 5][tid & 31] = qsum;
+        __syncthreads();
+        if (w == 0) {
+            const int row = m0 + l31;
+            const float q1v = s_q[0][l31] + b3_1, q2v = s_q[1][l31] + b3_2, q1pi = s_q[2][l31] + b3_1;
+            const float q1t = s_q[3][l31] + b3_1t, q2t = s_q[4][l31] + b3_2t;
+            const float minq = fminf(q1t, q2t);                          // actor_learner.py:59
+            const float vb = minq - a.alpha * lp1;                       // :62
+            const float backup = rew + (a.gamma * (1.0f - done)) * vb;   // :63
+            const float e1 = backup - q1v, e2 = backup - q2v;
+            const float inv_b = 1.0f / (float)B;
+            const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b;
+            if (lane < 32) {
+                s_g[l31] = slot == 0 ? dq1 : dq2;
+                if (first_n && slot == 0) {
+                    a.q1o[row] = q1v; a.q2o[row] = q2v;
+                    a.loss_part[row * 3 + 0] = a.alpha * lp0 - q1pi;     // :66
+                    a.loss_part[row * 3 + 1] = e1 * e1;                  // :67
+                    a.loss_part[row * 3 + 2] = e2 * e2;                  // :68
+                    *reinterpret_cast<float4 *>(a.dq4 + (long long)row * 4) = make_float4(dq1, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4 *>(a.dq4 + ((long long)B + row) * 4) = make_float4(dq2, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    } else if (tid < 32) {
+        s_g[tid] = -1.0f / (float)B;
+    }
+    __syncthreads();
+    float gr[8];  // dq of this lane's eight A-tile rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gr[i] = s_g[i * 4 + (lane >> 4)];
+    float *z2row = (jb.dZ2 && first_n) ? jb.dZ2 + (long long)m0 * K : nullptr;
+
+    // A operand: dZ2 tile made from the H2 tile on its way into LDS
+    auto stage_a = [&](const float4 (&v)[8], const float4 &w3, int ks, int kbase) {
+        if (kk < ks) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = i * 4 + (lane >> 4);
+                const float g = gr[i];
+                const float4 z = make_float4(v[i].x > 0.f ? g * w3.x : 0.f, v[i].y > 0.f ? g * w3.y : 0.f,
+                                             v[i].z > 0.f ? g * w3.z : 0.f, v[i].w > 0.f ? g * w3.w : 0.f);
+                float *d = sA + r * kcs + kk;
+                *reinterpret_cast<float2 *>(d) = make_float2(z.x, z.y);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(z.z, z.w);
+                if (z2row) *reinterpret_cast<float4 *>(z2row + (long long)r * K + kbase + kk) = z;
+            }
+        }
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    stage_a(pa, w3a, ks_a, k0);
+    ob.store(sB, ks_a, kcs, lane, pb);
+    if (ks_b > 0) {
+        oa.load(1, ks_a, ks_b, ldh2, pa);
+        ob.load(1, ks_a, ks_b, K, pb);
+    }
+    wave_lds_sync();
+    mfma_chunk<true, true>(sA, sB, ks_a, kcs, l31, h, acc);
+    if (ks_b > 0) {
+        wave_lds_sync();
+        stage_a(pa, w3b, ks_b, k0 + ks_a);
+        ob.store(sB, ks_b, kcs, lane, pb);
+        wave_lds_sync();
+        mfma_chunk<true, true>(sA, sB, ks_b, kcs, l31, h, acc);
+    }
+    // split-K combine, relu mask, dZ1 store
+    __syncthreads();
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + 256 * q;
+        const int row = o >> 5, col = o & 31;
+        const float s = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+        const int gj = n0 + col;
+        if (gj < N) jb.dZ1[(long long)(m0 + row) * N + gj] = maskv[q] > 0.f ? s : 0.f;
+    }
+}
+
+static size_t bq_smem(const BqArgs &a) {
+    const size_t x = (size_t)4 * 2 * a.op_lds * sizeof(float), y = (size_t)RED_LDS * sizeof(float);
+    return x > y ? x : y;
+}
+static void launch_bwdq(const BqArgs &A, hipStream_t s) {
+    const BqHead &d = A.hd;
+    k_bwdq<<<3 * d.tpj, 256, bq_smem(A), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.h2_off[0], d.h2_off[1], d.h2_off[2], d.w2_off[0], d.w2_off[1],
+                                              d.w2_off[2], A);
+}
