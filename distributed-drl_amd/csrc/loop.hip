@@ -15,6 +15,9 @@
 #include <cstring>
 #include <vector>
 
+// internal (sac1.hip): put the learner's double-buffered optimizer state on copy 0
+int ddrl_sac1_internal_opt_sync(ddrl_sac1_t *h, void *stream);
+
 struct ddrl_loop {
     ddrl_sac1_t *learner;
     ddrl_replay_t *replay;
@@ -55,8 +58,9 @@ static int grads_from(ddrl_loop *h, int set, void *stream) {
                                    stream);
 }
 
-// Capture `per_graph` updates.  Default: one branch; the sampler of update u+1 is an extra workgroup
-// of update u's Adam kernel (ddrl_sac1_apply_grads_and_sample).
+// Capture `per_graph` updates.  Default: one branch; the sampler of update u+1 rides inside update u
+// (ddrl_sac1_step_and_sample: an extra workgroup of a forward launch on the fused path, of the Adam
+// kernel otherwise).
 // Experimental overlap modes (bit-identical results, both measured SLOWER on MI355X — a kernel
 // starting or ending on another branch costs the kernel running beside it more than it hides):
 //   DDRL_LOOP_FORK=adam  sampler of update u+1 beside the Adam/polyak kernel of update u (105 us)
@@ -76,7 +80,9 @@ static int capture(ddrl_loop *h, hipStream_t main_s) {
         DDRL_HIP_CHECK(hipEventCreateWithFlags(&e_grad[i], hipEventDisableTiming));
     }
     hipGraph_t graph = nullptr;
-    int rc = DDRL_OK;
+    int rc = ddrl_sac1_internal_opt_sync(h->learner, (void *)main_s);  // the graph starts on copy 0 of the optimizer state ...
+    if (rc != DDRL_OK) return rc;
+    DDRL_HIP_CHECK(hipStreamSynchronize(main_s));  // one-time: the capture stream may not be the caller's
     DDRL_HIP_CHECK(hipStreamBeginCapture(main_s, hipStreamCaptureModeThreadLocal));
     hipError_t e = hipSuccess;
 #define HE(x) do { if (e == hipSuccess && rc == DDRL_OK) e = (x); } while (0)
@@ -86,9 +92,14 @@ static int capture(ddrl_loop *h, hipStream_t main_s) {
         // interleave inside one graph, so this equals the sequential sample -> update order.
         RC(sample_into(h, 0, (void *)main_s));
         for (int i = 0; i < n; ++i) {
-            RC(grads_from(h, i & 1, (void *)main_s));
-            if (i + 1 < n) RC(ddrl_sac1_apply_grads_and_sample(h->learner, h->replay, (i + 1) & 1, (void *)main_s));
-            else RC(ddrl_sac1_apply_grads(h->learner, (void *)main_s));
+            RC(ddrl_sac1_fill_noise(h->learner, h->seed, (void *)main_s));
+            if (i + 1 < n) {
+                RC(ddrl_sac1_step_and_sample(h->learner, i & 1, h->replay, (i + 1) & 1, (void *)main_s));
+            } else {
+                float **b = h->buf[i & 1];
+                RC(ddrl_sac1_step(h->learner, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr,
+                                  (void *)main_s));
+            }
         }
     } else if (mode == 2) {
         HE(hipEventRecord(e_fork, main_s));
@@ -116,6 +127,7 @@ static int capture(ddrl_loop *h, hipStream_t main_s) {
             if (i + 1 < n) HE(hipStreamWaitEvent(main_s, e_smp[i + 1], 0));
         }
     }
+    RC(ddrl_sac1_internal_opt_sync(h->learner, (void *)main_s));  // ... and ends on it (a copy node when n is odd)
 #undef HE
 #undef RC
     // every side-branch node is an ancestor of a main-stream node: the branch is joined
@@ -178,6 +190,10 @@ int ddrl_loop_run(ddrl_loop_t *h, int64_t n_updates, void *stream) {
             rc = capture(h, cs);
             if (own) (void)hipStreamDestroy(own);
             if (rc != DDRL_OK) return rc;
+        }
+        if (left >= h->per_graph) {  // eager updates since the last replay may have left the optimizer state on copy 1
+            const int rc2 = ddrl_sac1_internal_opt_sync(h->learner, stream);
+            if (rc2 != DDRL_OK) return rc2;
         }
         while (left >= h->per_graph) {
             DDRL_HIP_CHECK(hipGraphLaunch(h->exec, s));

@@ -38,6 +38,7 @@ constexpr float STD_EPS = 1e-8f;               // core.py:5 EPS
 // ------------------------------------------------------------------------------------------
 // job descriptors
 // ------------------------------------------------------------------------------------------
+struct OptState;
 struct GemmJob {
     const float *A, *B;
     float *C;
@@ -56,6 +57,26 @@ struct GemmJob {
     float *part;
     int part_nk, part_ldx;
     int tiles_n, tile_start, ntiles;
+    // optional optimizer step in the epilogue (wgrad jobs; GemmJobs::ad.on): element (i, j) of C is
+    // parameter adam_off + i*ldc + j of the flat buffers (-1: none).  For the job with the fused
+    // layer-1 partials, adam_off addresses row 0 of that layer-1 kernel (its bias row follows it).
+    long long adam_off;
+};
+// Adam + polyak applied by the workgroup that produced a gradient tile (every wgrad tile is complete
+// inside one workgroup: in-workgroup split-K).  The one gradient that is NOT complete inside a
+// workgroup — the policy's layer 1, summed over the row tiles' partials — is stepped by a 16-block
+// k_adam_polyak launch behind it.  (Stepping it inside this launch was measured: a last-arriver among
+// the producers +3.5 us, polling consumer workgroups +7 us — store ack, counter, partial loads and
+// the parameter stores are four dependent memory round trips behind the slowest producer; a
+// __threadfence per producer, i.e. L2 write-back + invalidate, made the launch 5x slower.)
+struct AdamCtx {
+    int on;
+    float *p, *t, *m, *v; // flat buffers in the internal layout, indexed like the gradient buffer
+    float *g;
+    const OptState *opt;  // optimizer state read by this step (advanced into its other copy by the k_adam_polyak launch that follows)
+    long long n_pi;       // elements below n_pi belong to the policy optimizer
+    float lr, b1, b2, eps, pk, pk1;
+    unsigned int noise_adv;
 };
 constexpr int MAX_GEMM_JOBS = 12;
 #ifdef DDRL_STAMPS
@@ -75,6 +96,7 @@ struct GemmJobs {
     int ks_max;   // deepest sub-chunk of any job in this launch (two-chunk loop): sizes the LDS tiles
     int op_lds;   // floats per operand tile = max(32 * (ks_max + 2), ks_max * 36, 32 * 36)
     int tile_start[MAX_GEMM_JOBS];  // flat copy: the job lookup is one scalar load, not a pointer chase
+    AdamCtx ad;
     GemmJob job[MAX_GEMM_JOBS];
 };
 
@@ -104,9 +126,17 @@ struct Seg {  // one tensor: dense external offset <-> padded internal offset
 struct OptState {  // device-resident Adam bookkeeping (running beta powers like TF's beta*_power)
     float b1p_pi, b2p_pi, b1p_q, b2p_q;
     long long t_pi, t_q;
-    unsigned int ticket_adam, pad;
+    unsigned int pad0, pad1;
     unsigned long long noise_ctr;
 };
+
+__device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, float &t, float omb1, float omb2, float al,
+                                      float eps, float pk, float pk1) {
+    m = m + (g - m) * omb1;
+    v = v + (g * g - v) * omb2;
+    p = p - (m * al) / (sqrtf(v) + eps);
+    t = pk * t + pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
+}
 
 // ------------------------------------------------------------------------------------------
 // K: layer 1 (K = obs_dim or obs_dim+act_dim: tiny) — VALU, threads along the output feature.
@@ -551,6 +581,24 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
         biasv[q] = jb.bias ? jb.bias[gjc] : 0.f;
         maskv[q] = jb.mask ? jb.mask[(long long)gic * jb.ldmask + gjc] : 1.f;
     }
+    // optimizer state of this tile's parameters (fused step): fetched now, used in the epilogue
+    const bool do_adam = jobs.ad.on && jb.adam_off >= 0 && !jb.part;  // block-uniform
+    float am[4], av[4], ap[4], at[4];
+    float al_pi = 0.f, al_q = 0.f;
+    if (jobs.ad.on) {
+        const float b1p_pi = jobs.ad.opt->b1p_pi, b2p_pi = jobs.ad.opt->b2p_pi, b1p_q = jobs.ad.opt->b1p_q, b2p_q = jobs.ad.opt->b2p_q;
+        al_pi = jobs.ad.lr * sqrtf(1.0f - b2p_pi) / (1.0f - b1p_pi);
+        al_q = jobs.ad.lr * sqrtf(1.0f - b2p_q) / (1.0f - b1p_q);
+    }
+    if (do_adam) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = tid + 256 * q;
+            const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+            const long long idx = okv[q] ? jb.adam_off + (long long)gi * jb.ldc + gj : 0;
+            am[q] = jobs.ad.m[idx]; av[q] = jobs.ad.v[idx]; ap[q] = jobs.ad.p[idx]; at[q] = jobs.ad.t[idx];
+        }
+    }
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -593,6 +641,12 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
         v = maskv[q] > 0.f ? v : 0.f;
         if (okv[q]) jb.C[(long long)gi * jb.ldc + gj] = v;
         outv[q] = okv[q] ? v : 0.f;
+        if (do_adam && okv[q]) {
+            const long long idx = jb.adam_off + (long long)gi * jb.ldc + gj;
+            const float al = idx < jobs.ad.n_pi ? al_pi : al_q;
+            adam1(v, am[q], av[q], ap[q], at[q], 1.0f - jobs.ad.b1, 1.0f - jobs.ad.b2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+            jobs.ad.m[idx] = am[q]; jobs.ad.v[idx] = av[q]; jobs.ad.p[idx] = ap[q]; jobs.ad.t[idx] = at[q];
+        }
     }
     if (jb.part) {  // block-uniform
         __syncthreads();
@@ -983,8 +1037,10 @@ __global__ void __launch_bounds__(64) k_rows_c(RowsC a) {
 struct AdamArgs {
     float *p, *t, *m, *v;
     float *g;
-    OptState *opt;
+    const OptState *opt;  // read ...
+    OptState *opt_next;   // ... and advanced into (by thread 0 of block 0)
     long long n, n_pi;
+    long long base4;      // first float4 element of this launch (0: the whole buffer)
     float lr, b1, b2, eps, pk, pk1;
     // fused pi layer-1 wgrad: gradient of float4 elements [part_off4, part_off4 + part_n4) is the sum of
     // `nparts` row-tile partials written by the pi dgrad tiles (k_gemm epilogue), summed in tile order
@@ -998,13 +1054,6 @@ struct AdamArgs {
     ddrl_replay_dev::RingPtrs ring;
     ddrl_replay_dev::BatchPtrs sout;
 };
-__device__ __forceinline__ void adam1(float g, float &m, float &v, float &p, float &t, float omb1, float omb2, float al,
-                                      float eps, float pk, float pk1) {
-    m = m + (g - m) * omb1;
-    v = v + (g * g - v) * omb2;
-    p = p - (m * al) / (sqrtf(v) + eps);
-    t = pk * t + pk1 * p;  // polyak with the post-update main (actor_learner.py:85-87)
-}
 __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     if (a.do_sample && (int)blockIdx.x == a.adam_blocks) {
         // Rides along: `idxs = np.random.randint(0, size, B)` + the five gathers of the NEXT update
@@ -1015,11 +1064,11 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
         return;
     }
     const long long n4 = a.n >> 2, npi4 = a.n_pi >> 2;  // both buffers are padded to multiples of 4
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // grid covers n4 exactly once
+    const long long i = a.base4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;  // grid covers [base4, n4) exactly once
     float4 *P = reinterpret_cast<float4 *>(a.p), *T = reinterpret_cast<float4 *>(a.t);
     float4 *M = reinterpret_cast<float4 *>(a.m), *V = reinterpret_cast<float4 *>(a.v);
     const float4 *G = reinterpret_cast<const float4 *>(a.g);
-    const long long ic = i < n4 ? i : 0;
+    const long long ic = i < n4 ? i : a.base4;
     const bool from_parts = a.nparts > 0 && i >= a.part_off4 && i < a.part_off4 + a.part_n4;
     float4 g = G[ic];  // all loads of the kernel issued together
     float4 m = M[ic], v = V[ic], p = P[ic], t = T[ic];
@@ -1050,15 +1099,12 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
         adam1(g.w, m.w, v.w, p.w, t.w, omb1, omb2, al, a.eps, a.pk, a.pk1);
         M[i] = m; V[i] = v; P[i] = p; T[i] = t;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned tk = atomicAdd(&a.opt->ticket_adam, 1u);
-        if (tk == (unsigned)a.adam_blocks - 1) {  // every Adam block has read the powers before taking its ticket
-            a.opt->b1p_pi = b1p_pi * a.b1; a.opt->b2p_pi = b2p_pi * a.b2; a.opt->b1p_q = b1p_q * a.b1; a.opt->b2p_q = b2p_q * a.b2;
-            a.opt->t_pi += 1; a.opt->t_q += 1;
-            a.opt->noise_ctr += a.noise_adv;
-            a.opt->ticket_adam = 0;
-        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // nobody reads the copy this writes
+        OptState n = *a.opt;
+        n.b1p_pi = b1p_pi * a.b1; n.b2p_pi = b2p_pi * a.b2; n.b1p_q = b1p_q * a.b1; n.b2p_q = b2p_q * a.b2;
+        n.t_pi += 1; n.t_q += 1;
+        n.noise_ctr += a.noise_adv;
+        *a.opt_next = n;
     }
 }
 
@@ -1220,6 +1266,7 @@ static void set_fast(GemmJob &j) {
 // H2 = relu(H1 * W2 + b2)
 static GemmJob gemm_fwd(const float *H1, int ldh1, const float *W2, const float *b2, float *H2, int ldh2, int rows, int h1, int h2) {
     GemmJob j{};
+    j.adam_off = -1;
     j.A = H1; j.B = W2; j.C = H2; j.bias = b2; j.mask = nullptr;
     j.M = rows; j.N = h2; j.K = h1; j.lda = ldh1; j.ldb = h2; j.ldc = ldh2; j.ldmask = 0; j.a_kc = 1; j.b_kc = 0; j.relu = 1;
     set_fast(j);
@@ -1228,6 +1275,7 @@ static GemmJob gemm_fwd(const float *H1, int ldh1, const float *W2, const float 
 // dZ1 = (dZ2 * W2^T) .* (H1 > 0)
 static GemmJob gemm_dgrad(const float *dZ2, const float *W2, const float *H1mask, int ldh1, float *dZ1, int rows, int h1, int h2) {
     GemmJob j{};
+    j.adam_off = -1;
     j.A = dZ2; j.B = W2; j.C = dZ1; j.bias = nullptr; j.mask = H1mask;
     j.M = rows; j.N = h1; j.K = h2; j.lda = h2; j.ldb = h2; j.ldc = h1; j.ldmask = ldh1; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
     set_fast(j);
@@ -1237,6 +1285,7 @@ static GemmJob gemm_dgrad(const float *dZ2, const float *W2, const float *H1mask
 // (row stride ldz) -> C[(nin+1), nout] (row stride ldc); the kernel's bias lives right behind it.
 static GemmJob gemm_wgrad(const float *X, int ldx, int nin, const float *dZ, int ldz, int nout, float *C, int ldc, int rows) {
     GemmJob j{};
+    j.adam_off = -1;
     j.A = X; j.B = dZ; j.C = C; j.bias = nullptr; j.mask = nullptr;
     j.M = nin + 1; j.N = nout; j.K = rows; j.lda = ldx; j.ldb = ldz; j.ldc = ldc; j.ldmask = 0; j.a_kc = 0; j.b_kc = 0; j.relu = 0;
     set_fast(j);
@@ -1282,7 +1331,8 @@ struct ddrl_sac1 {
     float *H1, *H2, *dZ2, *dZ1, *xa, *xp, *part;
     float *act0, *act2, *logp0, *logp1, *save0, *q1o, *q2o, *dq4, *dhead, *loss_part, *losses;
     int ldh1, ldh2, ldxa, ldxp, ldd;
-    OptState *opt;
+    OptState *opt;       // two copies; opt + opt_cur is current, every optimizer step advances into the other one
+    int opt_cur;
     Seg *segs_d;
     L1Jobs l1a[2];
     GemmJobs g_fa, g_fb, g_bq, g_bpi, g_last;
@@ -1294,8 +1344,15 @@ struct ddrl_sac1 {
     bool fused;          // fused forward stages (sac1_fused.h) instead of k_l1 / k_gemm / k_rows_a
     FwdArgs f_a[2], f_b[2];
     BqArgs bq[2];
+    bool fuse_apply;     // this launch_grads also applies the optimizer (Adam in the wgrad epilogues)
+    // sampler riding in k_fwd<1> (ddrl_sac1_step_and_sample)
+    bool sample_armed;
+    ddrl_replay_dev::RingState *smp_rs;
+    ddrl_replay_dev::RingPtrs smp_ring;
+    int smp_set;
     GemmJobs g_bpi_f;    // fused path: the policy backward launch also carries the Q layer-2/head wgrads
     float *hp;           // head partials [NEVAL][FH][nt2][B]
+    float *w2snap;       // fused path: this update's copy of the policy W2 (read by the policy dgrad)
     bool fused_l1_wgrad;  // pi layer-1 wgrad via dgrad-epilogue partials + Adam (needs hidden1 % 4 == 0)
     // set by ddrl_sac1_fill_noise, consumed by the next compute_grads / apply_grads
     bool noise_armed;
@@ -1314,6 +1371,7 @@ static int reset_opt(ddrl_sac1 *h, hipStream_t s) {
     OptState o{};
     o.b1p_pi = o.b1p_q = (float)h->cfg.beta1;
     o.b2p_pi = o.b2p_q = (float)h->cfg.beta2;
+    h->opt_cur = 0;
     DDRL_HIP_CHECK(hipMemcpyAsync(h->opt, &o, sizeof(o), hipMemcpyHostToDevice, s));
     DDRL_HIP_CHECK(hipStreamSynchronize(s));
     return DDRL_OK;
@@ -1369,8 +1427,9 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     ALLOC(loss_part, (size_t)h->rows_b_blocks * 3); ALLOC(losses, 4);
     const int nt2 = (h2 + 31) / 32;
     ALLOC(hp, (size_t)NEVAL * FH * nt2 * B);
+    ALLOC(w2snap, (size_t)h1 * h2 + 64);
 #undef ALLOC
-    const size_t opt_off = reserve((sizeof(OptState) + 3) / 4);
+    const size_t opt_off = reserve((2 * sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((L.segs.size() * sizeof(Seg) + 3) / 4);
     (void)reserve(2048);  // readable guard behind the last buffer (unclamped tile loads, see OpPre)
     hipError_t e = hipMalloc((void **)&h->slab, slab_floats * sizeof(float));
@@ -1498,7 +1557,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         };
         FwdArgs &FA = h->f_a[st], &FB = h->f_b[st];
         base(FA, 5);
-        FA.job[0] = pij(Pm, x, 0, true);   FA.job[0].aug = h->xp; FA.job[0].aug_ld = h->ldxp;
+        FA.job[0] = pij(Pm, x, 0, true);   FA.job[0].aug = h->xp; FA.job[0].aug_ld = h->ldxp; FA.job[0].w2snap = h->w2snap;
         FA.job[1] = pij(Pm, x2, 1, false);
         FA.job[2] = pij(Pt, x2, 2, false);
         FA.job[3] = qj(Pm, 0, x, ac, 3, true); FA.job[3].aug = h->xa; FA.job[3].aug_ld = h->ldxa;
@@ -1543,6 +1602,16 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             gemm_add(h->g_bpi_f, gemm_wgrad(h->H1 + (3 + q) * BH1, ldh1, h1, h->dZ2 + q * BZ2, h2, h2, G + L.q_W2[q], h2, B));
             gemm_add(h->g_bpi_f, gemm_wgrad(h->H2 + (3 + q) * BH2, ldh2, h2, h->dq4 + (long long)q * B * 4, 4, 1, G + L.q_W3[q], 1, B));
         }
+        GemmJobs &J = h->g_bpi_f;
+        DDRL_REQUIRE(J.job[0].B == Pm + L.pi_W2 && J.job[0].part != nullptr, "internal: job 0 of the policy backward launch must be the pi dgrad");
+        J.job[0].B = h->w2snap;  // the wgrad tiles of this launch update pi W2 in place: read this update's copy instead
+        for (int i = 0; i < J.njobs; ++i) {
+            GemmJob &j = J.job[i];
+            if (!j.part && j.C >= G && j.C < G + L.total_int) j.adam_off = j.C - G;  // wgrads write straight into the gradient buffer
+        }
+        J.ad = AdamCtx{0, h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, L.n_pi_int,
+                       (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
+                       (float)cfg->polyak, (float)(1.0 - cfg->polyak), 0u};
     }
 
     // ---- row kernels
@@ -1559,12 +1628,13 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 3 * BZ2,
                   h->loss_part, h->losses, B, h1, h2, ldh2, o, a, h->ldd, h->rows_b_blocks, (float)cfg->alpha,
                   (float)cfg->act_scale};
-    h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, L.total_int, L.n_pi_int,
+    h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, L.total_int, L.n_pi_int, 0,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak),
                      h->part, L.pi_W1 / 4, (long long)(o + 1) * h1 / 4, (long long)(o + 1) * h1 / 4,
                      h->fused_l1_wgrad ? (B + 31) / 32 : 0, 0u};
     h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
+    h->fuse_apply = false; h->sample_armed = false;
     *out = h;
     return DDRL_OK;
 }
@@ -1631,7 +1701,7 @@ int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *s
     ddrl::DeviceGuard g(h->device);
     OptState o;
     hipStream_t s = ddrl::as_stream(stream);
-    DDRL_HIP_CHECK(hipMemcpyAsync(&o, h->opt, sizeof(o), hipMemcpyDeviceToHost, s));
+    DDRL_HIP_CHECK(hipMemcpyAsync(&o, h->opt + h->opt_cur, sizeof(o), hipMemcpyDeviceToHost, s));
     DDRL_HIP_CHECK(hipStreamSynchronize(s));
     if (t_pi_h) *t_pi_h = o.t_pi;
     if (t_q_h) *t_q_h = o.t_q;
@@ -1645,19 +1715,45 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
     if (h->fused && stage <= 5) {
         switch (stage) {
-            case 2: launch_fwd<0>(h->f_a[st], s); break;
-            case 5: launch_fwd<1>(h->f_b[st], s); break;
+            case 2: h->f_a[st].opt = h->opt + h->opt_cur; launch_fwd<0>(h->f_a[st], s); break;
+            case 5: {
+                FwdArgs &F = h->f_b[st];
+                F.do_sample = h->sample_armed ? 1 : 0;
+                if (h->sample_armed) {
+                    F.rs = h->smp_rs; F.ring = h->smp_ring; F.sample_batch = h->cfg.batch;
+                    float **b = h->in[h->smp_set];
+                    F.sout = ddrl_replay_dev::BatchPtrs{{b[0], b[1], b[2], b[3], b[4], nullptr}};
+                }
+                launch_fwd<1>(F, s);
+                break;
+            }
             default: break;  // 1, 3: folded into the fused forward kernels
         }
         return;
     }
     if (h->fused && (stage == 6 || stage == 7 || stage == 9)) {
         if (stage == 7) launch_bwdq(h->bq[st], s);  // 6 (k_rows_b) is folded into it
-        if (stage == 9) k_gemm<<<h->g_bpi_f.total_tiles, 256, gemm_smem(h->g_bpi_f), s>>>(h->g_bpi_f);
+        if (stage == 9) {
+            GemmJobs &J = h->g_bpi_f;
+            J.ad.on = h->fuse_apply ? 1 : 0;
+            J.ad.noise_adv = h->noise_pending;
+            J.ad.opt = h->opt + h->opt_cur;
+            k_gemm<<<J.total_tiles, 256, gemm_smem(J), s>>>(J);
+            if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
+                AdamArgs A = h->ad;
+                A.base4 = A.part_off4; A.n = (A.part_off4 + A.part_n4) * 4;
+                A.opt = h->opt + h->opt_cur; A.opt_next = h->opt + (h->opt_cur ^ 1);
+                A.noise_adv = h->noise_pending;
+                A.do_sample = 0;
+                A.adam_blocks = (int)((A.part_n4 + 255) / 256);
+                k_adam_polyak<<<A.adam_blocks, 256, 0, s>>>(A);
+                h->opt_cur ^= 1;
+            }
+        }
         return;
     }
     switch (stage) {
-        case 1: k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
+        case 1: h->l1a[st].opt = h->opt + h->opt_cur; k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
         case 2: k_gemm<<<h->g_fa.total_tiles, 256, gemm_smem(h->g_fa), s>>>(h->g_fa); break;
         case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]); break;
         case 5: k_gemm<<<h->g_fb.total_tiles, 256, gemm_smem(h->g_fb), s>>>(h->g_fb); break;
@@ -1669,6 +1765,8 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
         case 11: {
             const long long blocks = (h->L.total_int / 4 + 255) / 256;
             h->ad.adam_blocks = (int)blocks;
+            h->ad.opt = h->opt + h->opt_cur; h->ad.opt_next = h->opt + (h->opt_cur ^ 1);
+            h->opt_cur ^= 1;
             k_adam_polyak<<<(unsigned)(blocks + (h->ad.do_sample ? 1 : 0)), 256, 0, s>>>(h->ad);
             break;
         }
@@ -1704,6 +1802,7 @@ static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, cons
     h->grad_imported = false;
     for (int stage = 1; stage <= 10; ++stage) launch_stage(h, stage, st, s);
     DDRL_LAUNCH_CHECK();
+    if (h->fuse_apply) h->noise_pending = 0;  // consumed by the optimizer bookkeeping of the last stage
     if (losses_d) DDRL_HIP_CHECK(hipMemcpyAsync(losses_d, h->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (q1_d || q2_d || logp_d) {
         k_copy3<<<(B + 255) / 256, 256, 0, s>>>(h->q1o, h->q2o, h->logp0, q1_d, q2_d, logp_d, B);
@@ -1806,10 +1905,54 @@ int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int 
 int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
                    const float *done_d, const float *eps_x_d, const float *eps_x2_d, const float *eps_t_d,
                    float *losses_d, float *q1_d, float *q2_d, float *logp_pi_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    // fused path: the optimizer runs in the epilogues of the last GEMM launch — no Adam kernel
+    h->fuse_apply = h->fused;
     int rc = ddrl_sac1_compute_grads(h, obs1_d, obs2_d, acts_d, rews_d, done_d, eps_x_d, eps_x2_d, eps_t_d, losses_d,
                                      q1_d, q2_d, logp_pi_d, stream);
-    if (rc != DDRL_OK) return rc;
+    const bool applied = h->fuse_apply;
+    h->fuse_apply = false;
+    if (rc != DDRL_OK || applied) return rc;
     return ddrl_sac1_apply_grads(h, stream);
+}
+
+}  // extern "C"
+
+__global__ void k_opt_copy(const OptState *src, OptState *dst) { *dst = *src; }
+
+// Internal (loop.hip): make copy 0 of the double-buffered optimizer state the current one, so that a
+// captured graph starts and ends on the same copy whatever the number of updates it holds.
+int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    if (h->opt_cur == 0) return DDRL_OK;
+    ddrl::DeviceGuard g(h->device);
+    k_opt_copy<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->opt + 1, h->opt);
+    DDRL_LAUNCH_CHECK();
+    h->opt_cur = 0;
+    return DDRL_OK;
+}
+
+extern "C" {
+
+int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream) {
+    DDRL_REQUIRE(h != nullptr && replay != nullptr && (set_in == 0 || set_in == 1) && (set_out == 0 || set_out == 1) && set_in != set_out,
+                 "NULL pointer, or input sets not {0,1} / not distinct");
+    ddrl::DeviceGuard g(h->device);
+    float **b = h->in[set_in];
+    if (!h->fused || !ddrl_replay_can_fuse(replay, h->cfg.batch)) {  // generic kernels: sampler beside the Adam kernel (or on its own)
+        int rc = ddrl_sac1_compute_grads(h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr, stream);
+        if (rc != DDRL_OK) return rc;
+        return ddrl_sac1_apply_grads_and_sample(h, replay, set_out, stream);
+    }
+    const ddrl_replay_dev::SamplerView v = ddrl_replay_sampler_view(replay);
+    DDRL_REQUIRE(v.ring.n_arr == 5 && v.ring.w[0] == h->cfg.obs_dim && v.ring.w[1] == h->cfg.obs_dim && v.ring.w[2] == h->cfg.act_dim &&
+                     v.ring.w[3] == 1 && v.ring.w[4] == 1,
+                 "replay row shape differs from the learner's (obs1, obs2, acts, rews, done)");
+    h->sample_armed = true; h->smp_rs = v.state; h->smp_ring = v.ring; h->smp_set = set_out;
+    const int rc = ddrl_sac1_step(h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr, stream);
+    h->sample_armed = false;
+    if (rc == DDRL_OK) ddrl_replay_note_sample(replay);
+    return rc;
 }
 
 }  // extern "C"

@@ -34,6 +34,8 @@ struct FwdJob {
     float *H1;               // side output of the n-tile-0 workgroups: X1 rows [B][ldh1] (nullptr: not needed later)
     float *aug;              // side output of the n-tile-0 workgroups: [in0 | in1] rows with row stride aug_ld (ones column is physical)
     int aug_ld;
+    float *w2snap;           // side output of the m-tile-0 workgroups: a copy of W2 as read by this update (see k_gemm's fused
+                             // optimizer step: the policy dgrad must not read W2 while the wgrad tiles update it in place)
     const float *wh0, *wh1;  // head kernels — policy: Wmu, Wls ([h2][act]); Q: W3 ([h2]), unused
     int nh, hsplit, hstride; // heads; heads < hsplit come from wh0, the rest from wh1; element stride between rows of a head kernel
     float *hp;               // head partials [nh][nt2][B]
@@ -65,6 +67,13 @@ struct FwdArgs {
     uint32_t noise_seed;
     float *e0, *e1, *e2;
     const OptState *opt;
+    // phase 1, optional: one extra workgroup draws the NEXT update's batch (np.random.randint + the five
+    // gathers, example/dsac.py:39-45) into the learner's other input set — phase 1 has idle CUs
+    // (240 tiles on 256) and nothing in this update touches that set or the sampler state
+    int do_sample, sample_batch;
+    ddrl_replay_dev::RingState *rs;
+    ddrl_replay_dev::RingPtrs ring;
+    ddrl_replay_dev::BatchPtrs sout;
     FwdJob job[5];
 #ifdef DDRL_STAMPS
     long long *stamps;
@@ -126,6 +135,10 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
     __shared__ __attribute__((aligned(16))) float s_in[FD][32];  // transposed input tile: [input column][row]
     __shared__ float s_wh[FH][32];
     __shared__ float s_hd[2][FH][32];
+    if (PH == 1 && (int)blockIdx.x == 3 * tpj) {  // only launched when a.do_sample
+        ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
+        return;
+    }
 #ifdef DDRL_STAMPS
     long long *st = (a.stamps && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) ? a.stamps + (long long)blockIdx.x * 32 : nullptr;
     STAMP(0);
@@ -346,6 +359,12 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
     if (32 < ks_b) l1_block(av, wb[3], D, xb1);
     STAMP(3);
     ob.store(sB, ks_a, kcs, lane, pb);
+    float *snap = (jb.w2snap && m0 == 0 && ob.okc[0]) ? jb.w2snap + (long long)k0 * H2N + n0 + (lane & 7) * 4 : nullptr;
+    if (snap) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (ob.krow[i] < ks_a) *reinterpret_cast<float4 *>(snap + (long long)ob.krow[i] * H2N) = pb[i];
+    }
     if (ks_b > 0) ob.load(1, ks_a, ks_b, H2N, pb);
     wave_lds_sync();
     STAMP(4);
@@ -357,6 +376,11 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
         put(xb1, 1, ks_b, k0 + 64);
         STAMP(6);
         ob.store(sB, ks_b, kcs, lane, pb);
+        if (snap) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (ob.krow[i] < ks_b) *reinterpret_cast<float4 *>(snap + (long long)(ks_a + ob.krow[i]) * H2N) = pb[i];
+        }
         wave_lds_sync();
         STAMP(7);
         mfma_chunk<true, false>(sA, sB, ks_b, kcs, l31, h, acc);
@@ -414,7 +438,7 @@ static size_t fwd_smem(const FwdArgs &a) {
 template <int PH>
 static void launch_fwd(const FwdArgs &F, hipStream_t s) {
     const FwdHead &d = F.hd;
-    k_fwd<PH><<<F.njobs * d.tpj, 256, fwd_smem(F), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.w2_off[0], d.w2_off[1], d.w2_off[2], d.w2_off[3],
+    k_fwd<PH><<<F.njobs * d.tpj + ((PH == 1 && F.do_sample) ? 1 : 0), 256, fwd_smem(F), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.w2_off[0], d.w2_off[1], d.w2_off[2], d.w2_off[3],
                                                         d.w2_off[4], d.w1_off[0], d.w1_off[1], d.w1_off[2], d.w1_off[3], d.w1_off[4], F);
 }
 

@@ -217,6 +217,12 @@ int ddrl_sac1_apply_grads(ddrl_sac1_t *h, void *stream);
  * extra workgroup of the Adam/polyak kernel instead of as a kernel of its own (it writes an input
  * set the Adam kernel does not touch).  Same results, same MT19937 stream, same counters. */
 int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int set, void *stream);
+/* One whole update from input set `set_in` (noise as armed by ddrl_sac1_fill_noise) AND the next
+ * update's sample_batch (example/dsac.py:39-45: np.random.randint + five gathers) into set `set_out`,
+ * i.e. Learner.train of update u plus `ray.get(replay_buffer.sample_batch.remote())` of update u+1
+ * (actor_learner.py:135-142).  On the fused path the sampler rides in a forward launch and the
+ * optimizer in the last backward launch; otherwise == compute_grads + apply_grads_and_sample. */
+int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream);
 
 /* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
  * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of
