@@ -524,7 +524,12 @@ __device__ __forceinline__ void gemm_kloop(const GemmJob &jb, float *sA, float *
     }
 }
 
-__global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
+// Leading scalar arguments (total tiles, the flat tile_start table) are preloaded into SGPRs at wave
+// launch; fields of the by-value struct behind them are s_load'ed from the kernarg segment, cold after
+// every kernel boundary — with everything in the struct the ISA showed three dependent round trips
+// (gridDim, tile_start, job record) before the first vector load; now it is one (the job record).
+__global__ void __launch_bounds__(256) k_gemm(int total_tiles, int ts1, int ts2, int ts3, int ts4, int ts5, int ts6, int ts7, int ts8, int ts9,
+                                              int ts10, int ts11, GemmJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x (A tile, B tile) of jobs.op_lds floats; reused for the split-K combine
     // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, whose L2s
     // are private and cold after every kernel boundary.  Give each XCD a CONTIGUOUS run of tiles,
@@ -535,11 +540,12 @@ __global__ void __launch_bounds__(256) k_gemm(GemmJobs jobs) {
     // W2 / dZ panel and an activation matrix are fetched by one or two L2s instead of all eight.
     int t, ji = 0;
     {
-        const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
-#pragma unroll
-    for (int i = 1; i < MAX_GEMM_JOBS; ++i) ji += (t >= jobs.tile_start[i]) ? 1 : 0;
+    static_assert(MAX_GEMM_JOBS == 12, "k_gemm takes tile_start[1..11] as scalar arguments");
+    ji = (t >= ts1) + (t >= ts2) + (t >= ts3) + (t >= ts4) + (t >= ts5) + (t >= ts6) + (t >= ts7) + (t >= ts8) + (t >= ts9) + (t >= ts10) +
+         (t >= ts11);
     const GemmJob &jb = jobs.job[ji];
     t -= jb.tile_start;
     const int tiles_m = jb.ntiles / jb.tiles_n;
@@ -923,9 +929,9 @@ struct RowsC {
     int B, h1, h2, ldh2, obs, act, ldd, loss_blocks;
     float alpha, scale;
 };
-__global__ void __launch_bounds__(64) k_rows_c(RowsC a) {
+__global__ void __launch_bounds__(64) k_rows_c(int nrows, RowsC a) {
     const int lane = threadIdx.x;
-    if (blockIdx.x == gridDim.x - 1) {
+    if ((int)blockIdx.x == nrows) {  // (gridDim is a hidden-argument load)
         // reduce_mean over the batch: the extra last workgroup sums the per-row terms of k_rows_b in
         // a fixed order (lane-strided partial sums, then the xor-shuffle tree)
         const int ln = lane;
@@ -1232,6 +1238,11 @@ static NetQ net_q(const float *base, const Layout &L, int q) {
     return NetQ{base + L.q_W1[q], base + L.q_b1[q], base + L.q_W2[q], base + L.q_b2[q], base + L.q_W3[q], base + L.q_b3[q]};
 }
 
+static size_t gemm_smem(const GemmJobs &js);
+static void launch_gemm(const GemmJobs &J, hipStream_t s) {
+    const int *ts = J.tile_start;
+    k_gemm<<<J.total_tiles, 256, gemm_smem(J), s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], ts[8], ts[9], ts[10], ts[11], J);
+}
 static size_t gemm_smem(const GemmJobs &js) {
     const size_t a = (size_t)4 * 2 * js.op_lds * sizeof(float), b = (size_t)RED_LDS * sizeof(float);
     return a > b ? a : b;
@@ -1738,7 +1749,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
             J.ad.on = h->fuse_apply ? 1 : 0;
             J.ad.noise_adv = h->noise_pending;
             J.ad.opt = h->opt + h->opt_cur;
-            k_gemm<<<J.total_tiles, 256, gemm_smem(J), s>>>(J);
+            launch_gemm(J, s);
             if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
                 AdamArgs A = h->ad;
                 A.base4 = A.part_off4; A.n = (A.part_off4 + A.part_n4) * 4;
@@ -1754,14 +1765,14 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     }
     switch (stage) {
         case 1: h->l1a[st].opt = h->opt + h->opt_cur; k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
-        case 2: k_gemm<<<h->g_fa.total_tiles, 256, gemm_smem(h->g_fa), s>>>(h->g_fa); break;
+        case 2: launch_gemm(h->g_fa, s); break;
         case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]); break;
-        case 5: k_gemm<<<h->g_fb.total_tiles, 256, gemm_smem(h->g_fb), s>>>(h->g_fb); break;
+        case 5: launch_gemm(h->g_fb, s); break;
         case 6: k_rows_b<<<h->cfg.batch, 64, 0, s>>>(h->rb[st]); break;
-        case 7: k_gemm<<<h->g_bq.total_tiles, 256, gemm_smem(h->g_bq), s>>>(h->g_bq); break;
-        case 8: k_rows_c<<<B + 1, 64, 0, s>>>(h->rc); break;  // +1: the loss-reduction workgroup
-        case 9: k_gemm<<<h->g_bpi.total_tiles, 256, gemm_smem(h->g_bpi), s>>>(h->g_bpi); break;
-        case 10: if (h->g_last.total_tiles > 0) k_gemm<<<h->g_last.total_tiles, 256, gemm_smem(h->g_last), s>>>(h->g_last); break;
+        case 7: launch_gemm(h->g_bq, s); break;
+        case 8: k_rows_c<<<B + 1, 64, 0, s>>>(B, h->rc); break;  // +1: the loss-reduction workgroup
+        case 9: launch_gemm(h->g_bpi, s); break;
+        case 10: if (h->g_last.total_tiles > 0) launch_gemm(h->g_last, s); break;
         case 11: {
             const long long blocks = (h->L.total_int / 4 + 255) / 256;
             h->ad.adam_blocks = (int)blocks;
@@ -2038,7 +2049,7 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     k_l1<<<dim3((c.hidden1 + 255) / 256, (unsigned)((n + L1_ROWS - 1) / L1_ROWS), 1), 256, 0, s>>>(l1);
     GemmJobs gj{};
     gemm_add(gj, gemm_fwd(h->H1, h->ldh1, h->pi_p + L.pi_W2, h->pi_p + L.pi_b2, h->H2, h->ldh2, (int)n, c.hidden1, c.hidden2));
-    k_gemm<<<gj.total_tiles, 256, gemm_smem(gj), s>>>(gj);
+    launch_gemm(gj, s);
     ActArgs aa{h->H2, net_pi(h->pi_p, L), eps_d, act_d, (int)n, c.hidden2, h->ldh2, c.act_dim, deterministic, (float)c.act_scale};
     k_rows_act<<<(unsigned)((n + 3) / 4), 256, 0, s>>>(aa);
     DDRL_LAUNCH_CHECK();

@@ -16,14 +16,14 @@ int main() {
     hipMalloc(&stamps, (size_t)js.total_tiles * 32 * 8); hipMemset(stamps, 0, (size_t)js.total_tiles * 32 * 8);
     js.stamps = nullptr;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) { k_touch<<<2048, 256>>>(H1, NE * B * ldh1); k_gemm<<<js.total_tiles, 256, gemm_smem(js)>>>(js); }
+    for (int i = 0; i < 5; ++i) { k_touch<<<2048, 256>>>(H1, NE * B * ldh1); launch_gemm(js, nullptr); }
     hipDeviceSynchronize();
     float ms;
-    hipEventRecord(e0); for (int i = 0; i < 100; ++i) k_gemm<<<js.total_tiles, 256, gemm_smem(js)>>>(js); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventRecord(e0); for (int i = 0; i < 100; ++i) launch_gemm(js, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1); printf("k_gemm back-to-back: %.2f us/launch\n", ms * 10.f);
     js.stamps = stamps;
     k_touch<<<2048, 256>>>(H1, NE * B * ldh1);
-    k_gemm<<<js.total_tiles, 256, gemm_smem(js)>>>(js); hipDeviceSynchronize();
+    launch_gemm(js, nullptr); hipDeviceSynchronize();
     std::vector<long long> hs((size_t)js.total_tiles * 32);
     hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
     long long tmin = hs[0];
