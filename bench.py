@@ -23,8 +23,9 @@ deterministic last-writer-wins).  `--dp-learners` instead all-reduces the gradie
 (BASELINE config 4 semantics).
 
 Prints ONE JSON line on rank 0.  `value` = whole-job env-steps/s; `updates_per_s` rides along.
-`roofline` prices the dominant kernel (k_gemm: the fp32-MFMA fc GEMMs, 97 % of an update's FLOPs)
-from HIP-event stage timings taken right after the timed region; `cpu_baseline` times the oracle
+`roofline` prices the four MFMA stage launches of an update (k_fwd<0>, k_fwd<1>, k_bwdq, k_gemm: layer 1
+on the matrix cores + the fc GEMMs + the fused head / loss / optimizer epilogues = all of an update's
+network FLOPs) from HIP-event stage timings taken right after the timed region; `cpu_baseline` times the oracle
 (CPU restatement of the reference path) on this box's host cores for a bounded sample.
 """
 import argparse
@@ -229,10 +230,12 @@ def main():
     for st in range(1, 11):   # idempotent stages, `stage_samples` back-to-back launches between two HIP events
         _lib.check(lib.ddrl_sac1_stage_time(trainer.agent._h, st, args.stage_samples, ctypes.byref(ms), _lib.stream_ptr()))
         stage[st] = ms.value
-    gemm_ms = [stage[i] for i in (2, 5, 7, 9)]   # the four large k_gemm launches of one update
+    gemm_ms = [stage[i] for i in (2, 5, 7, 9)]   # the four MFMA stage launches of one update
     gemm_launch_s = float(np.mean(gemm_ms)) * 1e-3
-    gf = gemm_flops_per_update(**cfgd)
-    achieved = gf / 4.0 / gemm_launch_s / 1e12   # the tiny pi layer-1 wgrad launch (stage 10) is not counted
+    # algorithmic FLOPs per launch = SURVEY §8(d)'s per-update figure / 4 launches (on the fused path the
+    # launches also carry layer 1, the heads, the losses and the optimizer step: nothing else computes)
+    gf = update_flops(**cfgd)
+    achieved = gf / 4.0 / gemm_launch_s / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -240,7 +243,7 @@ def main():
             traffic = json.load(open(tpath)).get("k_gemm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "k_gemm (fp32 MFMA fc GEMMs: 4 launches/update)", "bound": "mfma",
+    roofline = {"kernel": "MFMA stage launches k_fwd<0> / k_fwd<1> / k_bwdq / k_gemm (4 per update, fp32 MFMA)", "bound": "mfma",
                 "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "flops_per_launch": gf / 4.0, "avg_launch_us": gemm_launch_s * 1e6,
