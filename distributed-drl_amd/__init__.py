@@ -27,7 +27,7 @@ def __getattr__(name):
         "VecLunarLander": "env",
         "worker_rollout": "workers", "worker_train": "workers", "worker_test": "workers",
         "worker_rollout_sac1": "workers", "worker_train_sac1": "workers",
-        "RolloutDevice": "workers", "TrainDevice": "workers",
+        "RolloutDevice": "workers", "TrainDevice": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers",
     }
     if name in table:
         return getattr(importlib.import_module("." + table[name], __name__), name)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ddrl_replay_gather": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ddrl_replay_create_ex": (c_int, [POINTER(_P), c_int, c_int64, c_int32, POINTER(c_int32), c_int64, c_int64]),
     "ddrl_replay_store_ex": (c_int, [_P, POINTER(_P), c_int64, _P]),
+    "ddrl_replay_store_masked_ex": (c_int, [_P, POINTER(_P), _P, c_int64, _P]),
     "ddrl_replay_sample_ex": (c_int, [_P, c_int64, POINTER(_P), _P, _P]),
     "ddrl_replay_gather_ex": (c_int, [_P, _P, c_int64, POINTER(_P), _P]),
     "ddrl_replay_buffers_ex": (c_int, [_P, POINTER(_P), POINTER(c_int32), POINTER(c_int32)]),
@@ -92,9 +93,15 @@ SIGNATURES = {
     "ddrl_env_destroy": (c_int, [_P]),
     "ddrl_env_reset": (c_int, [_P, _P, _P, _P]),
     "ddrl_env_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "ddrl_env_step_wrapped": (c_int, [_P, _P, c_float, c_float, c_float, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "ddrl_env_stats": (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), _P]),
     "ddrl_env_get_state": (c_int, [_P, _P, _P]),
     "ddrl_env_set_state": (c_int, [_P, _P, _P]),
+    "ddrl_winq_create": (c_int, [POINTER(_P), c_int, c_int64, c_int32, c_int32, c_int32, c_int32]),
+    "ddrl_winq_destroy": (c_int, [_P]),
+    "ddrl_winq_begin": (c_int, [_P, _P, _P, _P]),
+    "ddrl_winq_push": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "ddrl_winq_buffers": (c_int, [_P, POINTER(_P), POINTER(_P)]),
     "ddrl_normal_fill": (c_int, [_P, c_int64, c_uint32, c_uint64, _P]),
     "ddrl_uniform_fill": (c_int, [_P, c_int64, c_float, c_float, c_uint32, c_uint64, _P]),
 }

@@ -75,6 +75,10 @@ class HyperParameters:
         self.max_ep_len = 2900
         self.seed = 0
         self.push_freq = 300  # sac1.py:149
+        # n-step driver (algos/sac1/sac_ray.py) entries: hyperparams.py:40-42, 84-88
+        self.obs_noise, self.act_noise, self.reward_scale = 0, 0.3, 5
+        self.Ln, self.action_repeat, self.save_freq = 8, 2, 1
+        self.obs_shape, self.act_shape = (obs_dim,), (act_dim,)
         self.num_envs = 1     # vectorised rollouts: envs stepped together by one worker
 
     def config(self, batch=None):

@@ -277,6 +277,80 @@ __global__ void __launch_bounds__(256) k_env_step(float *S, long long n, uint32_
     }
 }
 
+// `Wrapper(env, obs_noise, act_noise, reward_scale, action_repeat)` of algos/sac1/hyperparams.py:107-134
+// around env.step, plus the n-step rollout's episode bookkeeping (algos/sac1/sac_ray.py:212-216,
+// 238-258: ep_len counts WRAPPED steps, the episode ends on d or ep_len >= limit_steps, the stored
+// done is the raw d).  The wrapper's np.random.random noise is the env's counter generator
+// (slots 2.. of the per-step stream; a stream of its own for the reset observation).
+constexpr uint32_t RESET_NOISE_STREAM = 0xFFFFFFEFu;
+__global__ void __launch_bounds__(256) k_env_step_wrapped(float *S, long long n, uint32_t seed, float limit_steps, const float *act,
+                                                          float act_noise, float obs_noise, float reward_scale, int repeat,
+                                                          float *obs2, float *rew_out, float *done_out, float *next_obs,
+                                                          uint8_t *ended_out, EnvStats *stats) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n_end = 0, len_end = 0;
+    double ret_end = 0.0;
+    if (i < n) {
+        Env e;
+        e.seed = seed; e.id = (uint32_t)i;
+        e.load(S, n, i);
+        float o[8];
+        bool done_env = false;
+        const uint32_t st0 = (uint32_t)e.pstep;
+        const float2 a = *reinterpret_cast<const float2 *>(act + i * 2);
+        const float a0 = a.x + act_noise * (-2.0f * e.rng(st0, 2) + 1.0f);   // hyperparams.py:124
+        const float a1 = a.y + act_noise * (-2.0f * e.rng(st0, 3) + 1.0f);
+        float r = 0.0f, rew = 0.0f;
+        bool noisy = true;
+        for (int k = 0; k < repeat; ++k) {                                    // :126-133
+            const float rk = e.physics(a0, a1, done_env, o);
+            r = r + rk;
+            if (done_env && repeat != 1) { rew = 0.0f; break; }               // :130-131 (the reward is dropped)
+            if (repeat == 1) { rew = r; noisy = false; break; }               // :132-133 (no noise, no scale)
+            rew = reward_scale * r;                                           // :134 when the loop runs out
+        }
+        if (noisy) {
+            const uint32_t st1 = (uint32_t)e.pstep;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = o[j] + obs_noise * (-2.0f * e.rng(st1, 4 + j) + 1.0f);
+        }
+        e.eplen = e.eplen + 1.0f;                                             // sac_ray.py:216
+        e.epret = e.epret + rew;                                              // :215
+        const bool ended = done_env || e.eplen >= limit_steps;                // :252
+        if (obs2) {
+            float4 *p = reinterpret_cast<float4 *>(obs2 + i * 8);
+            p[0] = make_float4(o[0], o[1], o[2], o[3]);
+            p[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (rew_out) rew_out[i] = rew;
+        if (done_out) done_out[i] = done_env ? 1.0f : 0.0f;                   // raw d (the time-limit override is commented out, :221)
+        if (ended_out) ended_out[i] = ended ? 1 : 0;
+        if (ended) {
+            n_end = 1; len_end = (long long)e.eplen; ret_end = (double)e.epret;
+            e.epi = e.epi + 1.0f;
+            e.reset(o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = o[j] + obs_noise * (-2.0f * e.rng(RESET_NOISE_STREAM, j) + 1.0f);  // hyperparams.py:119-121
+        }
+        if (next_obs) {
+            float4 *p = reinterpret_cast<float4 *>(next_obs + i * 8);
+            p[0] = make_float4(o[0], o[1], o[2], o[3]);
+            p[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        e.store(S, n, i);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_end += __shfl_xor(n_end, off);
+        len_end += __shfl_xor(len_end, off);
+        ret_end += __shfl_xor(ret_end, off);
+    }
+    if ((threadIdx.x & 63) == 0 && n_end > 0) {
+        atomicAdd((unsigned long long *)&stats->episodes, (unsigned long long)n_end);
+        atomicAdd((unsigned long long *)&stats->len_sum, (unsigned long long)len_end);
+        atomicAdd(&stats->ret_sum, ret_end);
+    }
+}
+
 }  // namespace
 
 struct ddrl_env {
@@ -334,6 +408,19 @@ int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d
     ddrl::DeviceGuard g(h->device);
     k_env_step<<<(unsigned)((h->n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(
         h->S, h->n, h->seed, (float)h->max_ep_len, act_d, obs2_d, rew_d, done_d, next_obs_d, ended_d, h->stats);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_env_step_wrapped(ddrl_env_t *h, const float *act_d, float act_noise, float obs_noise, float reward_scale, int32_t action_repeat,
+                          int32_t limit_steps, float *obs2_d, float *rew_d, float *done_d, float *next_obs_d, uint8_t *ended_d,
+                          void *stream) {
+    DDRL_REQUIRE(h != nullptr && act_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(action_repeat >= 1 && limit_steps >= 1, "action_repeat and limit_steps must be >= 1");
+    ddrl::DeviceGuard g(h->device);
+    k_env_step_wrapped<<<(unsigned)((h->n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(
+        h->S, h->n, h->seed, (float)limit_steps, act_d, act_noise, obs_noise, reward_scale, action_repeat, obs2_d, rew_d, done_d, next_obs_d,
+        ended_d, h->stats);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }

@@ -77,6 +77,68 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, Sto
 }
 
 // ------------------------------------------------------------------------------------------
+// masked store: store() for the rows with mask != 0, in row order — the n-step rollout stores a
+// window only for the envs whose deque is full (algos/sac1/sac_ray.py:243-246), so the number of
+// rows is known on the device only.  Pass 1 (one workgroup) ranks the selected rows, pass 2 copies.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mask_scan(const uint8_t *__restrict__ mask, long long n, int *__restrict__ rank) {
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (long long i0 = 0; i0 < n; i0 += 256) {
+        const long long i = i0 + tid;
+        const bool f = i < n && mask[i] != 0;
+        const unsigned long long b = __ballot(f);
+        const int pre = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wave] = __popcll(b);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { woff += (w < wave) ? s_w[w] : 0; tot += s_w[w]; }
+        if (i < n) rank[i] = f ? base + woff + pre : -1;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) rank[n] = base;
+}
+__global__ void __launch_bounds__(256) k_store_masked(RingState *st, RingPtrs ring, StoreSrc srcs, const int *__restrict__ rank, long long n) {
+    __shared__ long long s_ptr;
+    if (threadIdx.x == 0) s_ptr = st->ptr;
+    __syncthreads();
+    const long long ptr = s_ptr, cap = ring.capacity;
+    const long long total = rank[n];
+    const long long skip = total > cap ? total - cap : 0;  // ranks below `skip` would be overwritten later in this batch
+    const int which = blockIdx.y;
+    const float *src = srcs.a[which];
+    float *dst = ring.a[which];
+    const int width = ring.w[which];
+    const bool v4 = (width & 3) == 0;
+    const int wv = v4 ? width >> 2 : width;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * wv; e += stride) {
+        const long long ri = e / wv;
+        const int c = (int)(e - ri * wv);
+        const long long r = rank[ri];
+        if (r < skip) continue;  // not selected (-1) or overwritten within the batch
+        const long long row = (ptr + r) % cap;
+        if (v4) reinterpret_cast<float4 *>(dst)[row * wv + c] = reinterpret_cast<const float4 *>(src)[e];
+        else dst[row * wv + c] = src[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total_blocks = gridDim.x * gridDim.y;
+        const unsigned ticket = atomicAdd(&st->done_counter, 1u);
+        if (ticket == total_blocks - 1) {
+            st->ptr = (ptr + total) % cap;
+            const long long sz = st->size + total;
+            st->size = sz > cap ? cap : sz;
+            st->steps += total * ring.steps_inc;
+            st->done_counter = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // MT19937 (NumPy legacy RandomState): seed == init_genrand
 // ------------------------------------------------------------------------------------------
 __global__ void k_mt_seed(RingState *st, uint32_t seed) {
@@ -139,6 +201,9 @@ struct ddrl_replay {
     // host mirror of the counters: exact while every store/sample goes through this API
     // eagerly; refreshed from the device by ddrl_replay_counts (graph replays run ahead of it)
     long long h_ptr, h_size, h_steps, h_samples;
+    bool h_dirty;        // a masked store (row count known on the device only) has run since the last refresh
+    int *rank_buf;       // device scratch of the masked store
+    long long rank_cap;
     uint32_t flags;
 };
 
@@ -147,6 +212,7 @@ static int refresh_counts(ddrl_replay *h, hipStream_t s) {
     DDRL_HIP_CHECK(hipMemcpyAsync(&tmp, h->state, offsetof(RingState, mt_key), hipMemcpyDeviceToHost, s));
     DDRL_HIP_CHECK(hipStreamSynchronize(s));
     h->h_ptr = tmp.ptr; h->h_size = tmp.size; h->h_steps = tmp.steps; h->h_samples = tmp.sample_times;
+    h->h_dirty = false;
     return DDRL_OK;
 }
 
@@ -218,7 +284,7 @@ int ddrl_replay_destroy(ddrl_replay_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
     for (int j = 0; j < MAX_ARRAYS; ++j) (void)hipFree(h->ring.a[j]);
-    (void)hipFree(h->state); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->state); (void)hipFree(h->idx_buf); (void)hipFree(h->rank_buf);
     delete h;
     return DDRL_OK;
 }
@@ -256,6 +322,35 @@ int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n,
     return DDRL_OK;
 }
 
+int ddrl_replay_store_masked_ex(ddrl_replay_t *h, const float *const *src_h, const uint8_t *mask_d, int64_t n, void *stream) {
+    DDRL_REQUIRE(h != nullptr && src_h != nullptr && mask_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(n >= 0 && n < 0x7fffffffll, "n must be in [0, 2^31)");
+    if (n == 0) return DDRL_OK;
+    StoreSrc srcs{};
+    int widest = 1;
+    for (int j = 0; j < h->ring.n_arr; ++j) {
+        DDRL_REQUIRE(src_h[j] != nullptr, "NULL source array");
+        srcs.a[j] = src_h[j];
+        const int wv = (h->ring.w[j] & 3) == 0 ? h->ring.w[j] / 4 : h->ring.w[j];
+        if (wv > widest) widest = wv;
+    }
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    if (n + 1 > h->rank_cap) {
+        DDRL_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(h->rank_buf);
+        h->rank_cap = n + 1;
+        DDRL_HIP_CHECK(hipMalloc(&h->rank_buf, h->rank_cap * sizeof(int)));
+    }
+    k_mask_scan<<<1, 256, 0, s>>>(mask_d, n, h->rank_buf);
+    long long blocks = (n * widest + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    k_store_masked<<<dim3((unsigned)blocks, (unsigned)h->ring.n_arr), 256, 0, s>>>(h->state, h->ring, srcs, h->rank_buf, n);
+    DDRL_LAUNCH_CHECK();
+    h->h_dirty = true;
+    return DDRL_OK;
+}
+
 int ddrl_replay_store(ddrl_replay_t *h, const float *obs_d, const float *act_d, const float *rew_d,
                       const float *obs2_d, const float *done_d, int64_t n, void *stream) {
     DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");
@@ -279,8 +374,8 @@ int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, 
     }
     ddrl::DeviceGuard g(h->device);
     hipStream_t s = ddrl::as_stream(stream);
-    if (h->h_size <= 0) {
-        // the mirror may lag behind graph replays: ask the device before reporting empty
+    if (h->h_size <= 0 || h->h_dirty) {
+        // the mirror may lag behind graph replays / masked stores: ask the device before reporting empty
         int rc = refresh_counts(h, s);
         if (rc != DDRL_OK) return rc;
         if (h->h_size <= 0) {

@@ -54,6 +54,16 @@ class VecLunarLander:
                                            _lib.stream_ptr()))
         return self.obs2, self.rew, self.done, self.obs, self.ended
 
+    def step_wrapped(self, act, act_noise=0.0, obs_noise=0.0, reward_scale=1.0, action_repeat=3, limit_steps=None):
+        """env.step through `Wrapper` (algos/sac1/hyperparams.py:107-134) + the n-step rollout's episode
+        bookkeeping (algos/sac1/sac_ray.py:212-258).  Same outputs as step(); done is the raw d."""
+        act = act.to(device=self.device, dtype=torch.float32).contiguous()
+        limit = int(limit_steps if limit_steps is not None else self.max_ep_len)
+        _lib.check(self._lib.ddrl_env_step_wrapped(self._h, _lib.dptr(act), float(act_noise), float(obs_noise), float(reward_scale),
+                                                   int(action_repeat), limit, _lib.dptr(self.obs2), _lib.dptr(self.rew),
+                                                   _lib.dptr(self.done), _lib.dptr(self.obs), _lib.dptr(self.ended), _lib.stream_ptr()))
+        return self.obs2, self.rew, self.done, self.obs, self.ended
+
     def sample_actions(self, out=None):
         """env.action_space.sample() for every env: U[-1, 1) from the counter generator."""
         out = out if out is not None else torch.empty(self.n, 2, dtype=torch.float32, device=self.device)

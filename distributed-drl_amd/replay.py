@@ -254,6 +254,17 @@ class ReplayBufferNStep:
         ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
         _lib.check(self._lib.ddrl_replay_store_ex(self._h, ptrs, n, _lib.stream_ptr()))
 
+    def store_masked(self, obs, acts, rews, done, mask):
+        """store() for the rows with mask != 0, in row order (device uint8[n]); the row count stays on the
+        device — get_counts() refreshes the host view."""
+        ts = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(dtype=torch.float32).contiguous() for t in (obs, acts, rews, done)]
+        n = int(ts[2].shape[0])
+        for t, w in zip(ts, self.widths):
+            assert t.numel() == n * w
+        m = mask if (mask.dtype == torch.uint8 and mask.is_contiguous()) else mask.to(dtype=torch.uint8).contiguous()
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+        _lib.check(self._lib.ddrl_replay_store_masked_ex(self._h, ptrs, _lib.dptr(m), n, _lib.stream_ptr()))
+
     def sample_batch_device(self, batch_size=None, with_indices=False):
         B = int(self.opt.batch_size if batch_size is None else batch_size)
         outs = [torch.empty((B,) + s, dtype=torch.float32, device=self.device) for s in self.shapes]

@@ -248,6 +248,93 @@ class RolloutDevice:
         self.pull()
 
 
+class WindowQueue:
+    """Per-env o_queue / a_r_d_queue of algos/sac1/sac_ray.py:192-248 on the device (csrc/winq.hip)."""
+
+    def __init__(self, n_envs, Ln, obs_dim, act_dim, save_freq=1, device=None):
+        import ctypes
+        import torch
+        from . import _lib
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self._check, self._dptr, self._stream = _lib.check, _lib.dptr, _lib.stream_ptr
+        self.n, self.Ln, self.obs_dim, self.act_dim = int(n_envs), int(Ln), int(obs_dim), int(act_dim)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ddrl_winq_create(ctypes.byref(h), self.device.index, self.n, self.Ln, self.obs_dim, self.act_dim, int(save_freq)))
+        self._h = h
+        p = (ctypes.c_void_p * 4)()
+        tq = ctypes.c_void_p()
+        _lib.check(self._lib.ddrl_winq_buffers(self._h, p, ctypes.byref(tq)))
+        from .replay import _view
+        shapes = [(self.n, self.Ln + 1, self.obs_dim), (self.n, self.Ln, self.act_dim), (self.n, self.Ln), (self.n, self.Ln)]
+        self.arrays = [_view(p[j], shapes[j], self.device) for j in range(4)]   # o, a, r, d windows: views of the device arrays
+        self.ready = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_winq_destroy(h)
+
+    def begin(self, obs, mask=None):
+        self._check(self._lib.ddrl_winq_begin(self._h, self._dptr(mask), self._dptr(obs), self._stream()))
+
+    def push(self, obs2, act, rew, done):
+        """Returns the device mask (uint8[n]) of the envs whose window is to be stored this step."""
+        self._check(self._lib.ddrl_winq_push(self._h, self._dptr(obs2), self._dptr(act), self._dptr(rew), self._dptr(done),
+                                             self._dptr(self.ready), self._stream()))
+        return self.ready
+
+
+class RolloutDeviceNStep:
+    """worker_rollout of the n-step driver (algos/sac1/sac_ray.py:179-262) for `opt.num_envs` envs per launch:
+    Wrapper'd env.step (action noise, action repeat 3, observation noise, reward scale), the per-env window
+    queues, and `replay_buffer[random shard].store(o_queue, a_r_d_queue)` for every env whose queues are full —
+    one masked row store per vector step.  `replay_buffers` is a ReplayBufferNStep or a list of them."""
+
+    WRAPPER_REPEAT = 3  # the literal in sac_ray.py:189 (opt.action_repeat only scales the episode limit)
+
+    def __init__(self, ps, replay_buffers, opt, worker_index=0):
+        import numpy as np
+        import torch
+        from .agent import Actor
+        from .env import VecLunarLander
+        self.ps, self.opt = ps, opt
+        self.rbs = list(replay_buffers) if isinstance(replay_buffers, (list, tuple)) else [replay_buffers]
+        n = int(opt.num_envs)
+        self.env = VecLunarLander(n, seed=int(opt.seed) + 1000003 * int(worker_index), max_ep_len=1 << 23)
+        self.limit_steps = -(-int(opt.max_ep_len) // int(opt.action_repeat))   # ep_len * action_repeat >= max_ep_len (sac_ray.py:252)
+        self.actor = Actor(opt, job="worker", max_rows=n) if ps is not None else None
+        self.span = ps.span(self.actor.keys) if ps is not None else None
+        self.version = -1
+        self.filling_steps = 0
+        self.winq = WindowQueue(n, opt.Ln, opt.obs_dim, opt.act_dim, getattr(opt, "save_freq", 1), device=self.env.device.index)
+        self.winq.begin(self.env.obs)
+        self.o = torch.empty_like(self.env.obs)
+        self.act = torch.empty(n, 2, dtype=torch.float32, device=self.env.device)
+        self.pick = np.random.RandomState(int(opt.seed) + 7919 * int(worker_index))
+        self.pull()
+
+    pull = RolloutDevice.pull
+
+    def step(self):
+        """One vector step = num_envs iterations of sac_ray.py:208-262."""
+        env, opt = self.env, self.opt
+        self.o.copy_(env.obs)
+        if self.actor is not None and (self.filling_steps > opt.start_steps or getattr(opt, "weights_file", "")):
+            self.actor.get_actions(self.o, out=self.act)
+        else:
+            env.sample_actions(out=self.act)
+            self.filling_steps += 1
+        o2, r, d, next_obs, ended = env.step_wrapped(self.act, getattr(opt, "act_noise", 0.0), getattr(opt, "obs_noise", 0.0),
+                                                     getattr(opt, "reward_scale", 1.0), self.WRAPPER_REPEAT, self.limit_steps)
+        ready = self.winq.push(o2, self.act, r, d)
+        rb = self.rbs[int(self.pick.choice(len(self.rbs), 1)[0])]   # replay_buffer[np.random.choice(opt.num_buffers, 1)[0]]
+        rb.store_masked(*self.winq.arrays, ready)
+        self.winq.begin(next_obs, ended)
+        self.pull()
+
+
 class TrainDevice:
     """State of one device-resident learner worker: the hot loop of sac1.py:146-151
     (`batch = sample; agent.train(batch); push every push_freq-th update`) with the sample/train

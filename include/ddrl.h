@@ -103,6 +103,10 @@ int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_
 int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays,
                           const int32_t *widths_h, int64_t steps_inc, int64_t samples_inc);
 int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n, void *stream);
+/* store() for the rows whose mask_d[i] != 0 (device uint8[n]), in row order: the n-step rollout stores
+ * a window only for the envs whose deque is full (algos/sac1/sac_ray.py:243-246).  The row count
+ * stays on the device; host-side counters are refreshed by the next ddrl_replay_counts. */
+int ddrl_replay_store_masked_ex(ddrl_replay_t *h, const float *const *src_h, const uint8_t *mask_d, int64_t n, void *stream);
 int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, int64_t *idx_d, void *stream);
 int ddrl_replay_gather_ex(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *const *out_h, void *stream);
 int ddrl_replay_buffers_ex(ddrl_replay_t *h, float **arrays_h, int32_t *widths_h, int32_t *n_arrays_h);
@@ -312,6 +316,15 @@ int ddrl_env_reset(ddrl_env_t *h, const uint8_t *mask_d, float *obs_d, void *str
  * act_d[n,2] device float32. */
 int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d, float *done_d,
                   float *next_obs_d, uint8_t *ended_d, void *stream);
+/* env.step through `Wrapper(env, obs_noise, act_noise, reward_scale, action_repeat)`
+ * (algos/sac1/hyperparams.py:107-134: uniform action noise, `action_repeat` physics steps with the
+ * rewards summed — dropped to 0.0 when the episode ends inside the repeat —, uniform observation
+ * noise, reward scale; action_repeat == 1 returns the bare step) followed by the n-step rollout's
+ * bookkeeping (algos/sac1/sac_ray.py:212-258): an episode ends on d or after `limit_steps` wrapped
+ * steps (= ceil(max_ep_len / opt.action_repeat)), done_d is the raw d.  Same outputs as ddrl_env_step. */
+int ddrl_env_step_wrapped(ddrl_env_t *h, const float *act_d, float act_noise, float obs_noise, float reward_scale,
+                          int32_t action_repeat, int32_t limit_steps, float *obs2_d, float *rew_d, float *done_d,
+                          float *next_obs_d, uint8_t *ended_d, void *stream);
 /* Episode statistics accumulated on device since the last call: number of finished episodes,
  * sum of their returns and lengths.  Synchronises `stream`; resets the accumulators. Host outs. */
 int ddrl_env_stats(ddrl_env_t *h, int64_t *episodes_h, double *ret_sum_h, int64_t *len_sum_h,
@@ -321,6 +334,26 @@ int ddrl_env_stats(ddrl_env_t *h, int64_t *episodes_h, double *ret_sum_h, int64_
 #define DDRL_ENV_STATE_FIELDS 32
 int ddrl_env_get_state(ddrl_env_t *h, float *state_d, void *stream);
 int ddrl_env_set_state(ddrl_env_t *h, const float *state_d, void *stream);
+
+/* ===================================================================================== */
+/* Rollout-side window queues of the n-step driver: per env, o_queue = deque(maxlen=Ln+1) of  */
+/* observations and a_r_d_queue = deque(maxlen=Ln) of (a, r, d) — algos/sac1/sac_ray.py:192-248 */
+/* ===================================================================================== */
+typedef struct ddrl_winq ddrl_winq_t;
+int ddrl_winq_create(ddrl_winq_t **out, int device, int64_t n_envs, int32_t Ln, int32_t obs_dim, int32_t act_dim,
+                     int32_t save_freq);
+int ddrl_winq_destroy(ddrl_winq_t *h);
+/* Episode start for every env (mask_d NULL) or the envs with mask_d[i] != 0 (sac_ray.py:199-207):
+ * o_queue = [obs_d[i]], t_queue = 1. */
+int ddrl_winq_begin(ddrl_winq_t *h, const uint8_t *mask_d, const float *obs_d, void *stream);
+/* After env.step (sac_ray.py:229-248): a_r_d_queue.append((a, r, d)); o_queue.append((o2,));
+ * ready_d[i] = (t_queue >= Ln and t_queue % save_freq == 0); t_queue += 1.  ready_d (device uint8[n])
+ * is the mask of `replay_buffer.store(o_queue, a_r_d_queue)`: pass it with ddrl_winq_buffers' arrays to
+ * ddrl_replay_store_masked_ex of a ring created with widths {(Ln+1)*obs, Ln*act, Ln, Ln}. */
+int ddrl_winq_push(ddrl_winq_t *h, const float *obs2_d, const float *act_d, const float *rew_d, const float *done_d,
+                   uint8_t *ready_d, void *stream);
+/* Device pointers of the window arrays (o, a, r, d; row = env) and of t_queue (int32[n]). */
+int ddrl_winq_buffers(ddrl_winq_t *h, float **arrays_h, int32_t **t_queue_h);
 
 /* ===================================================================================== */
 /* Counter-based noise (stands in for tf.random_normal, core.py:77, and                    */

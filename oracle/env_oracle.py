@@ -58,6 +58,7 @@ MU = F(0.5)
 SLEEP_V2 = F(0.0025)
 SLEEP_W = F(0.05)
 SLEEP_STEPS = F(25.0)
+RESET_NOISE_STREAM = 0xFFFFFFEF
 RESET_STREAM = np.uint32(0xFFFFFFF0)
 
 
@@ -255,6 +256,57 @@ class LanderOracle:
         if ended.any():
             next_obs = self.reset(ended)
         return obs2, rew, done_store, next_obs, ended.astype(np.uint8)
+
+    # -- Wrapper.step (algos/sac1/hyperparams.py:123-134) + the n-step rollout's bookkeeping
+    #    (algos/sac1/sac_ray.py:212-258); mirrors k_env_step_wrapped statement by statement ----------
+    def step_wrapped(self, act, act_noise, obs_noise, reward_scale, repeat, limit_steps):
+        S = self.S
+        act = np.asarray(act, dtype=F).reshape(self.n, 2)
+        st0 = S[PSTEP].astype(np.uint32)
+        a = np.empty_like(act)
+        a[:, 0] = act[:, 0] + F(act_noise) * (F(-2.0) * self._rng(st0, 2) + F(1.0))
+        a[:, 1] = act[:, 1] + F(act_noise) * (F(-2.0) * self._rng(st0, 3) + F(1.0))
+        r = np.zeros(self.n, F)
+        rew = np.zeros(self.n, F)
+        obs = np.zeros((self.n, 8), F)
+        done = np.zeros(self.n, bool)
+        noisy = np.ones(self.n, bool)
+        active = np.ones(self.n, bool)
+        for _ in range(int(repeat)):
+            if not active.any():
+                break
+            keep = S.copy()
+            rk, dk, ok = self._physics(a)
+            S[:, ~active] = keep[:, ~active]
+            r = np.where(active, (r + rk).astype(F), r)
+            obs[active] = ok[active]
+            done = np.where(active, dk, done)
+            brk_done = active & dk & (repeat != 1)
+            rew = np.where(brk_done, F(0.0), rew)
+            brk_one = active & ~brk_done & (repeat == 1)
+            rew = np.where(brk_one, r, rew)
+            noisy = noisy & ~brk_one
+            cont = active & ~brk_done & ~brk_one
+            rew = np.where(cont, (F(reward_scale) * r).astype(F), rew)
+            active = cont
+        st1 = S[PSTEP].astype(np.uint32)
+        for j in range(8):
+            nz = (obs[:, j] + F(obs_noise) * (F(-2.0) * self._rng(st1, 4 + j) + F(1.0))).astype(F)
+            obs[:, j] = np.where(noisy, nz, obs[:, j])
+        S[EPLEN] = S[EPLEN] + F(1.0)
+        S[EPRET] = (S[EPRET] + rew).astype(F)
+        ended = done | (S[EPLEN] >= F(limit_steps))
+        self.episodes += int(ended.sum())
+        self.ret_sum += float(S[EPRET][ended].astype(np.float64).sum())
+        self.len_sum += int(S[EPLEN][ended].sum())
+        S[EPI] = np.where(ended, S[EPI] + F(1.0), S[EPI]).astype(F)
+        next_obs = obs.copy()
+        if ended.any():
+            ro = self.reset(ended)
+            for j in range(8):
+                nz = (ro[:, j] + F(obs_noise) * (F(-2.0) * self._rng(RESET_NOISE_STREAM, j) + F(1.0))).astype(F)
+                next_obs[:, j] = np.where(ended, nz, next_obs[:, j])
+        return obs, rew.astype(F), done.astype(F), next_obs, ended.astype(np.uint8)
 
     def stats(self):
         out = (self.episodes, self.ret_sum, self.len_sum)

@@ -86,3 +86,52 @@ def test_device_style_workers_learn_something():
     assert ln >= 0 and np.isfinite(ret)
     losses, _ = trainer.agent.train(rb.sample_batch_device(256), return_outputs=True)
     assert torch.isfinite(losses).all()
+
+
+def test_nstep_rollout_equals_per_env_reference_loop():
+    """RolloutDeviceNStep (Wrapper'd vector env + device window queues + masked window store) stores, for
+    every env, exactly the windows the reference's worker loop (algos/sac1/sac_ray.py:192-262: deques of
+    maxlen Ln+1 / Ln, store once t_queue >= Ln, new deques at episode end) would store for that env, and
+    in env order within a vector step — ring contents and counters bit-exact vs a Python restatement
+    with real deques over the NumPy env oracle."""
+    from collections import deque
+    import distributed_drl_amd as d
+    from distributed_drl_amd.agent import HyperParameters
+    from oracle.env_oracle import LanderOracle
+    from oracle.replay_oracle import NStepReplayOracle
+    from oracle import noise_oracle as no
+    opt = HyperParameters()
+    opt.num_envs, opt.seed, opt.Ln, opt.max_ep_len, opt.action_repeat = 24, 3, 4, 60, 2
+    opt.buffer_size, opt.batch_size, opt.num_buffers = 150, 8, 1
+    opt.obs_noise, opt.act_noise, opt.reward_scale = 0.01, 0.3, 5
+    rb = d.ReplayBufferNStep(opt)
+    ro = d.RolloutDeviceNStep(None, rb, opt)
+    # ---- reference-order restatement: one deque pair per env, sequential over envs inside a step
+    n, Ln = opt.num_envs, opt.Ln
+    env = LanderOracle(n, seed=opt.seed, max_ep_len=1 << 23)
+    ora = NStepReplayOracle(opt)
+    oq = [deque([(env.obs()[e].copy(),)], maxlen=Ln + 1) for e in range(n)]
+    aq = [deque([], maxlen=Ln) for e in range(n)]
+    tq = [1] * n
+    limit = -(-opt.max_ep_len // opt.action_repeat)
+    steps = 70
+    for t in range(steps):
+        ro.step()
+        act = no.uniform_fill(n * 2, -1.0, 1.0, opt.seed ^ 0x5EED5EED, counter=t * n * 2).reshape(n, 2)  # env.action_space.sample()
+        np.testing.assert_array_equal(ro.act.cpu().numpy(), act)
+        o2, r, dd, nxt, ended = env.step_wrapped(act, opt.act_noise, opt.obs_noise, opt.reward_scale, 3, limit)
+        for e in range(n):
+            aq[e].append((act[e].copy(), r[e], dd[e]))
+            oq[e].append((o2[e].copy(),))
+            if tq[e] >= Ln and tq[e] % opt.save_freq == 0:
+                ora.store(oq[e], aq[e], 0)
+            tq[e] += 1
+            if ended[e]:
+                oq[e] = deque([(nxt[e].copy(),)], maxlen=Ln + 1)
+                aq[e] = deque([], maxlen=Ln)
+                tq[e] = 1
+    rings = rb.rings()
+    for k in ("buffer_o", "buffer_a", "buffer_r", "buffer_d"):
+        np.testing.assert_array_equal(rings[k].cpu().numpy(), getattr(ora, k), err_msg=k)
+    assert rb.get_counts() == ora.get_counts()
+    assert ora.steps > opt.buffer_size  # the ring wrapped

@@ -127,3 +127,32 @@ def test_gym_facade(ddrl):
     assert o.shape == (8,)
     with pytest.raises(ValueError):
         E.make("BipedalWalker-v2")
+
+
+@pytest.mark.parametrize("repeat,act_noise,obs_noise,scale", [(3, 0.3, 0.01, 5.0), (1, 0.3, 0.01, 5.0), (2, 0.0, 0.0, 1.0)])
+def test_wrapped_step_bit_exact_vs_oracle(ddrl, repeat, act_noise, obs_noise, scale):
+    """`Wrapper` (algos/sac1/hyperparams.py:107-134: action noise, action repeat with the reward summed /
+    dropped at an in-repeat terminal, observation noise, reward scale, bare step for repeat == 1) and
+    the n-step rollout's bookkeeping (sac_ray.py:212-258): HIP kernel == NumPy oracle, bit for bit."""
+    from distributed_drl_amd.env import VecLunarLander
+    from oracle.env_oracle import LanderOracle
+    n, limit = 192, 120
+    env = VecLunarLander(n, seed=11, max_ep_len=1000)
+    ora = LanderOracle(n, seed=11, max_ep_len=1000)
+    np.testing.assert_array_equal(env.obs.cpu().numpy(), ora.obs())
+    rs = np.random.RandomState(5)
+    ended_total = 0
+    for t in range(260):
+        act = rs.uniform(-1.4, 1.4, (n, 2)).astype(np.float32)   # beyond [-1, 1] too: the env clips after the noise
+        g = [x.cpu().numpy() for x in env.step_wrapped(torch.from_numpy(act).cuda(), act_noise, obs_noise, scale, repeat, limit)]
+        w = ora.step_wrapped(act, act_noise, obs_noise, scale, repeat, limit)
+        for name, a, b in zip(("obs2", "rew", "done", "next_obs", "ended"), g, w):
+            np.testing.assert_array_equal(a, b, err_msg="%s at step %d" % (name, t))
+        ended_total += int(w[4].sum())
+        if repeat != 1:  # an in-repeat terminal returns reward 0.0 (hyperparams.py:130-131)
+            assert (g[1][g[2] > 0] == 0.0).all()
+    assert ended_total > 0
+    ge, gr, gl = env.stats()
+    we, wr, wl = ora.stats()
+    assert (ge, gl) == (we, wl) and ge == ended_total
+    assert abs(gr - wr) <= 1e-9 * max(1.0, abs(wr))
