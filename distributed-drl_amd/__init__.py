@@ -22,12 +22,12 @@ def __getattr__(name):
     import importlib
     table = {
         "ReplayBuffer": "replay", "ReplayBufferSAC1": "replay", "ReplayBufferDQN": "replay", "ReplayBufferNStep": "replay",
-        "ParameterServer": "ps",
+        "ParameterServer": "ps", "ParameterServerNode": "ps",
         "Learner": "agent", "Actor": "agent", "HyperParameters": "agent",
         "VecLunarLander": "env",
         "worker_rollout": "workers", "worker_train": "workers", "worker_test": "workers",
         "worker_rollout_sac1": "workers", "worker_train_sac1": "workers",
-        "RolloutDevice": "workers", "TrainDevice": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers",
+        "RolloutDevice": "workers", "TrainDevice": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers", "ActorLearnerLoop": "workers",
     }
     if name in table:
         return getattr(importlib.import_module("." + table[name], __name__), name)

@@ -192,6 +192,24 @@ class Learner(_Net):
         _lib.check(self._lib.ddrl_sac1_opt_steps(self._h, ctypes.byref(a), ctypes.byref(b), _lib.stream_ptr()))
         return int(a.value), int(b.value)
 
+    def save_state(self, path):
+        """Full learner checkpoint (own .npz format; the reference only pickles the weights): main / target
+        parameters, Adam moments, step counts and the noise counter.  load_state() resumes bit-identically."""
+        import ctypes
+        t_pi, t_q, ctr = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_uint64()
+        _lib.check(self._lib.ddrl_sac1_opt_state_get(self._h, ctypes.byref(t_pi), ctypes.byref(t_q), ctypes.byref(ctr), _lib.stream_ptr()))
+        np.savez(path, main=self.export(_lib.SAC1_MAIN).cpu().numpy(), target=self.export(_lib.SAC1_TARGET).cpu().numpy(),
+                 adam_m=self.export(_lib.SAC1_ADAM_M).cpu().numpy(), adam_v=self.export(_lib.SAC1_ADAM_V).cpu().numpy(),
+                 opt=np.array([t_pi.value, t_q.value, ctr.value], dtype=np.uint64), keys=np.array(self.keys))
+
+    def load_state(self, path):
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        assert list(z["keys"]) == list(self.keys), "checkpoint is for a different network"
+        for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target"), (_lib.SAC1_ADAM_M, "adam_m"), (_lib.SAC1_ADAM_V, "adam_v")):
+            self.import_(which, torch.from_numpy(z[name]).to(self.device))
+        t_pi, t_q, ctr = (int(x) for x in z["opt"])
+        _lib.check(self._lib.ddrl_sac1_opt_state_set(self._h, t_pi, t_q, ctr, _lib.stream_ptr()))
+
     def _args(self, batch, eps, outs):
         B, a = self.cfg.batch, self.cfg.act_dim
         x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))

@@ -1719,6 +1719,36 @@ int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *s
     return DDRL_OK;
 }
 
+int ddrl_sac1_opt_state_get(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, uint64_t *noise_ctr_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    OptState o;
+    hipStream_t s = ddrl::as_stream(stream);
+    DDRL_HIP_CHECK(hipMemcpyAsync(&o, h->opt + h->opt_cur, sizeof(o), hipMemcpyDeviceToHost, s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    if (t_pi_h) *t_pi_h = o.t_pi;
+    if (t_q_h) *t_q_h = o.t_q;
+    if (noise_ctr_h) *noise_ctr_h = o.noise_ctr;
+    return DDRL_OK;
+}
+
+int ddrl_sac1_opt_state_set(ddrl_sac1_t *h, int64_t t_pi, int64_t t_q, uint64_t noise_ctr, void *stream) {
+    DDRL_REQUIRE(h != nullptr && t_pi >= 0 && t_q >= 0, "NULL handle or negative step count");
+    ddrl::DeviceGuard g(h->device);
+    // beta powers as TF keeps them: a running float32 product, one multiply per applied step
+    OptState o{};
+    const float b1 = (float)h->cfg.beta1, b2 = (float)h->cfg.beta2;
+    o.b1p_pi = b1; o.b2p_pi = b2; o.b1p_q = b1; o.b2p_q = b2;
+    for (int64_t i = 0; i < t_pi; ++i) { o.b1p_pi *= b1; o.b2p_pi *= b2; }
+    for (int64_t i = 0; i < t_q; ++i) { o.b1p_q *= b1; o.b2p_q *= b2; }
+    o.t_pi = t_pi; o.t_q = t_q; o.noise_ctr = noise_ctr;
+    hipStream_t s = ddrl::as_stream(stream);
+    h->opt_cur = 0;
+    DDRL_HIP_CHECK(hipMemcpyAsync(h->opt, &o, sizeof(o), hipMemcpyHostToDevice, s));
+    DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    return DDRL_OK;
+}
+
 // One stage of the update (input set `st`).  Stage ids as documented for ddrl_sac1_stage_time.
 static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const ddrl_sac1_config_t &c = h->cfg;

@@ -132,3 +132,48 @@ class ParameterServer(object):
     @property
     def version(self):
         return int(self._lib.ddrl_ps_version(self._h))
+
+
+class ParameterServerNode(ParameterServer):
+    """The per-node flavour of algos/dqn/train.py:111-174: `ParameterServer(opt, weights_file, checkpoint_path,
+    ps_index)` writes <save_dir>/All_Parameters.json, restores from <checkpoint_path>/checkpoint_weights.pickle
+    when opt.recover (train.py:139-142) or from `weights_file` (:144-154), counts learner steps
+    (`learner_step += opt.push_freq` per push, :164) and saves with save_weights() to
+    <save_dir>/checkpoint/checkpoint_weights.pickle (:172-174).  keys/values default to a fresh Learner(opt)."""
+
+    def __init__(self, opt, weights_file="", checkpoint_path="", ps_index=0, keys=None, values=None, device=None):
+        import copy
+        import json
+        import os
+        self.opt = opt
+        self.learner_step = 0
+        self.ps_index = ps_index
+        if keys is None:
+            from .agent import Learner
+            keys, values = Learner(opt, job="ps").get_weights()
+        os.makedirs(os.path.join(opt.save_dir, "checkpoint"), exist_ok=True)
+        all_parameters = {k: v for k, v in copy.deepcopy(vars(opt)).items()}
+        all_parameters["obs_space"] = ""
+        all_parameters["act_space"] = ""
+        with open(os.path.join(opt.save_dir, "All_Parameters.json"), "w") as fp:
+            json.dump(all_parameters, fp, indent=4, sort_keys=True, default=str)
+        if not checkpoint_path:
+            checkpoint_path = os.path.join(opt.save_dir, "checkpoint")
+        restored = None
+        if getattr(opt, "recover", False):
+            with open(os.path.join(checkpoint_path, "checkpoint_weights.pickle"), "rb") as pickle_in:
+                restored = pickle.load(pickle_in)
+                print("****** weights restored! ******")
+        if restored is not None and not weights_file:
+            keys, values = list(restored.keys()), list(restored.values())
+        super().__init__(keys, values, weights_file=weights_file, device=device)
+        self.learner_step = 0  # the constructor's initial fill is not a learner push
+
+    def push(self, keys, values):
+        super().push(keys, values)
+        self.learner_step += self.opt.push_freq
+
+    def save_weights(self):
+        import os
+        with open(os.path.join(self.opt.save_dir, "checkpoint", "checkpoint_weights.pickle"), "wb") as pickle_out:
+            pickle.dump(self.get_weights(), pickle_out)

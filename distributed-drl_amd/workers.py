@@ -388,3 +388,40 @@ class TrainDevice:
 
     def step(self):
         self.run(1)
+
+
+class ActorLearnerLoop:
+    """The actor/learner ratio gate of algos/sac1/sac1.py:203-207 (`while steps / sample_times > a_l_ratio:
+    sleep`) and the `Cache` prefetch of sac1.py:103-130 for the device-resident workers.  The reference
+    stalls the rollouts until the learner has caught up; with both on one stream the same invariant —
+    steps / sample_times <= a_l_ratio once learning has started (steps > start_steps, sac1.py:196) — is
+    kept by running, after every vector step, exactly the updates that re-open the gate.  The prefetch
+    queue is the learner's two input sets: update u+1's batch is drawn while update u runs
+    (ddrl_sac1_step_and_sample inside ddrl_loop_run).  Counts are tracked on the host (no device sync);
+    `counts()` reads the device."""
+
+    def __init__(self, rollout, trainer, opt):
+        self.rollout, self.trainer, self.opt = rollout, trainer, opt
+        self.a_l_ratio = float(opt.a_l_ratio)
+        self.start_steps = int(getattr(opt, "start_steps", 0))
+        self.steps = 0          # store() calls (rollout side)
+        self.sample_times = 0   # sample_batch() calls (learner side)
+
+    def due(self):
+        """Updates the learner owes before the rollouts may continue (0 while the buffer is filling)."""
+        if self.steps <= self.start_steps:
+            return 0
+        return max(0, int(self.steps // self.a_l_ratio) - self.sample_times)
+
+    def run(self, vector_steps):
+        n_env = int(self.opt.num_envs)
+        for _ in range(int(vector_steps)):
+            self.rollout.step()
+            self.steps += n_env
+            k = self.due()
+            if k:
+                self.trainer.run(k)
+                self.sample_times += k
+
+    def counts(self):
+        return self.trainer.rb.get_counts()

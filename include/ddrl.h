@@ -193,6 +193,12 @@ int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream);
 int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *stream);
 /* Adam step counters of the two optimizers (host outputs); synchronises `stream`. */
 int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *stream);
+/* Optimizer bookkeeping for checkpoint / resume: Adam step counts of the two optimizers and the
+ * device noise counter.  set() rebuilds the beta powers as TF keeps them (running float32 products,
+ * one multiply per applied step), so that a learner restored from export()ed MAIN / TARGET / ADAM_M /
+ * ADAM_V continues bit-identically.  Both synchronise `stream`. */
+int ddrl_sac1_opt_state_get(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, uint64_t *noise_ctr_h, void *stream);
+int ddrl_sac1_opt_state_set(ddrl_sac1_t *h, int64_t t_pi, int64_t t_q, uint64_t noise_ctr, void *stream);
 
 /* Learner.train(batch) == sess.run(step_ops) (actor_learner.py:58-101,135-142): forward of main
  * and target nets, pi_loss / q1_loss / q2_loss from the PRE-update parameters, Adam(pi) then

@@ -135,3 +135,68 @@ def test_nstep_rollout_equals_per_env_reference_loop():
         np.testing.assert_array_equal(rings[k].cpu().numpy(), getattr(ora, k), err_msg=k)
     assert rb.get_counts() == ora.get_counts()
     assert ora.steps > opt.buffer_size  # the ring wrapped
+
+
+def test_actor_learner_ratio_gate():
+    """sac1.py:203-207: once learning has started the rollouts never run ahead of
+    steps / sample_times <= a_l_ratio; nothing is trained while the buffer fills (steps <= start_steps)."""
+    import distributed_drl_amd as d
+    from distributed_drl_amd.agent import HyperParameters
+    opt = HyperParameters()
+    opt.num_envs, opt.start_steps, opt.a_l_ratio, opt.batch_size, opt.hidden_sizes, opt.push_freq = 64, 256, 2, 32, (64, 32), 50
+    rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 10000, seed=0)
+    from distributed_drl_amd.agent import Learner
+    net = Learner(opt)
+    ps = d.ParameterServer(*net.get_weights())
+    loop = d.ActorLearnerLoop(d.RolloutDevice(ps, rb, opt), d.TrainDevice(ps, rb, opt, updates_per_graph=4), opt)
+    loop.run(4)                                   # 256 steps: still filling
+    assert loop.counts() == (0, 256, 256)
+    v0 = ps.version
+    loop.run(20)
+    samples, steps, size = loop.counts()
+    assert steps == 24 * 64 and samples == steps // 2 and steps / samples <= opt.a_l_ratio
+    assert (loop.steps, loop.sample_times) == (steps, samples)
+    assert ps.version > v0                        # the learner pushed (every 50th update)
+
+
+def test_checkpoint_resume_formats(tmp_path):
+    """N3: (a) weights pickle {name: ndarray} + per-node recover (algos/dqn/train.py:111-174);
+    (b) full learner state: a learner restored from save_state() continues bit-identically."""
+    import pickle
+    import distributed_drl_amd as d
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    from oracle import sac1_oracle as so
+    opt = HyperParameters()
+    opt.hidden_sizes, opt.batch_size, opt.save_dir, opt.recover, opt.seed = (64, 32), 32, str(tmp_path / "run"), False, 4
+    net = Learner(opt)
+    keys, vals = net.get_weights()
+    ps = d.ParameterServerNode(opt, "", "", 0, keys, vals)
+    assert (tmp_path / "run" / "All_Parameters.json").exists()
+    vals2 = [v + 1.0 for v in vals]
+    ps.push(keys, vals2)
+    assert ps.learner_step == opt.push_freq
+    ps.save_weights()
+    w = pickle.load(open(tmp_path / "run" / "checkpoint" / "checkpoint_weights.pickle", "rb"))
+    assert list(w.keys()) == keys and all((w[k] == v).all() for k, v in zip(keys, vals2))
+    opt.recover = True
+    ps2 = d.ParameterServerNode(opt, "", "", 0, keys, vals)           # recovers the pushed weights, not `vals`
+    for a, b in zip(ps2.pull(keys), vals2):
+        np.testing.assert_array_equal(a, b)
+    # ---- (b)
+    cfg = so.Config(obs_dim=opt.obs_dim, act_dim=opt.act_dim, hidden1=64, hidden2=32, batch=32)
+    l1 = Learner(opt)
+    for it in range(3):
+        batch, eps = so.synthetic_batch(cfg, seed=it)
+        l1.train(batch, eps=eps)
+    l1.save_state(str(tmp_path / "learner"))
+    l2 = Learner(opt)
+    l2.load_state(str(tmp_path / "learner"))
+    assert l2.opt_steps() == (3, 3)
+    for it in range(3, 6):
+        batch, eps = so.synthetic_batch(cfg, seed=it)
+        a, _ = l1.train(batch, eps=eps, return_outputs=True)
+        b, _ = l2.train(batch, eps=eps, return_outputs=True)
+        assert torch.equal(a, b)
+    for which in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V):
+        assert torch.equal(l1.export(which), l2.export(which))
