@@ -23,7 +23,7 @@ def __getattr__(name):
     table = {
         "ReplayBuffer": "replay", "ReplayBufferSAC1": "replay", "ReplayBufferDQN": "replay", "ReplayBufferNStep": "replay",
         "ParameterServer": "ps", "ParameterServerNode": "ps",
-        "Learner": "agent", "Actor": "agent", "HyperParameters": "agent",
+        "Learner": "agent", "Actor": "agent", "Model": "agent", "HyperParameters": "agent",
         "VecLunarLander": "env",
         "worker_rollout": "workers", "worker_train": "workers", "worker_test": "workers",
         "worker_rollout_sac1": "workers", "worker_train_sac1": "workers",

@@ -19,18 +19,19 @@ DDRL_REPLAY_ACTS_1D = 1
 DDRL_ENV_STATE_FIELDS = 32
 SAC1_STAGES = 12
 SAC1_MAIN, SAC1_TARGET, SAC1_ADAM_M, SAC1_ADAM_V, SAC1_GRAD = range(5)
+SAC1, SAC_V = 0, 1  # ddrl_sac1_config_t.variant
 
 
 class Sac1Config(ctypes.Structure):
     """ddrl_sac1_config_t; defaults = algos/sac1/hyperparams.py + core.py:91 at LunarLander dims."""
     _fields_ = [("obs_dim", c_int32), ("act_dim", c_int32), ("hidden1", c_int32), ("hidden2", c_int32),
-                ("batch", c_int32), ("reserved", c_int32), ("alpha", c_double), ("gamma", c_double),
+                ("batch", c_int32), ("variant", c_int32), ("alpha", c_double), ("gamma", c_double),
                 ("lr", c_double), ("polyak", c_double), ("beta1", c_double), ("beta2", c_double),
                 ("adam_eps", c_double), ("act_scale", c_double)]
 
     def __init__(self, obs_dim=8, act_dim=2, hidden1=400, hidden2=300, batch=256, alpha=0.1, gamma=0.997,
-                 lr=5e-5, polyak=0.995, beta1=0.9, beta2=0.999, adam_eps=1e-8, act_scale=1.0):
-        super().__init__(obs_dim, act_dim, hidden1, hidden2, batch, 0, alpha, gamma, lr, polyak, beta1, beta2,
+                 lr=5e-5, polyak=0.995, beta1=0.9, beta2=0.999, adam_eps=1e-8, act_scale=1.0, variant=0):
+        super().__init__(obs_dim, act_dim, hidden1, hidden2, batch, variant, alpha, gamma, lr, polyak, beta1, beta2,
                          adam_eps, act_scale)
 
 

@@ -36,6 +36,10 @@ def param_specs(obs_dim, act_dim, hidden1, hidden2, nets=("pi", "q1", "q2")):
             specs += [("main/%s/dense/kernel" % q, (o + a, h1)), ("main/%s/dense/bias" % q, (h1,)),
                       ("main/%s/dense_1/kernel" % q, (h1, h2)), ("main/%s/dense_1/bias" % q, (h2,)),
                       ("main/%s/dense_2/kernel" % q, (h2, 1)), ("main/%s/dense_2/bias" % q, (1,))]
+    if "v" in nets:  # example/core.py:112-113,126-127: vf_mlp(x)
+        specs += [("main/v/dense/kernel", (o, h1)), ("main/v/dense/bias", (h1,)),
+                  ("main/v/dense_1/kernel", (h1, h2)), ("main/v/dense_1/bias", (h2,)),
+                  ("main/v/dense_2/kernel", (h2, 1)), ("main/v/dense_2/bias", (1,))]
     return specs
 
 
@@ -81,9 +85,9 @@ class HyperParameters:
         self.obs_shape, self.act_shape = (obs_dim,), (act_dim,)
         self.num_envs = 1     # vectorised rollouts: envs stepped together by one worker
 
-    def config(self, batch=None):
+    def config(self, batch=None, variant=0):
         return _lib.Sac1Config(obs_dim=self.obs_dim, act_dim=self.act_dim, hidden1=self.hidden_sizes[0],
-                               hidden2=self.hidden_sizes[1], batch=self.batch_size if batch is None else batch,
+                               hidden2=self.hidden_sizes[1], batch=self.batch_size if batch is None else batch, variant=variant,
                                alpha=self.alpha, gamma=self.gamma, lr=self.lr, polyak=self.polyak,
                                act_scale=self.act_scale)
 
@@ -154,13 +158,17 @@ class _Net:
 class Learner(_Net):
     """algos/sac1/actor_learner.py:19-148."""
 
+    NETS = ("pi", "q1", "q2")
+    VARIANT = 0   # _lib.SAC1
+    N_LOSSES = 3
+
     def __init__(self, opt, job="learner"):
-        self._setup(opt, ("pi", "q1", "q2"))
-        self.cfg = opt.config()
+        self._setup(opt, self.NETS)
+        self.cfg = opt.config(variant=self.VARIANT)
         h = ctypes.c_void_p()
         _lib.check(self._lib.ddrl_sac1_create(ctypes.byref(h), self.device.index, ctypes.byref(self.cfg)))
         self._h = h
-        self.losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.losses = torch.zeros(self.N_LOSSES, dtype=torch.float32, device=self.device)
         # tf.global_variables_initializer with tf.set_random_seed(opt.seed): glorot / zeros
         self._flat_set(torch.from_numpy(glorot_init(self.specs, opt.seed)).to(self.device))
 
@@ -245,6 +253,74 @@ class Learner(_Net):
         if gradients is not None:
             self.import_(_lib.SAC1_GRAD, gradients)
         _lib.check(self._lib.ddrl_sac1_apply_grads(self._h, _lib.stream_ptr()))
+
+
+class _ModelOpt:
+    """example/dsac.py:185-216's `args` as the option bag the kernels read."""
+
+    def __init__(self, args):
+        hs = list(args.ac_kwargs.get("hidden_sizes", (400, 300))) if hasattr(args, "ac_kwargs") else list(getattr(args, "hidden_sizes", (400, 300)))
+        if len(hs) == 1:
+            hs = hs * 2
+        assert len(hs) == 2, "two hidden layers (example/dsac.py: --l 2; --l 1 is widened to two equal layers here)"
+        self.hidden_sizes = tuple(int(h) for h in hs)
+        self.obs_dim, self.act_dim = int(args.obs_dim), int(args.act_dim)
+        g = args.gamma[0] if isinstance(args.gamma, (tuple, list)) else args.gamma   # dsac.py:198 sets a 1-tuple
+        self.alpha, self.gamma, self.lr, self.polyak = float(args.alpha), float(g), float(args.lr), float(args.polyak)
+        self.batch_size = int(args.batch_size)
+        self.seed = int(getattr(args, "seed", 0))
+        sp = args.ac_kwargs.get("action_space") if hasattr(args, "ac_kwargs") else None
+        self.act_scale = float(sp.high[0]) if sp is not None else float(getattr(args, "act_scale", 1.0))
+        self.max_ep_len = int(getattr(args, "max_ep_len", 1000))
+
+    def config(self, batch=None, variant=0):
+        return _lib.Sac1Config(obs_dim=self.obs_dim, act_dim=self.act_dim, hidden1=self.hidden_sizes[0], hidden2=self.hidden_sizes[1],
+                               batch=self.batch_size if batch is None else batch, variant=variant, alpha=self.alpha,
+                               gamma=self.gamma, lr=self.lr, polyak=self.polyak, act_scale=self.act_scale)
+
+
+class Model(Learner):
+    """example/model.py:12-118 — the SAC-v learner of example/dsac.py (policy + twin Q + V + target V):
+    `Model(args)`, set_weights / get_weights ("main" variables: pi, q1, q2, v), get_action(o, deterministic),
+    train(replay_buffer, args) = one sample_batch + one sess.run(step_ops), test_agent(test_env, args, n)."""
+    NETS = ("pi", "q1", "q2", "v")
+    VARIANT = 1   # _lib.SAC_V
+    N_LOSSES = 4  # pi_loss, q1_loss, q2_loss, v_loss (model.py:66)
+
+    def __init__(self, args):
+        super().__init__(_ModelOpt(args) if not isinstance(args, (HyperParameters, _ModelOpt)) else args)
+        self._actor = None
+
+    def _policy(self):
+        if self._actor is None:
+            self._actor = Actor(self.opt, job="worker", max_rows=1)
+        flat = self._flat_get()
+        n = self._actor.n_params
+        self._actor.set_weights_flat(flat[:n])   # the policy variables lead the flat vector
+        return self._actor
+
+    def get_action(self, o, deterministic=False):
+        a = self._policy().get_actions(torch.as_tensor(np.asarray(o, dtype=np.float32)).reshape(1, -1), deterministic=deterministic)
+        return a[0].cpu().numpy()
+
+    def train(self, replay_buffer, args=None, eps=None, return_outputs=False):
+        if isinstance(replay_buffer, dict):   # a batch, as Learner.train takes it
+            batch = replay_buffer
+        else:
+            from .workers import _remote, _get
+            batch = _get(_remote(replay_buffer.sample_batch, self.cfg.batch if args is None else args.batch_size))
+        return super().train(batch, eps=eps, return_outputs=return_outputs)
+
+    def test_agent(self, test_env, args, n=10):
+        test_ret = []
+        for _ in range(n):
+            o, r, d, ep_ret, ep_len = test_env.reset(), 0, False, 0, 0
+            while not (d or (ep_len == args.max_ep_len)):
+                o, r, d, _ = test_env.step(self.get_action(o, True))
+                ep_ret += r
+                ep_len += 1
+            test_ret.append(ep_ret)
+        return sum(test_ret) / len(test_ret)
 
 
 class Actor(_Net):

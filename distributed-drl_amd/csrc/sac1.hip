@@ -928,6 +928,7 @@ struct RowsC {
     float *losses;           // [3] pi_loss, q1_loss, q2_loss (actor_learner.py:66-68)
     int B, h1, h2, ldh2, obs, act, ldd, loss_blocks;
     float alpha, scale;
+    int nl;  // loss terms per row: 3 (SAC1) or 4 (SAC-v: + v_loss)
 };
 __global__ void __launch_bounds__(64) k_rows_c(int nrows, RowsC a) {
     const int lane = threadIdx.x;
@@ -935,21 +936,21 @@ __global__ void __launch_bounds__(64) k_rows_c(int nrows, RowsC a) {
         // reduce_mean over the batch: the extra last workgroup sums the per-row terms of k_rows_b in
         // a fixed order (lane-strided partial sums, then the xor-shuffle tree)
         const int ln = lane;
-        float s3[3] = {0.f, 0.f, 0.f};
+        float s3[4] = {0.f, 0.f, 0.f, 0.f};
         for (int b0 = 0; b0 < a.loss_blocks; b0 += 64) {
             const int b = b0 + ln;
             const bool ok = b < a.loss_blocks;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = a.loss_part[(ok ? b : 0) * 3 + c];
-                s3[c] += ok ? v : 0.f;
+            for (int c = 0; c < 4; ++c) {
+                const float v = a.loss_part[(ok ? b : 0) * a.nl + (c < a.nl ? c : 0)];
+                s3[c] += (ok && c < a.nl) ? v : 0.f;
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const float tot = wave_sum(s3[c]);
             const float mean = tot / (float)a.B;
-            if (ln == 0) a.losses[c] = c == 0 ? mean : 0.5f * mean;
+            if (ln == 0 && c < a.nl) a.losses[c] = c == 0 ? mean : 0.5f * mean;
         }
         return;
     }
@@ -1031,6 +1032,109 @@ __global__ void __launch_bounds__(64) k_rows_c(int nrows, RowsC a) {
     for (int i = 0; i < RV; ++i) {
         const int j = lane + 64 * i;
         if (j < a.h2) out[j] = hrow[i] > 0.f ? acc[i] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SAC-v (example/model.py:17-76: policy + twin Q + V + target V).  Evaluations and their H1/H2 slots:
+// 0 pi(x)  1 q1(x,a)  2 q2(x,a)  3 q1(x,pi)  4 q2(x,pi)  5 v(x)  6 v_targ(x2).
+// ------------------------------------------------------------------------------------------
+struct RowsAV {
+    const float *H2;
+    NetPi pi;
+    NetQ q1, q2, v, vt;
+    const float *e0;
+    float *act0, *logp0, *save0, *q1o, *q2o, *vo, *vto;
+    float *H1;
+    const float *Wa_q1, *Wa_q2;  // action rows of the main q1 / q2 layer-1 kernels
+    int B, h2, ldh2, act, h1, ldh1;
+    float scale;
+};
+__global__ void __launch_bounds__(256) k_rows_a_v(RowsAV a) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= a.B * 5) return;
+    const int k = wid / a.B, r = wid - k * a.B;
+    const int e = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 2 : (k == 3 ? 5 : 6)));
+    float hrow[RV];
+    load_row(a.H2 + ((long long)e * a.B + r) * a.ldh2, a.h2, lane, hrow);
+    if (k == 0) {
+        const float el = a.e0[(long long)r * a.act + (lane < a.act ? lane : 0)];
+        mask_row(hrow, a.h2, lane);
+        const HeadOut o = policy_head(hrow, a.h2, a.act, a.pi, el, a.scale, lane);
+        if (lane < a.act) {
+            a.act0[r * a.act + lane] = o.act;
+            *reinterpret_cast<float4 *>(a.save0 + ((long long)r * a.act + lane) * 4) = make_float4(o.a, o.std, o.t, o.eps);
+        }
+        if (lane == 0) a.logp0[r] = o.logp;
+        const long long BH1 = (long long)a.B * a.ldh1;
+        finish_l1(a.H1 + 3 * BH1 + (long long)r * a.ldh1, a.h1, a.act, a.Wa_q1, o.act, lane);  // q1(x, pi)
+        finish_l1(a.H1 + 4 * BH1 + (long long)r * a.ldh1, a.h1, a.act, a.Wa_q2, o.act, lane);  // q2(x, pi)
+    } else {
+        const NetQ &q = k == 1 ? a.q1 : (k == 2 ? a.q2 : (k == 3 ? a.v : a.vt));
+        float w3[RV];
+        load_row(q.W3, a.h2, lane, w3);
+        const float b3 = q.b3[0];
+        mask_row(hrow, a.h2, lane);
+        const float v = wave_sum(dot_rv(hrow, w3)) + b3;
+        if (lane == 0) (k == 1 ? a.q1o : (k == 2 ? a.q2o : (k == 3 ? a.vo : a.vto)))[r] = v;
+    }
+}
+
+// example/model.py:33-47: min double-Q, the Q and V regression targets, the four losses and their
+// derivatives w.r.t. the head outputs; dZ2 slots: 0 q1(x,a)  1 q2(x,a)  2 q1(x,pi)  3 v(x)  (4 = pi)
+struct RowsBV {
+    const float *H2;
+    NetQ q1, q2, v;
+    const float *rew, *done, *logp0, *q1o, *q2o, *vo, *vto;
+    float *dZ2, *dq4, *loss_part;
+    int B, h2, ldh2;
+    float alpha, gamma;
+};
+__global__ void __launch_bounds__(64) k_rows_b_v(RowsBV a) {
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
+    if (r >= a.B) return;
+    const long long BH = (long long)a.B * a.ldh2, BZ = (long long)a.B * a.h2;
+    float h1r[RV], h2r[RV], h3r[RV], h4r[RV], h5r[RV], w1[RV], w2[RV], wv[RV];
+    load_row(a.H2 + 1 * BH + (long long)r * a.ldh2, a.h2, lane, h1r);
+    load_row(a.H2 + 2 * BH + (long long)r * a.ldh2, a.h2, lane, h2r);
+    load_row(a.H2 + 3 * BH + (long long)r * a.ldh2, a.h2, lane, h3r);
+    load_row(a.H2 + 4 * BH + (long long)r * a.ldh2, a.h2, lane, h4r);
+    load_row(a.H2 + 5 * BH + (long long)r * a.ldh2, a.h2, lane, h5r);
+    load_row(a.q1.W3, a.h2, lane, w1);
+    load_row(a.q2.W3, a.h2, lane, w2);
+    load_row(a.v.W3, a.h2, lane, wv);
+    const float rew = a.rew[r], done = a.done[r], lp0 = a.logp0[r], q1v = a.q1o[r], q2v = a.q2o[r], vv = a.vo[r], vt = a.vto[r];
+    const float b1 = a.q1.b3[0], b2 = a.q2.b3[0];
+    mask_row(w1, a.h2, lane); mask_row(w2, a.h2, lane);
+    const float q1pi = wave_sum(dot_rv(h3r, w1)) + b1;
+    const float q2pi = wave_sum(dot_rv(h4r, w2)) + b2;
+    const float minq = fminf(q1pi, q2pi);                              // model.py:34
+    const float q_backup = rew + (a.gamma * (1.0f - done)) * vt;       // :37
+    const float v_backup = minq - a.alpha * lp0;                       // :38
+    const float e1 = q_backup - q1v, e2 = q_backup - q2v, ev = v_backup - vv;
+    const float inv_b = 1.0f / (float)a.B;
+    const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b, dv = -ev * inv_b, dqp = -inv_b;
+    if (lane == 0) {
+        *reinterpret_cast<float4 *>(a.dq4 + (long long)r * 4) = make_float4(dq1, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(a.dq4 + ((long long)a.B + r) * 4) = make_float4(dq2, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(a.dq4 + ((long long)2 * a.B + r) * 4) = make_float4(dv, 0.f, 0.f, 0.f);
+        a.loss_part[r * 4 + 0] = a.alpha * lp0 - q1pi;                 // :41
+        a.loss_part[r * 4 + 1] = e1 * e1;                              // :42
+        a.loss_part[r * 4 + 2] = e2 * e2;                              // :43
+        a.loss_part[r * 4 + 3] = ev * ev;                              // :44
+    }
+    float *z0 = a.dZ2 + (long long)r * a.h2, *z1 = z0 + BZ, *z2 = z1 + BZ, *z3 = z2 + BZ;
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < a.h2) {
+            z0[j] = h1r[i] > 0.f ? dq1 * w1[i] : 0.f;
+            z1[j] = h2r[i] > 0.f ? dq2 * w2[i] : 0.f;
+            z2[j] = h3r[i] > 0.f ? dqp * w1[i] : 0.f;
+            z3[j] = h5r[i] > 0.f ? dv * wv[i] : 0.f;
+        }
     }
 }
 
@@ -1197,6 +1301,7 @@ struct Layout {
     // internal (padded) offsets
     long long pi_W1, pi_b1, pi_W2, pi_b2, pi_Wmu, pi_bmu, pi_Wls, pi_bls;
     long long q_W1[2], q_b1[2], q_W2[2], q_b2[2], q_W3[2], q_b3[2];
+    long long v_W1, v_b1, v_W2, v_b2, v_W3, v_b3;  // SAC-v only (example/model.py: 'main/v')
     long long n_pi_int, total_int;
     long long n_pi, n_q, total_ext;
     std::vector<Seg> segs;  // 20 tensors in external order
@@ -1224,6 +1329,11 @@ static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only) {
         add(L.q_W1[q], (o + a) * h1, false); add(L.q_b1[q], h1, true); add(L.q_W2[q], h1 * h2, false); add(L.q_b2[q], h2, true);
         add(L.q_W3[q], h2, false); add(L.q_b3[q], 1, true);
     }
+    L.v_W1 = L.v_b1 = L.v_W2 = L.v_b2 = L.v_W3 = L.v_b3 = -1;
+    if (!pi_only && c.variant == DDRL_SAC_V) {  // vf_mlp(x): obs -> h1 -> h2 -> 1 (example/core.py:112-113)
+        add(L.v_W1, o * h1, false); add(L.v_b1, h1, true); add(L.v_W2, h1 * h2, false); add(L.v_b2, h2, true);
+        add(L.v_W3, h2, false); add(L.v_b3, 1, true);
+    }
     L.total_int = in;
     L.total_ext = ext;
     L.n_q = pi_only ? 0 : (ext - L.n_pi) / 2;
@@ -1236,6 +1346,9 @@ static NetPi net_pi(const float *base, const Layout &L) {
 }
 static NetQ net_q(const float *base, const Layout &L, int q) {
     return NetQ{base + L.q_W1[q], base + L.q_b1[q], base + L.q_W2[q], base + L.q_b2[q], base + L.q_W3[q], base + L.q_b3[q]};
+}
+static NetQ net_v(const float *base, const Layout &L) {
+    return NetQ{base + L.v_W1, base + L.v_b1, base + L.v_W2, base + L.v_b2, base + L.v_W3, base + L.v_b3};
 }
 
 static size_t gemm_smem(const GemmJobs &js);
@@ -1314,6 +1427,7 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
     DDRL_REQUIRE(c != nullptr, "config is NULL");
     DDRL_REQUIRE(c->obs_dim > 0 && c->act_dim > 0 && c->hidden1 > 0 && c->hidden2 > 0 && c->batch > 0, "dims must be positive");
     DDRL_REQUIRE(c->act_dim <= MAXA, "act_dim > 8 unsupported");
+    DDRL_REQUIRE(c->variant == DDRL_SAC1 || c->variant == DDRL_SAC_V, "variant must be DDRL_SAC1 or DDRL_SAC_V");
     DDRL_REQUIRE(c->obs_dim + c->act_dim <= L1_MAXD, "obs_dim + act_dim > 40 unsupported by the layer-1 kernel");
     DDRL_REQUIRE(c->hidden1 <= 64 * RV && c->hidden2 <= 64 * RV, "hidden sizes > 512 unsupported by the row kernels");
     return DDRL_OK;
@@ -1323,7 +1437,7 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
 static bool fused_ok(const ddrl_sac1_config_t &c, const Layout &L) {
     const bool al = (L.pi_W2 % 4 == 0) && (L.q_W2[0] % 4 == 0) && (L.q_W2[1] % 4 == 0) && (L.pi_W1 % 4 == 0) && (L.q_W1[0] % 4 == 0) &&
                     (L.q_W1[1] % 4 == 0);
-    return c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * F_MAXNT &&
+    return c.variant == DDRL_SAC1 && c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * F_MAXNT &&
            c.obs_dim + c.act_dim <= FD && 2 * c.act_dim <= FH && c.act_dim <= 4 && c.batch % 32 == 0 && al;
 }
 
@@ -1350,6 +1464,9 @@ struct ddrl_sac1 {
     RowsA ra[2];
     RowsB rb[2];
     RowsC rc;
+    RowsAV rav[2];       // SAC-v
+    RowsBV rbv[2];
+    float *vo, *vto;
     AdamArgs ad;
     int rows_b_blocks;
     bool fused;          // fused forward stages (sac1_fused.h) instead of k_l1 / k_gemm / k_rows_a
@@ -1385,6 +1502,90 @@ static int reset_opt(ddrl_sac1 *h, hipStream_t s) {
     h->opt_cur = 0;
     DDRL_HIP_CHECK(hipMemcpyAsync(h->opt, &o, sizeof(o), hipMemcpyHostToDevice, s));
     DDRL_HIP_CHECK(hipStreamSynchronize(s));
+    return DDRL_OK;
+}
+
+// Job tables of the SAC-v update (example/model.py:17-76) on the generic kernels.
+static int build_sacv(ddrl_sac1 *h) {
+    const ddrl_sac1_config_t *cfg = &h->cfg;
+    const Layout &L = h->L;
+    const int B = cfg->batch, o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
+    const float *Pm = h->main_p, *Pt = h->target_p;
+    const int ldh1 = h->ldh1, ldh2 = h->ldh2;
+    const long long BH1 = (long long)B * ldh1, BH2 = (long long)B * ldh2, BZ1 = (long long)B * h1, BZ2 = (long long)B * h2;
+    h->fused = false;
+    // evaluations: 0 pi(x) 1 q1(x,a) 2 q2(x,a) | 3 q1(x,pi) 4 q2(x,pi) (observation part here, finished by k_rows_a_v) | 5 v(x) 6 v_targ(x2)
+    for (int st = 0; st < 2; ++st) {
+        float *x = h->in[st][0], *x2 = h->in[st][1], *ac = h->in[st][2];
+        auto l1 = [&](const float *in0, int d0, const float *in1, int d1, const float *W, const float *b, int ev, int pre) {
+            return L1Job{in0, in1, W, b, h->H1 + ev * BH1, nullptr, d0, d1, B, h1, ldh1, 0, pre};
+        };
+        L1Jobs &J = h->l1a[st];
+        J.njobs = 7;
+        J.noise_on = 0; J.act = a; J.n_each = B * a; J.noise_seed = 0;
+        J.e0 = h->in[st][5]; J.e1 = h->in[st][6]; J.e2 = h->in[st][7]; J.opt = h->opt;
+        J.job[0] = l1(x, o, nullptr, 0, Pm + L.pi_W1, Pm + L.pi_b1, 0, 0);
+        J.job[1] = l1(x, o, ac, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 1, 0);
+        J.job[2] = l1(x, o, ac, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 2, 0);
+        J.job[3] = l1(x, o, nullptr, a, Pm + L.q_W1[0], Pm + L.q_b1[0], 3, 1);
+        J.job[4] = l1(x, o, nullptr, a, Pm + L.q_W1[1], Pm + L.q_b1[1], 4, 1);
+        J.job[5] = l1(x, o, nullptr, 0, Pm + L.v_W1, Pm + L.v_b1, 5, 0);
+        J.job[6] = l1(x2, o, nullptr, 0, Pt + L.v_W1, Pt + L.v_b1, 6, 0);
+        J.job[0].aug_out = h->xp; J.job[0].aug_ld = h->ldxp;  // [x | 1]     : pi and v layer-1 wgrads
+        J.job[1].aug_out = h->xa; J.job[1].aug_ld = h->ldxa;  // [x | a | 1] : Q layer-1 wgrads
+        h->rav[st] = RowsAV{h->H2, net_pi(Pm, L), net_q(Pm, L, 0), net_q(Pm, L, 1), net_v(Pm, L), net_v(Pt, L), h->in[st][5],
+                            h->act0, h->logp0, h->save0, h->q1o, h->q2o, h->vo, h->vto, h->H1,
+                            Pm + L.q_W1[0] + (long long)o * h1, Pm + L.q_W1[1] + (long long)o * h1, B, h2, ldh2, a, h1, ldh1,
+                            (float)cfg->act_scale};
+        h->rbv[st] = RowsBV{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_v(Pm, L), h->in[st][3], h->in[st][4], h->logp0, h->q1o, h->q2o,
+                            h->vo, h->vto, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2, (float)cfg->alpha, (float)cfg->gamma};
+    }
+    auto fwd = [&](const float *P, long long W2, long long b2, int ev) {
+        return gemm_fwd(h->H1 + ev * BH1, ldh1, P + W2, P + b2, h->H2 + ev * BH2, ldh2, B, h1, h2);
+    };
+    gemm_add(h->g_fa, fwd(Pm, L.pi_W2, L.pi_b2, 0));
+    gemm_add(h->g_fa, fwd(Pm, L.q_W2[0], L.q_b2[0], 1));
+    gemm_add(h->g_fa, fwd(Pm, L.q_W2[1], L.q_b2[1], 2));
+    gemm_add(h->g_fa, fwd(Pm, L.v_W2, L.v_b2, 5));
+    gemm_add(h->g_fa, fwd(Pt, L.v_W2, L.v_b2, 6));
+    gemm_add(h->g_fb, fwd(Pm, L.q_W2[0], L.q_b2[0], 3));
+    gemm_add(h->g_fb, fwd(Pm, L.q_W2[1], L.q_b2[1], 4));
+    float *G = h->grad;
+    // value backward: dZ2 / dZ1 slots 0 q1(x,a) 1 q2(x,a) 2 q1(x,pi) 3 v(x)
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 2 * BZ2, Pm + L.q_W2[0], h->H1 + 3 * BH1, ldh1, h->dZ1 + 2 * BZ1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 0 * BZ2, Pm + L.q_W2[0], h->H1 + 1 * BH1, ldh1, h->dZ1 + 0 * BZ1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 1 * BZ2, Pm + L.q_W2[1], h->H1 + 2 * BH1, ldh1, h->dZ1 + 1 * BZ1, B, h1, h2));
+    gemm_add(h->g_bq, gemm_dgrad(h->dZ2 + 3 * BZ2, Pm + L.v_W2, h->H1 + 5 * BH1, ldh1, h->dZ1 + 3 * BZ1, B, h1, h2));
+    for (int q = 0; q < 2; ++q) {
+        gemm_add(h->g_bq, gemm_wgrad(h->H1 + (1 + q) * BH1, ldh1, h1, h->dZ2 + q * BZ2, h2, h2, G + L.q_W2[q], h2, B));
+        gemm_add(h->g_bq, gemm_wgrad(h->H2 + (1 + q) * BH2, ldh2, h2, h->dq4 + (long long)q * B * 4, 4, 1, G + L.q_W3[q], 1, B));
+    }
+    gemm_add(h->g_bq, gemm_wgrad(h->H1 + 5 * BH1, ldh1, h1, h->dZ2 + 3 * BZ2, h2, h2, G + L.v_W2, h2, B));
+    gemm_add(h->g_bq, gemm_wgrad(h->H2 + 5 * BH2, ldh2, h2, h->dq4 + (long long)2 * B * 4, 4, 1, G + L.v_W3, 1, B));
+    // policy backward (dZ2 / dZ1 slot 4) + the layer-1 wgrads of the value networks
+    {
+        GemmJob j = gemm_dgrad(h->dZ2 + 4 * BZ2, Pm + L.pi_W2, h->H1 + 0 * BH1, ldh1, h->dZ1 + 4 * BZ1, B, h1, h2);
+        h->fused_l1_wgrad = (h1 % 4 == 0) && (o + 1 <= 12) && (L.pi_W1 % 4 == 0);
+        if (h->fused_l1_wgrad) { j.part_x = h->xp; j.part = h->part; j.part_nk = o + 1; j.part_ldx = h->ldxp; }
+        gemm_add(h->g_bpi, j);
+    }
+    gemm_add(h->g_bpi, gemm_wgrad(h->H1 + 0 * BH1, ldh1, h1, h->dZ2 + 4 * BZ2, h2, h2, G + L.pi_W2, h2, B));
+    gemm_add(h->g_bpi, gemm_wgrad(h->H2, ldh2, h2, h->dhead, h->ldd, a, G + L.pi_Wmu, a, B));
+    gemm_add(h->g_bpi, gemm_wgrad(h->H2, ldh2, h2, h->dhead + a, h->ldd, a, G + L.pi_Wls, a, B));
+    for (int q = 0; q < 2; ++q)
+        gemm_add(h->g_bpi, gemm_wgrad(h->xa, h->ldxa, o + a, h->dZ1 + q * BZ1, h1, h1, G + L.q_W1[q], h1, B));
+    gemm_add(h->g_bpi, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 3 * BZ1, h1, h1, G + L.v_W1, h1, B));
+    if (!h->fused_l1_wgrad) gemm_add(h->g_last, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 4 * BZ1, h1, h1, G + L.pi_W1, h1, B));
+    h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 4 * BZ2,
+                  h->loss_part, h->losses, B, h1, h2, ldh2, o, a, h->ldd, h->rows_b_blocks, (float)cfg->alpha,
+                  (float)cfg->act_scale, 4};
+    h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, L.total_int, L.n_pi_int, 0,
+                     (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
+                     (float)cfg->polyak, (float)(1.0 - cfg->polyak),
+                     h->part, L.pi_W1 / 4, (long long)(o + 1) * h1 / 4, (long long)(o + 1) * h1 / 4,
+                     h->fused_l1_wgrad ? (B + 31) / 32 : 0, 0u};
+    h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
+    h->fuse_apply = false; h->sample_armed = false;
     return DDRL_OK;
 }
 
@@ -1431,11 +1632,11 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     }
     ALLOC(part, (size_t)((B + 31) / 32) * (o + 1) * h1);
     ALLOC(H1, (size_t)NEVAL * B * h->ldh1); ALLOC(H2, (size_t)NEVAL * B * h->ldh2);
-    ALLOC(dZ2, (size_t)4 * B * h2); ALLOC(dZ1, (size_t)4 * B * h1);
+    ALLOC(dZ2, (size_t)5 * B * h2); ALLOC(dZ1, (size_t)5 * B * h1);
     ALLOC(xa, (size_t)B * h->ldxa); ALLOC(xp, (size_t)B * h->ldxp);
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
-    ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(dq4, (size_t)2 * B * 4); ALLOC(dhead, (size_t)B * h->ldd);
-    ALLOC(loss_part, (size_t)h->rows_b_blocks * 3); ALLOC(losses, 4);
+    ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(vo, B); ALLOC(vto, B); ALLOC(dq4, (size_t)3 * B * 4); ALLOC(dhead, (size_t)B * h->ldd);
+    ALLOC(loss_part, (size_t)h->rows_b_blocks * 4); ALLOC(losses, 4);
     const int nt2 = (h2 + 31) / 32;
     ALLOC(hp, (size_t)NEVAL * FH * nt2 * B);
     ALLOC(w2snap, (size_t)h1 * h2 + 64);
@@ -1465,6 +1666,12 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     DDRL_LAUNCH_CHECK();
     DDRL_HIP_CHECK(hipDeviceSynchronize());
 
+    if (cfg->variant == DDRL_SAC_V) {
+        rc = build_sacv(h);
+        if (rc != DDRL_OK) { sac1_free(h); return rc; }
+        *out = h;
+        return DDRL_OK;
+    }
     const float *Pm = h->main_p, *Pt = h->target_p;
     const int ldh1 = h->ldh1, ldh2 = h->ldh2;
     const long long BH1 = (long long)B * ldh1, BH2 = (long long)B * ldh2, BZ1 = (long long)B * h1, BZ2 = (long long)B * h2;
@@ -1638,7 +1845,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     }
     h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 3 * BZ2,
                   h->loss_part, h->losses, B, h1, h2, ldh2, o, a, h->ldd, h->rows_b_blocks, (float)cfg->alpha,
-                  (float)cfg->act_scale};
+                  (float)cfg->act_scale, 3};
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, L.total_int, L.n_pi_int, 0,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak),
@@ -1796,9 +2003,15 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     switch (stage) {
         case 1: h->l1a[st].opt = h->opt + h->opt_cur; k_l1<<<dim3(l1grid.x, l1grid.y, h->l1a[st].njobs), 256, 0, s>>>(h->l1a[st]); break;
         case 2: launch_gemm(h->g_fa, s); break;
-        case 3: k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]); break;
+        case 3:
+            if (c.variant == DDRL_SAC_V) k_rows_a_v<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->rav[st]);
+            else k_rows_a<<<(B * 5 + 3) / 4, 256, 0, s>>>(h->ra[st]);
+            break;
         case 5: launch_gemm(h->g_fb, s); break;
-        case 6: k_rows_b<<<h->cfg.batch, 64, 0, s>>>(h->rb[st]); break;
+        case 6:
+            if (c.variant == DDRL_SAC_V) k_rows_b_v<<<B, 64, 0, s>>>(h->rbv[st]);
+            else k_rows_b<<<B, 64, 0, s>>>(h->rb[st]);
+            break;
         case 7: launch_gemm(h->g_bq, s); break;
         case 8: k_rows_c<<<B + 1, 64, 0, s>>>(B, h->rc); break;  // +1: the loss-reduction workgroup
         case 9: launch_gemm(h->g_bpi, s); break;
@@ -1844,7 +2057,7 @@ static int launch_grads(ddrl_sac1 *h, const float *obs1, const float *obs2, cons
     for (int stage = 1; stage <= 10; ++stage) launch_stage(h, stage, st, s);
     DDRL_LAUNCH_CHECK();
     if (h->fuse_apply) h->noise_pending = 0;  // consumed by the optimizer bookkeeping of the last stage
-    if (losses_d) DDRL_HIP_CHECK(hipMemcpyAsync(losses_d, h->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (losses_d) DDRL_HIP_CHECK(hipMemcpyAsync(losses_d, h->losses, (size_t)h->rc.nl * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (q1_d || q2_d || logp_d) {
         k_copy3<<<(B + 255) / 256, 256, 0, s>>>(h->q1o, h->q2o, h->logp0, q1_d, q2_d, logp_d, B);
         DDRL_LAUNCH_CHECK();

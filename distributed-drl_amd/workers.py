@@ -52,8 +52,10 @@ def worker_rollout(ps, replay_buffer, args, make_env=None, make_agent=None):
     if make_env is None:
         make_env = lambda name: _default_env(name, args)
     if make_agent is None:
-        from .agent import Actor
-        make_agent = lambda a: Actor(a, job="worker")
+        from .agent import Actor, Model
+        # with example/dsac.py's own `args` the rollout agent is a whole Model (dsac.py:83), whose "main"
+        # variables include q1, q2, v: pull(keys) must ask for the same key list the learner pushes
+        make_agent = (lambda a: Model(a)) if hasattr(args, "ac_kwargs") else (lambda a: Actor(a, job="worker"))
     env = make_env(args.env)
     o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
     total_steps = args.steps_per_epoch * args.epochs
@@ -87,13 +89,16 @@ def worker_rollout(ps, replay_buffer, args, make_env=None, make_agent=None):
 def worker_train(ps, replay_buffer, args, make_agent=None):
     """example/dsac.py:133-150: pull, then `train; push every 300th update` forever."""
     if make_agent is None:
-        from .agent import Learner
-
-        class _Model(Learner):  # example/model.py:92-101: train = sample_batch RPC + one step
-            def train(self, replay_buffer, args):
-                batch = _get(_remote(replay_buffer.sample_batch, args.batch_size))
-                return super().train(batch)
-        make_agent = lambda a: _Model(a, job="learner")
+        from .agent import Learner, Model
+        if hasattr(args, "ac_kwargs"):
+            # example/dsac.py's own `args` (dsac.py:185-216): its algorithm is the SAC-v of example/model.py
+            make_agent = lambda a: Model(a)
+        else:
+            class _Model(Learner):  # example/model.py:92-101's surface over the SAC1 learner: train = sample_batch RPC + one step
+                def train(self, replay_buffer, args):
+                    batch = _get(_remote(replay_buffer.sample_batch, args.batch_size))
+                    return super().train(batch)
+            make_agent = lambda a: _Model(a, job="learner")
     agent = make_agent(args)
     keys = agent.get_weights()[0]
     weights = _get(_remote(ps.pull, keys))

@@ -141,6 +141,8 @@ int64_t ddrl_ps_version(ddrl_ps_t *h);
 /* network of algos/sac1/core.py:91-121                                                   */
 /* ===================================================================================== */
 typedef struct ddrl_sac1 ddrl_sac1_t;
+#define DDRL_SAC1 0
+#define DDRL_SAC_V 1
 
 typedef struct {
     int32_t obs_dim;   /* 8  LunarLanderContinuous-v2 */
@@ -148,7 +150,7 @@ typedef struct {
     int32_t hidden1;   /* 400  core.py:91 hidden_sizes=(400,300) */
     int32_t hidden2;   /* 300 */
     int32_t batch;     /* 256  hyperparams.py:82 */
-    int32_t reserved;  /* 0 */
+    int32_t variant;   /* DDRL_SAC1 (0): algos/sac1 ; DDRL_SAC_V (1): example/model.py (policy + twin Q + V + target V) */
     /* Python floats in the reference (doubles): each derived constant is rounded to float32
      * exactly where TensorFlow would round it (e.g. float32(1 - polyak), float32(alpha)). */
     double alpha;      /* 0.1    hyperparams.py:60 (fixed, not 'auto') */

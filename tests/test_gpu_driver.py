@@ -200,3 +200,36 @@ def test_checkpoint_resume_formats(tmp_path):
         assert torch.equal(a, b)
     for which in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V):
         assert torch.equal(l1.export(which), l2.export(which))
+
+
+def test_dsac_driver_with_its_own_model():
+    """example/dsac.py:218-238 end to end with its own `args` (ac_kwargs, batch 100, lr 1e-3, alpha 0.2) and its
+    own algorithm (example/model.py's SAC-v): ParameterServer / ReplayBuffer actors, one rollout task, one
+    learner task, weights flow learner -> ps -> rollout."""
+    import distributed_drl_amd as d
+    from distributed_drl_amd import remote as ray
+    from distributed_drl_amd.agent import Model
+
+    class Args:
+        env, obs_dim, act_dim = "LunarLanderContinuous-v2", 8, 2
+        ac_kwargs = dict(hidden_sizes=[64, 64])
+        gamma = 0.99,
+        polyak, lr, alpha, batch_size, seed = 0.995, 1e-3, 0.2, 100, 0
+        replay_size, start_steps, max_ep_len, steps_per_epoch, epochs = 5000, 150, 200, 400, 1
+        push_freq, max_updates = 10, 40
+    args = Args()
+    ray.init()
+    net = Model(args)
+    all_keys, all_values = net.get_weights()
+    assert len(all_keys) == 26
+    ps = ray.remote(d.ParameterServer).remote(all_keys, all_values)
+    rb = ray.remote(d.ReplayBuffer).remote(args.obs_dim, args.act_dim, args.replay_size)
+    t_roll = ray.remote(d.worker_rollout).remote(ps, rb, args)
+    ray.get(t_roll)                                              # 400 env steps stored
+    assert ray.get(rb.get_counts.remote()) == 400
+    v0 = ray.get(ps.pull.remote(all_keys))
+    n = ray.get(ray.remote(d.worker_train).remote(ps, rb, args))  # 40 SAC-v updates, 4 pushes
+    assert n == 40
+    v1 = ray.get(ps.pull.remote(all_keys))
+    assert any((a != b).any() for a, b in zip(v0, v1))
+    assert all(np.isfinite(b).all() for b in v1)

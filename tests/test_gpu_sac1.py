@@ -237,3 +237,62 @@ def test_graph_loop_equals_eager_sample_noise_train(ddrl):
     k1, p1 = rbs[1].mt_state()
     assert p0 == p1 and (k0 == k1).all()
     assert ps.version == v0 + 3 and torch.equal(ps.pull_flat(0, td.agent.n_params), pushed)
+
+
+class _DsacArgs:
+    """What example/dsac.py:185-216 hands to Model(args)."""
+
+    def __init__(self, obs_dim=8, act_dim=2, hid=(400, 300), batch_size=100, seed=0):
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.ac_kwargs = dict(hidden_sizes=list(hid))
+        self.gamma = 0.99,          # dsac.py:198 really sets a 1-tuple
+        self.polyak, self.lr, self.alpha, self.batch_size, self.seed, self.max_ep_len = 0.995, 1e-3, 0.2, batch_size, seed, 1000
+
+
+@pytest.mark.parametrize("hid,batch", [((400, 300), 100), ((64, 48), 37)])
+def test_sacv_model_matches_oracle(ddrl, hid, batch):
+    """N4: the SAC-v learner of example/model.py (policy + twin Q + V + target V, batch 100, lr 1e-3,
+    alpha 0.2 as example/dsac.py sets them): losses within 1e-5 relative of the float64 oracle over
+    the first update (5e-5 over the next four), gradients / parameters / targets within the float32 band,
+    same variable order."""
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import Model
+    from oracle import sacv_oracle as sv
+    args = _DsacArgs(hid=hid, batch_size=batch, seed=3)
+    model = Model(args)
+    cfg = so.Config(obs_dim=8, act_dim=2, hidden1=hid[0], hidden2=hid[1], batch=batch, alpha=0.2, gamma=0.99, lr=1e-3, polyak=0.995)
+    keys, vals = model.get_weights()
+    assert keys == [n for n, _ in sv.param_specs(cfg)]
+    params = sv.init_params(cfg, 3)
+    for k, v in zip(keys, vals):
+        np.testing.assert_array_equal(v, params[k])
+    rs = np.random.RandomState(1)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.05, 0.05, params[k].shape).astype(np.float32)
+    model.set_weights(list(params.keys()), list(params.values()))
+    o64 = sv.SacVOracle(cfg, params, torch.float64, stable=True)
+    for it in range(5):
+        b, eps = so.synthetic_batch(cfg, seed=40 + it)
+        w = o64.step(b, eps[0])
+        losses, (q1, q2, lp) = model.train(b, eps=eps, return_outputs=True)
+        got = losses.cpu().numpy()
+        # identical parameters at update 0: the north star's 1e-5; afterwards the float32 and float64
+        # trajectories drift apart (lr = 1e-3, 20x SAC1's): 5e-5
+        tol = 1e-5 if it == 0 else 5e-5
+        for i, k in enumerate(("pi_loss", "q1_loss", "q2_loss", "v_loss")):
+            assert _rel(got[i], w[k]) <= tol, (it, k, got[i], float(w[k]))
+        np.testing.assert_allclose(q1.cpu().numpy(), w["q1"].numpy(), rtol=5 * tol, atol=5 * tol)
+        np.testing.assert_allclose(lp.cpu().numpy(), w["logp_pi"].numpy(), rtol=5 * tol, atol=5 * tol)
+        if it == 0:
+            g, g64 = model.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
+            assert np.abs(g - g64).max() <= 2e-4 * np.abs(g64).max()
+    a, b64 = model.export(_lib.SAC1_MAIN).cpu().numpy(), o64.flat("main")
+    assert np.abs(a - b64).max() <= 5 * 2e-2 * cfg.lr
+    a, b64 = model.export(_lib.SAC1_TARGET).cpu().numpy(), o64.flat("target")
+    assert np.abs(a - b64).max() <= 5 * 2e-2 * cfg.lr
+    assert model.opt_steps() == (5, 5)
+    # get_action: the policy head of the same variables (deterministic = tanh(mu))
+    obs = b["obs1"][0]
+    mu = sv.policy(o64.main, "main", torch.as_tensor(obs[None].astype(np.float64)), torch.zeros(1, 2, dtype=torch.float64), cfg)[0]
+    np.testing.assert_allclose(model.get_action(obs, True), mu.numpy()[0], rtol=1e-4, atol=1e-5)

@@ -145,3 +145,42 @@ def test_actor_act_matches_learner_policy():
     det = so.actor_act(cfg, p, batch["obs1"], None, deterministic=True)
     np.testing.assert_array_equal(det, out["mu"].numpy())
     assert np.abs(act).max() <= 1.0
+
+
+def test_sacv_oracle_gradients_match_finite_differences():
+    """example/model.py:33-52 restated: autograd gradients of pi_loss (w.r.t. main/pi) and of
+    q1_loss + q2_loss + v_loss (w.r.t. main/q1, q2, v) agree with central differences in float64;
+    the stop_gradient targets carry no gradient (pi_loss does not move q / v variables and v.v.)."""
+    from oracle import sacv_oracle as sv
+    cfg = so.Config(obs_dim=4, act_dim=2, hidden1=12, hidden2=8, batch=6, alpha=0.2, gamma=0.99, lr=1e-3)
+    params = sv.init_params(cfg, 3)
+    rs = np.random.RandomState(0)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.3, 0.3, params[k].shape).astype(np.float32)
+    batch, eps = so.synthetic_batch(cfg, seed=2)
+    o = sv.SacVOracle(cfg, params, torch.float64, stable=True)
+    base_out = o.compute_grads(batch, eps[0])
+    frozen = (base_out["q_backup"], base_out["v_backup"])
+    names = list(o.names)
+    pick = rs.choice(len(names), 10, replace=False)
+    for ni in pick:
+        n = names[ni]
+        g = o.grads[n].numpy().reshape(-1)
+        idx = rs.randint(0, g.size)
+        base = o.main[n].clone()
+        vals = []
+        for sgn in (+1, -1):
+            t = base.clone().reshape(-1)
+            t[idx] += sgn * 1e-6
+            o.main[n] = t.reshape(base.shape)
+            out = o.forward_losses(batch, eps[0], frozen=frozen)
+            vals.append(float(out["pi_loss"]) if "/pi/" in n else float(out["q1_loss"] + out["q2_loss"] + out["v_loss"]))
+        o.main[n] = base
+        fd = (vals[0] - vals[1]) / 2e-6
+        assert abs(fd - g[idx]) <= 1e-6 + 1e-5 * abs(fd), (n, fd, g[idx])
+    # the first Adam step moves every variable with a gradient by ~lr; polyak keeps target within (1-polyak)*lr
+    before = o.flat("main").copy()
+    o.apply_grads()
+    assert np.abs(o.flat("main") - before).max() <= 1.01 * cfg.lr
+    assert len(o.names) == 26 and sum("/v/" in n for n in o.names) == 6
