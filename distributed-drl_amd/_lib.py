@@ -35,6 +35,17 @@ class Sac1Config(ctypes.Structure):
                          adam_eps, act_scale)
 
 
+class DqnConfig(ctypes.Structure):
+    """ddrl_dqn_config_t; defaults = algos/dqn/hyperparams.py."""
+    _fields_ = [("obs_dim", c_int32), ("n_actions", c_int32), ("hidden1", c_int32), ("hidden2", c_int32), ("batch", c_int32),
+                ("reserved", c_int32), ("gamma", c_double), ("lr", c_double), ("polyak", c_double), ("beta1", c_double),
+                ("beta2", c_double), ("adam_eps", c_double)]
+
+    def __init__(self, obs_dim, n_actions, hidden1=400, hidden2=300, batch=128, gamma=0.99, lr=1e-3, polyak=0.995, beta1=0.9,
+                 beta2=0.999, adam_eps=1e-8):
+        super().__init__(obs_dim, n_actions, hidden1, hidden2, batch, 0, gamma, lr, polyak, beta1, beta2, adam_eps)
+
+
 _P = c_void_p  # device pointers and opaque handles cross as void*
 
 # name -> (restype, argtypes).  Must list every symbol include/ddrl.h declares
@@ -100,6 +111,13 @@ SIGNATURES = {
     "ddrl_env_stats": (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), _P]),
     "ddrl_env_get_state": (c_int, [_P, _P, _P]),
     "ddrl_env_set_state": (c_int, [_P, _P, _P]),
+    "ddrl_dqn_param_count": (c_int, [_P, POINTER(c_int64)]),
+    "ddrl_dqn_create": (c_int, [POINTER(_P), c_int, _P]),
+    "ddrl_dqn_destroy": (c_int, [_P]),
+    "ddrl_dqn_set_weights": (c_int, [_P, _P, _P]),
+    "ddrl_dqn_export": (c_int, [_P, c_int, _P, _P]),
+    "ddrl_dqn_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ddrl_dqn_q": (c_int, [_P, _P, c_int64, _P, _P]),
     "ddrl_winq_create": (c_int, [POINTER(_P), c_int, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "ddrl_winq_destroy": (c_int, [_P]),
     "ddrl_winq_begin": (c_int, [_P, _P, _P, _P]),

@@ -1,0 +1,121 @@
+"""Double-DQN learner / actor of the multi-node driver (algos/dqn/actor_learner.py:19-107, 175-201;
+network algos/dqn/core.py:40-50) on the MI355X: `Learner(opt, job)` with set_weights / get_weights /
+train(batch, cnt), `Actor(opt, job)` with get_action(o, deterministic) — same names and argument meaning.
+`opt` carries obs_dim, act_dim (number of discrete actions), hidden_size, gamma, lr, polyak, batch_size, seed
+(algos/dqn/hyperparams.py:26-60)."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def param_specs(obs_dim, n_actions, hidden_size):
+    """(name, shape) in TF variable-creation order: tf.make_template('q1', vf_mlp) under scope 'main'."""
+    h1, h2 = hidden_size
+    return [("main/q1/dense/kernel", (obs_dim, h1)), ("main/q1/dense/bias", (h1,)),
+            ("main/q1/dense_1/kernel", (h1, h2)), ("main/q1/dense_1/bias", (h2,)),
+            ("main/q1/dense_2/kernel", (h2, n_actions)), ("main/q1/dense_2/bias", (n_actions,))]
+
+
+def glorot_init(specs, seed):
+    rs = np.random.RandomState(seed)
+    parts = []
+    for name, shape in specs:
+        if name.endswith("kernel"):
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+            parts.append(rs.uniform(-lim, lim, size=shape).astype(np.float32).reshape(-1))
+        else:
+            parts.append(np.zeros(int(np.prod(shape)), np.float32))
+    return np.concatenate(parts)
+
+
+class Learner:
+    def __init__(self, opt, job="learner", batch=None):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self.opt = opt
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        hs = list(opt.hidden_size)
+        assert len(hs) == 2, "two hidden layers (algos/dqn/hyperparams.py:37)"
+        self.specs = param_specs(opt.obs_dim, opt.act_dim, hs)
+        self.keys = [n for n, _ in self.specs]
+        self.table, off = {}, 0
+        for n, s in self.specs:
+            cnt = int(np.prod(s))
+            self.table[n] = (off, cnt, s)
+            off += cnt
+        self.n_params = off
+        self.cfg = _lib.DqnConfig(opt.obs_dim, opt.act_dim, hs[0], hs[1], int(opt.batch_size if batch is None else batch),
+                                  gamma=opt.gamma, lr=opt.lr, polyak=opt.polyak)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ddrl_dqn_create(ctypes.byref(h), self.device.index, ctypes.byref(self.cfg)))
+        self._h = h
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._flat_set(torch.from_numpy(glorot_init(self.specs, getattr(opt, "seed", 0))).to(self.device))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_dqn_destroy(h)
+
+    def _flat_set(self, flat):
+        flat = flat.to(device=self.device, dtype=torch.float32).contiguous()
+        _lib.check(self._lib.ddrl_dqn_set_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
+
+    def export(self, which=_lib.SAC1_MAIN):
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_dqn_export(self._h, which, _lib.dptr(flat), _lib.stream_ptr()))
+        return flat
+
+    def get_weights(self):
+        flat = self.export().cpu().numpy()
+        return list(self.keys), [flat[o:o + n].reshape(s).copy() for (o, n, s) in (self.table[k] for k in self.keys)]
+
+    def set_weights(self, variable_names, weights):
+        flat = self.export()
+        for k, w in zip(variable_names, weights):
+            if k not in self.table:
+                continue
+            o, n, _ = self.table[k]
+            w = w if torch.is_tensor(w) else torch.from_numpy(np.asarray(w, np.float32))
+            flat[o:o + n] = w.to(self.device).reshape(-1)
+        self._flat_set(flat)
+
+    def _dev(self, x, shape):
+        t = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return t.to(device=self.device, dtype=torch.float32).contiguous().reshape(shape)
+
+    def train(self, batch, cnt=0, return_outputs=False):
+        """sess.run([q_loss, q, train_value_op, target_update]) (actor_learner.py:110-119)."""
+        B = self.cfg.batch
+        x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))
+        a, r, d = self._dev(batch["acts"], (B,)), self._dev(batch["rews"], (B,)), self._dev(batch["done"], (B,))
+        q = torch.empty(B, self.cfg.n_actions, dtype=torch.float32, device=self.device) if return_outputs else None
+        _lib.check(self._lib.ddrl_dqn_step(self._h, _lib.dptr(x), _lib.dptr(x2), _lib.dptr(a), _lib.dptr(r), _lib.dptr(d),
+                                           _lib.dptr(self.loss), _lib.dptr(q), _lib.stream_ptr()))
+        if return_outputs:
+            return self.loss, q
+        return None
+
+    def q_values(self, obs):
+        obs = self._dev(obs, (-1, self.cfg.obs_dim))
+        q = torch.empty(obs.shape[0], self.cfg.n_actions, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_dqn_q(self._h, _lib.dptr(obs), obs.shape[0], _lib.dptr(q), _lib.stream_ptr()))
+        return q
+
+
+class Actor(Learner):
+    """algos/dqn/actor_learner.py:152-201: the q network alone; get_action(o) = argmax q with probability 0.97,
+    a uniform random action otherwise (actor_learner.py:193-201; np.random there, a seeded RandomState here)."""
+
+    def __init__(self, opt, job="worker", max_rows=1):
+        super().__init__(opt, job, batch=max_rows)
+        self._rs = np.random.RandomState(getattr(opt, "seed", 0))
+
+    def get_action(self, o):
+        if self._rs.uniform() < 0.97:
+            return int(np.argmax(self.q_values(np.asarray(o, np.float32)[np.newaxis, :])[0].cpu().numpy()))
+        return int(self._rs.randint(0, self.opt.act_dim))

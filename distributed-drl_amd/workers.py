@@ -118,7 +118,13 @@ def worker_train(ps, replay_buffer, args, make_agent=None):
 
 
 def worker_test(ps, args, start_time=None, n=10, make_env=None, make_agent=None, log=print, max_rounds=None):
-    """example/dsac.py:153-177: pull, run n deterministic episodes, log, repeat."""
+    """example/dsac.py:153-177: pull, run n deterministic episodes, log, repeat.  With `args.logger_kwargs`
+    (dsac.py:205) the rounds also go to an EpochLogger: config.json + progress.txt (AverageTestEpRet, Time)."""
+    logger = None
+    if getattr(args, "logger_kwargs", None):
+        from .logx import EpochLogger
+        logger = EpochLogger(**args.logger_kwargs)
+        logger.save_config({k: v for k, v in vars(args).items()} if hasattr(args, "__dict__") else {})
     if make_env is None:
         make_env = lambda name: _default_env(name, args)
     if make_agent is None:
@@ -134,6 +140,10 @@ def worker_test(ps, args, start_time=None, n=10, make_env=None, make_agent=None,
         agent.set_weights(keys, weights)
         last = agent.test(test_env, None, n)
         log("AverageTestEpRet %.3f  Time %.1f" % (last, time.time() - start_time))
+        if logger is not None:
+            logger.log_tabular('AverageTestEpRet', last)
+            logger.log_tabular('Time', time.time() - start_time)
+            logger.dump_tabular()
         rounds += 1
         if (max_rounds is not None and rounds >= max_rounds) or _stop(args):
             return last

@@ -344,6 +344,33 @@ int ddrl_env_get_state(ddrl_env_t *h, float *state_d, void *stream);
 int ddrl_env_set_state(ddrl_env_t *h, const float *state_d, void *stream);
 
 /* ===================================================================================== */
+/* Double-DQN learner — algos/dqn/actor_learner.py:19-107 (network: algos/dqn/core.py:40-50: */
+/* mlp(obs -> hidden1 -> hidden2 -> n_actions), variables main/q1/dense{,_1,_2}/{kernel,bias}) */
+/* ===================================================================================== */
+typedef struct ddrl_dqn ddrl_dqn_t;
+typedef struct {
+    int32_t obs_dim, n_actions, hidden1, hidden2, batch, reserved;
+    double gamma;      /* 0.99   algos/dqn/hyperparams.py:26 */
+    double lr;         /* 1e-3   :57 */
+    double polyak;     /* 0.995  :58 */
+    double beta1, beta2, adam_eps;  /* tf.train.AdamOptimizer defaults */
+} ddrl_dqn_config_t;
+int ddrl_dqn_param_count(const ddrl_dqn_config_t *cfg, int64_t *n_h);
+int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg);
+int ddrl_dqn_destroy(ddrl_dqn_t *h);
+/* Learner.set_weights (flat "main" vector in variable order) incl. target_init (actor_learner.py:99-101). */
+int ddrl_dqn_set_weights(ddrl_dqn_t *h, const float *flat_main_d, void *stream);
+/* Flat copies of the learner's buffers; `which` = DDRL_SAC1_MAIN / TARGET / ADAM_M / ADAM_V / GRAD. */
+int ddrl_dqn_export(ddrl_dqn_t *h, int which, float *flat_d, void *stream);
+/* Learner.train(batch, cnt) == sess.run([q_loss, q, train_value_op, target_update]) (actor_learner.py:110-119):
+ * acts_d holds the action indices as float32 (the buffer's acts_buf), loss_d[1] and q_d[batch, n_actions]
+ * (either may be NULL) receive q_loss and self.q from the pre-update variables. */
+int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
+                  const float *done_d, float *loss_d, float *q_d, void *stream);
+/* self.q of the main network for n <= batch observations (Actor.get_action, actor_learner.py:193-198). */
+int ddrl_dqn_q(ddrl_dqn_t *h, const float *obs_d, int64_t n, float *q_d, void *stream);
+
+/* ===================================================================================== */
 /* Rollout-side window queues of the n-step driver: per env, o_queue = deque(maxlen=Ln+1) of  */
 /* observations and a_r_d_queue = deque(maxlen=Ln) of (a, r, d) — algos/sac1/sac_ray.py:192-248 */
 /* ===================================================================================== */

@@ -184,3 +184,33 @@ def test_sacv_oracle_gradients_match_finite_differences():
     o.apply_grads()
     assert np.abs(o.flat("main") - before).max() <= 1.01 * cfg.lr
     assert len(o.names) == 26 and sum("/v/" in n for n in o.names) == 6
+
+
+def test_dqn_oracle_gradients_match_finite_differences():
+    """algos/dqn/actor_learner.py:40-62 restated: d q_loss / d main variables (Double-DQN target frozen, as
+    tf.stop_gradient) agrees with central differences in float64."""
+    from oracle import dqn_oracle as do
+    cfg = do.Config(obs_dim=5, n_actions=3, hidden1=10, hidden2=7, batch=9)
+    params = do.init_params(cfg, 1)
+    rs = np.random.RandomState(0)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.3, 0.3, params[k].shape).astype(np.float32)
+    batch = do.synthetic_batch(cfg, 4)
+    o = do.DqnOracle(cfg, params, torch.float64)
+    base = o.forward_loss(batch)
+    ref = do.DqnOracle(cfg, params, torch.float64)
+    ref.step(batch)
+    for n in o.names:
+        g = ref.grads[n].numpy().reshape(-1)
+        idx = rs.randint(0, g.size)
+        keep = o.main[n].clone()
+        vals = []
+        for sgn in (+1, -1):
+            t = keep.clone().reshape(-1)
+            t[idx] += sgn * 1e-6
+            o.main[n] = t.reshape(keep.shape)
+            vals.append(float(o.forward_loss(batch, frozen=base["q_backup"])["q_loss"]))
+        o.main[n] = keep
+        fd = (vals[0] - vals[1]) / 2e-6
+        assert abs(fd - g[idx]) <= 1e-7 + 1e-5 * abs(fd), (n, fd, g[idx])

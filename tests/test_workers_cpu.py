@@ -241,3 +241,22 @@ def test_agent_param_specs_match_oracle_layout():
     cfg = so.Config()
     assert param_specs(8, 2, 400, 300) == so.param_specs(cfg)
     np.testing.assert_array_equal(glorot_init(param_specs(8, 2, 400, 300), 7), so.flatten(so.init_params(cfg, 7)))
+
+
+def test_epoch_logger_progress_file(tmp_path):
+    """The logger slice example/dsac.py:153-177 uses: config.json + tab-separated progress.txt with a header."""
+    from distributed_drl_amd.logx import EpochLogger, setup_logger_kwargs
+    kw = setup_logger_kwargs("dsac", 3, data_dir=str(tmp_path))
+    assert kw["output_dir"].endswith("dsac/dsac_s3")
+    lg = EpochLogger(quiet=True, **kw)
+    lg.save_config(dict(seed=3, env="LunarLanderContinuous-v2", fn=print))
+    for i in range(3):
+        lg.log_tabular("AverageTestEpRet", -100.0 + i)
+        lg.log_tabular("Time", 1.5 * i)
+        lg.dump_tabular()
+    rows = open(tmp_path / "dsac" / "dsac_s3" / "progress.txt").read().strip().split("\n")
+    assert rows[0] == "AverageTestEpRet\tTime" and rows[3] == "-98.0\t3.0" and len(rows) == 4
+    import json
+    assert json.load(open(tmp_path / "dsac" / "dsac_s3" / "config.json"))["exp_name"] == "dsac"
+    with pytest.raises(AssertionError):
+        lg.log_tabular("NewKey", 1)
