@@ -843,9 +843,7 @@ __global__ void __launch_bounds__(256) k_rows_a(RowsA a) {
 struct RowsB {
     const float *H2;
     NetQ q1, q2, q1t, q2t;
-    const float *rew, *done, *logp0, *logp1;
-    float *q1o, *q2o;
-    int own_q;   // 1: Q(x,a) of both critics is computed here (fused forward path: no k_rows_a) and written to q1o/q2o
+    const float *rew, *done, *logp0, *logp1, *q1o, *q2o;
     float *dZ2;  // [4][B][h2]  slots: 0 = q1(x,a), 1 = q2(x,a), 2 = q1(x,pi), 3 = pi
     float *dq4;  // [2][B][4]   (column 0 used; padded so that it is a 16-B aligned GEMM operand)
     float *loss_part;
@@ -870,16 +868,9 @@ __global__ void __launch_bounds__(64) k_rows_b(RowsB a) {
         load_row(a.q2.W3, a.h2, lane, w2);
         load_row(a.q1t.W3, a.h2, lane, w1t);
         load_row(a.q2t.W3, a.h2, lane, w2t);
-        const float rew = a.rew[r], done = a.done[r], lp0 = a.logp0[r], lp1 = a.logp1[r];
-        float q1v = a.q1o[r], q2v = a.q2o[r];
-        const float b1 = a.q1.b3[0], b1t = a.q1t.b3[0], b2t = a.q2t.b3[0], b2 = a.q2.b3[0];
+        const float rew = a.rew[r], done = a.done[r], lp0 = a.logp0[r], lp1 = a.logp1[r], q1v = a.q1o[r], q2v = a.q2o[r];
+        const float b1 = a.q1.b3[0], b1t = a.q1t.b3[0], b2t = a.q2t.b3[0];
         mask_row(w1, a.h2, lane); mask_row(w1t, a.h2, lane); mask_row(w2t, a.h2, lane);
-        if (a.own_q) {  // kernel-uniform
-            mask_row(w2, a.h2, lane);
-            q1v = wave_sum(dot_rv(h3, w1)) + b1;
-            q2v = wave_sum(dot_rv(h4, w2)) + b2;
-            if (lane == 0) { a.q1o[r] = q1v; a.q2o[r] = q2v; }
-        }
         const float q1pi = wave_sum(dot_rv(h5, w1)) + b1;
         const float q1t = wave_sum(dot_rv(h6, w1t)) + b1t;
         const float q2t = wave_sum(dot_rv(h7, w2t)) + b2t;
@@ -1840,7 +1831,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                           h->H1, Pm + L.q_W1[0] + (long long)o * h1, Pt + L.q_W1[0] + (long long)o * h1,
                           Pt + L.q_W1[1] + (long long)o * h1, B, h2, ldh2, a, h1, ldh1, (float)cfg->act_scale};
         h->rb[st] = RowsB{h->H2, net_q(Pm, L, 0), net_q(Pm, L, 1), net_q(Pt, L, 0), net_q(Pt, L, 1), h->in[st][3], h->in[st][4],
-                          h->logp0, h->logp1, h->q1o, h->q2o, h->fused ? 1 : 0, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
+                          h->logp0, h->logp1, h->q1o, h->q2o, h->dZ2, h->dq4, h->loss_part, B, h2, ldh2,
                           (float)cfg->alpha, (float)cfg->gamma};
     }
     h->rc = RowsC{h->H2, h->dZ1 + 2 * BZ1, Pm + L.q_W1[0], net_pi(Pm, L), h->save0, h->dhead, h->dZ2 + 3 * BZ2,

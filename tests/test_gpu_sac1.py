@@ -192,10 +192,12 @@ def test_actor_matches_oracle(ddrl):
     np.testing.assert_array_equal(a1, actor.get_actions(obs[:1], eps=eps[:1]).cpu().numpy()[0])
 
 
-def test_graph_loop_equals_eager_sample_noise_train(ddrl):
-    """ddrl_loop_run (hipGraph, sampler on a forked branch into the alternate input set, noise
-    generated inside the first kernel from the device counter) == the same updates issued one by
-    one through the public surface with ddrl_normal_fill noise — bit for bit."""
+@pytest.mark.parametrize("per_graph", [4, 3])
+def test_graph_loop_equals_eager_sample_noise_train(ddrl, per_graph):
+    """ddrl_loop_run (hipGraph: the fused step with the optimizer in the wgrad epilogues, the next batch's
+    sampler riding in a forward launch into the alternate input set, noise generated from the device counter,
+    double-buffered optimizer state — an odd number of updates per graph ends on a copy node) == the same
+    updates issued one by one through the public surface with ddrl_normal_fill noise — bit for bit."""
     import ctypes
     from distributed_drl_amd import _lib
     from distributed_drl_amd.agent import HyperParameters, Learner
@@ -214,10 +216,10 @@ def test_graph_loop_equals_eager_sample_noise_train(ddrl):
         rbs.append(rb)
     keys, vals = Learner(opt).get_weights()
     ps = ddrl.ParameterServer(keys, vals)
-    td = TrainDevice(ps, rbs[0], opt, updates_per_graph=4)
+    td = TrainDevice(ps, rbs[0], opt, updates_per_graph=per_graph)
     v0 = ps.version
     n_upd = 23
-    td.run(n_upd)          # 1 eager + 5 graph replays of 4 + 2 eager; pushes after updates 7, 14, 21
+    td.run(n_upd)          # eager updates and graph replays mixed (chunks of <= 7 between pushes); pushes after updates 7, 14, 21
     ref = Learner(opt)
     B, a = 256, 2
     pushed = None
