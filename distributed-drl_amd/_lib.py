@@ -38,12 +38,12 @@ class Sac1Config(ctypes.Structure):
 class DqnConfig(ctypes.Structure):
     """ddrl_dqn_config_t; defaults = algos/dqn/hyperparams.py."""
     _fields_ = [("obs_dim", c_int32), ("n_actions", c_int32), ("hidden1", c_int32), ("hidden2", c_int32), ("batch", c_int32),
-                ("reserved", c_int32), ("gamma", c_double), ("lr", c_double), ("polyak", c_double), ("beta1", c_double),
-                ("beta2", c_double), ("adam_eps", c_double)]
+                ("variant", c_int32), ("gamma", c_double), ("lr", c_double), ("polyak", c_double), ("beta1", c_double),
+                ("beta2", c_double), ("adam_eps", c_double), ("alpha", c_double)]
 
     def __init__(self, obs_dim, n_actions, hidden1=400, hidden2=300, batch=128, gamma=0.99, lr=1e-3, polyak=0.995, beta1=0.9,
-                 beta2=0.999, adam_eps=1e-8):
-        super().__init__(obs_dim, n_actions, hidden1, hidden2, batch, 0, gamma, lr, polyak, beta1, beta2, adam_eps)
+                 beta2=0.999, adam_eps=1e-8, variant=0, alpha=0.1):
+        super().__init__(obs_dim, n_actions, hidden1, hidden2, batch, variant, gamma, lr, polyak, beta1, beta2, adam_eps, alpha)
 
 
 _P = c_void_p  # device pointers and opaque handles cross as void*

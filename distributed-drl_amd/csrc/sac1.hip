@@ -2298,6 +2298,10 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
 // q_target = q_next[argmax q_x2]; q_loss = 0.5 mean((r + gamma (1-d) q_target - q[a])^2);
 // one Adam over main/q1, polyak over all.  Every layer (also layer 1: obs_dim is arbitrary here) is a
 // job of the generic MFMA GEMM kernel; 8 launches per update.
+// variant DDRL_SQN = the soft-Q learner of algos/sqn/actor_learner.py:19-78 on algos/sqn/core.py:30-79:
+// twin networks main/q1, main/q2; evaluations q1(x), q1(x2) (its softmax policy's sum p log p at x2),
+// q2(x) and the targets q1_(x2), q2_(x2); v_backup = min(max q1_, max q2_) - alpha * sum p log p;
+// q_loss = 0.5 mean((q_backup - q1[a])^2) + 0.5 mean((q_backup - q2[a])^2); one Adam over main/q1, main/q2.
 // ==========================================================================================
 namespace {
 
@@ -2342,6 +2346,59 @@ __global__ void __launch_bounds__(256) k_dqn_rows(DqnRows a) {
     if (threadIdx.x == 0) a.loss[0] = 0.5f * (s_red[0] / (float)a.B);
 }
 
+// SQN rows.  Q slots: 0 q1(x)  1 q1(x2)  2 q2(x)  3 q1_target(x2)  4 q2_target(x2);  dQ slots: 0 q1, 1 q2.
+struct SqnRows {
+    const float *Q;
+    const float *acts, *rew, *done;
+    float *dQ;     // [2][B][ldq]
+    float *loss;   // [1] q_loss = q1_loss + q2_loss
+    int B, A, ldq;
+    float gamma, alpha;
+};
+__global__ void __launch_bounds__(256) k_sqn_rows(SqnRows a) {
+    __shared__ float s_red[256];
+    float acc = 0.f;
+    const long long BQ = (long long)a.B * a.ldq;
+    for (int r0 = 0; r0 < a.B; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        if (r < a.B) {
+            const float *q1 = a.Q + (long long)r * a.ldq, *q1x2 = q1 + BQ, *q2 = q1x2 + BQ, *q1t = q2 + BQ, *q2t = q1t + BQ;
+            const int act = (int)a.acts[r];
+            const bool valid = act >= 0 && act < a.A;
+            // pi_log = log_softmax(q1(x2) / alpha); "entropy_x2" = sum exp(pi_log) * pi_log  (core.py:32-42)
+            float zmax = q1x2[0] / a.alpha;
+            for (int c = 1; c < a.A; ++c) zmax = fmaxf(zmax, q1x2[c] / a.alpha);
+            float se = 0.f;
+            for (int c = 0; c < a.A; ++c) se += expf(q1x2[c] / a.alpha - zmax);
+            const float lse = logf(se);
+            float plogp = 0.f;
+            for (int c = 0; c < a.A; ++c) {
+                const float pl = (q1x2[c] / a.alpha - zmax) - lse;
+                plogp += expf(pl) * pl;
+            }
+            float m1 = q1t[0], m2 = q2t[0];   // q_mu_ = q_[argmax q_] = max q_ (each target network's own greedy value)
+            for (int c = 1; c < a.A; ++c) { m1 = fmaxf(m1, q1t[c]); m2 = fmaxf(m2, q2t[c]); }
+            const float v_backup = fminf(m1, m2) - a.alpha * plogp;                 // actor_learner.py:47-50
+            const float q_backup = a.rew[r] + (a.gamma * (1.0f - a.done[r])) * v_backup;
+            const float e1 = q_backup - (valid ? q1[act] : 0.f), e2 = q_backup - (valid ? q2[act] : 0.f);
+            acc += e1 * e1 + e2 * e2;
+            const float g1 = -e1 / (float)a.B, g2 = -e2 / (float)a.B;
+            for (int c = 0; c < a.ldq; ++c) {
+                const bool hit = valid && c == act;
+                a.dQ[(long long)r * a.ldq + c] = hit ? g1 : 0.f;
+                a.dQ[BQ + (long long)r * a.ldq + c] = hit ? g2 : 0.f;
+            }
+        }
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loss[0] = 0.5f * (s_red[0] / (float)a.B);
+}
+
 __global__ void __launch_bounds__(256) k_dqn_stage(const float *o1, const float *o2, const float *ac, const float *r, const float *d,
                                                    float *x1, float *x2, float *acts, float *rew, float *done, int B, int obs, int ldx) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -2358,7 +2415,8 @@ __global__ void __launch_bounds__(256) k_dqn_stage(const float *o1, const float 
 struct ddrl_dqn {
     int device;
     ddrl_dqn_config_t cfg;
-    long long W1, b1, W2, b2, W3, b3, total_int, total_ext;
+    int nnet;  // 1 (DDQN) or 2 (SQN: q1, q2)
+    long long W1[2], b1[2], W2[2], b2[2], W3[2], b3[2], total_int, total_ext;
     std::vector<Seg> segs;
     float *slab;
     float *main_p, *target_p, *m, *v, *grad;
@@ -2369,6 +2427,7 @@ struct ddrl_dqn {
     Seg *segs_d;
     GemmJobs g_f1, g_f2, g_f3, g_b3, g_b2, g_b1;
     DqnRows rows;
+    SqnRows srows;
     AdamArgs ad;
 };
 
@@ -2386,12 +2445,14 @@ int ddrl_dqn_param_count(const ddrl_dqn_config_t *c, int64_t *n_h) {
     DDRL_REQUIRE(c != nullptr && n_h != nullptr, "NULL pointer");
     *n_h = (int64_t)c->obs_dim * c->hidden1 + c->hidden1 + (int64_t)c->hidden1 * c->hidden2 + c->hidden2 + (int64_t)c->hidden2 * c->n_actions +
            c->n_actions;
+    if (c->variant == DDRL_SQN) *n_h *= 2;
     return DDRL_OK;
 }
 
 int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) {
     DDRL_REQUIRE(out != nullptr && cfg != nullptr, "NULL pointer");
     DDRL_REQUIRE(cfg->obs_dim > 0 && cfg->n_actions > 0 && cfg->hidden1 > 0 && cfg->hidden2 > 0 && cfg->batch > 0, "dims must be positive");
+    DDRL_REQUIRE(cfg->variant == DDRL_DDQN || (cfg->variant == DDRL_SQN && cfg->alpha > 0.0), "variant must be DDRL_DDQN, or DDRL_SQN with alpha > 0");
     ddrl::DeviceGuard g(device);
     if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
     ddrl_dqn *h = new ddrl_dqn();
@@ -2407,8 +2468,11 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
             if (pad_after) in = pad4(in);
             ext += n;
         };
-        add(h->W1, (long long)o * h1, false); add(h->b1, h1, true); add(h->W2, (long long)h1 * h2, false); add(h->b2, h2, true);
-        add(h->W3, (long long)h2 * A, false); add(h->b3, A, true);
+        h->nnet = cfg->variant == DDRL_SQN ? 2 : 1;
+        for (int n = 0; n < h->nnet; ++n) {
+            add(h->W1[n], (long long)o * h1, false); add(h->b1[n], h1, true); add(h->W2[n], (long long)h1 * h2, false); add(h->b2[n], h2, true);
+            add(h->W3[n], (long long)h2 * A, false); add(h->b3[n], A, true);
+        }
         h->total_int = in; h->total_ext = ext;
     }
     h->ldx = (int)pad4(o + 1); h->ldh1 = (int)pad4(h1 + 1); h->ldh2 = (int)pad4(h2 + 1); h->ldq = (int)pad4(A);
@@ -2420,8 +2484,8 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     const size_t NT = (size_t)h->total_int;
     ALLOC(main_p, NT); ALLOC(target_p, NT); ALLOC(m, NT); ALLOC(v, NT); ALLOC(grad, NT);
     ALLOC(x1, (size_t)B * h->ldx); ALLOC(x2, (size_t)B * h->ldx); ALLOC(acts, B); ALLOC(rew, B); ALLOC(done, B);
-    ALLOC(H1, (size_t)3 * B * h->ldh1); ALLOC(H2, (size_t)3 * B * h->ldh2); ALLOC(Q, (size_t)3 * B * h->ldq); ALLOC(dQ, (size_t)B * h->ldq);
-    ALLOC(dZ2, (size_t)B * h2); ALLOC(dZ1, (size_t)B * h1); ALLOC(loss, 4); ALLOC(qsel, B);
+    ALLOC(H1, (size_t)5 * B * h->ldh1); ALLOC(H2, (size_t)5 * B * h->ldh2); ALLOC(Q, (size_t)5 * B * h->ldq); ALLOC(dQ, (size_t)2 * B * h->ldq);
+    ALLOC(dZ2, (size_t)2 * B * h2); ALLOC(dZ1, (size_t)2 * B * h1); ALLOC(loss, 4); ALLOC(qsel, B);
 #undef ALLOC
     const size_t opt_off = reserve((2 * sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((h->segs.size() * sizeof(Seg) + 3) / 4);
@@ -2446,34 +2510,45 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     }
     k_fill_col<<<(B + 255) / 256, 256>>>(h->x1, B, h->ldx, o, 1.0f);
     k_fill_col<<<(B + 255) / 256, 256>>>(h->x2, B, h->ldx, o, 1.0f);
-    k_fill_col<<<(3 * B + 255) / 256, 256>>>(h->H1, 3ll * B, h->ldh1, h1, 1.0f);
-    k_fill_col<<<(3 * B + 255) / 256, 256>>>(h->H2, 3ll * B, h->ldh2, h2, 1.0f);
+    k_fill_col<<<(5 * B + 255) / 256, 256>>>(h->H1, 5ll * B, h->ldh1, h1, 1.0f);
+    k_fill_col<<<(5 * B + 255) / 256, 256>>>(h->H2, 5ll * B, h->ldh2, h2, 1.0f);
     DDRL_LAUNCH_CHECK();
     DDRL_HIP_CHECK(hipDeviceSynchronize());
     const float *Pm = h->main_p, *Pt = h->target_p;
     const long long BH1 = (long long)B * h->ldh1, BH2 = (long long)B * h->ldh2, BQ = (long long)B * h->ldq;
-    const float *xin[3] = {h->x1, h->x2, h->x2};
-    const float *par[3] = {Pm, Pm, Pt};
-    for (int ev = 0; ev < 3; ++ev) {
-        gemm_add(h->g_f1, gemm_fwd(xin[ev], h->ldx, par[ev] + h->W1, par[ev] + h->b1, h->H1 + ev * BH1, h->ldh1, B, o, h1));
-        gemm_add(h->g_f2, gemm_fwd(h->H1 + ev * BH1, h->ldh1, par[ev] + h->W2, par[ev] + h->b2, h->H2 + ev * BH2, h->ldh2, B, h1, h2));
-        GemmJob j = gemm_fwd(h->H2 + ev * BH2, h->ldh2, par[ev] + h->W3, par[ev] + h->b3, h->Q + ev * BQ, h->ldq, B, h2, A);
+    // evaluations (input, parameters, network): DDQN q(x), q(x2), q_target(x2); SQN q1(x), q1(x2), q2(x), q1_target(x2), q2_target(x2)
+    const bool sqn = cfg->variant == DDRL_SQN;
+    const int nev = sqn ? 5 : 3;
+    const float *xin[5] = {h->x1, h->x2, sqn ? h->x1 : h->x2, h->x2, h->x2};
+    const float *par[5] = {Pm, Pm, sqn ? Pm : Pt, Pt, Pt};
+    const int net[5] = {0, 0, sqn ? 1 : 0, 0, 1};
+    for (int ev = 0; ev < nev; ++ev) {
+        const int n = net[ev];
+        gemm_add(h->g_f1, gemm_fwd(xin[ev], h->ldx, par[ev] + h->W1[n], par[ev] + h->b1[n], h->H1 + ev * BH1, h->ldh1, B, o, h1));
+        gemm_add(h->g_f2, gemm_fwd(h->H1 + ev * BH1, h->ldh1, par[ev] + h->W2[n], par[ev] + h->b2[n], h->H2 + ev * BH2, h->ldh2, B, h1, h2));
+        GemmJob j = gemm_fwd(h->H2 + ev * BH2, h->ldh2, par[ev] + h->W3[n], par[ev] + h->b3[n], h->Q + ev * BQ, h->ldq, B, h2, A);
         j.relu = 0;
         gemm_add(h->g_f3, j);
     }
     float *G = h->grad;
-    {   // dZ2 = (dQ * W3^T) .* (H2 > 0): A = dQ [B x A] (row stride ldq), B(k, j) = W3[j * A + k]
-        GemmJob j{};
-        j.adam_off = -1;
-        j.A = h->dQ; j.B = Pm + h->W3; j.C = h->dZ2; j.bias = nullptr; j.mask = h->H2;
-        j.M = B; j.N = h2; j.K = A; j.lda = h->ldq; j.ldb = A; j.ldc = h2; j.ldmask = h->ldh2; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
-        set_fast(j);
-        gemm_add(h->g_b3, j);
+    const int gev[2] = {0, 2};  // differentiated evaluation of network n: q(x) / q1(x), q2(x)
+    for (int n = 0; n < h->nnet; ++n) {
+        const int ev = gev[n];
+        float *dQ = h->dQ + (long long)n * BQ, *dZ2 = h->dZ2 + (long long)n * B * h2, *dZ1 = h->dZ1 + (long long)n * B * h1;
+        {   // dZ2 = (dQ * W3^T) .* (H2 > 0): A = dQ [B x A] (row stride ldq), B(k, j) = W3[j * A + k]
+            GemmJob j{};
+            j.adam_off = -1;
+            j.A = dQ; j.B = Pm + h->W3[n]; j.C = dZ2; j.bias = nullptr; j.mask = h->H2 + ev * BH2;
+            j.M = B; j.N = h2; j.K = A; j.lda = h->ldq; j.ldb = A; j.ldc = h2; j.ldmask = h->ldh2; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
+            set_fast(j);
+            gemm_add(h->g_b3, j);
+        }
+        gemm_add(h->g_b3, gemm_wgrad(h->H2 + ev * BH2, h->ldh2, h2, dQ, h->ldq, A, G + h->W3[n], A, B));
+        gemm_add(h->g_b2, gemm_dgrad(dZ2, Pm + h->W2[n], h->H1 + ev * BH1, h->ldh1, dZ1, B, h1, h2));
+        gemm_add(h->g_b2, gemm_wgrad(h->H1 + ev * BH1, h->ldh1, h1, dZ2, h2, h2, G + h->W2[n], h2, B));
+        gemm_add(h->g_b1, gemm_wgrad(h->x1, h->ldx, o, dZ1, h1, h1, G + h->W1[n], h1, B));
     }
-    gemm_add(h->g_b3, gemm_wgrad(h->H2, h->ldh2, h2, h->dQ, h->ldq, A, G + h->W3, A, B));
-    gemm_add(h->g_b2, gemm_dgrad(h->dZ2, Pm + h->W2, h->H1, h->ldh1, h->dZ1, B, h1, h2));
-    gemm_add(h->g_b2, gemm_wgrad(h->H1, h->ldh1, h1, h->dZ2, h2, h2, G + h->W2, h2, B));
-    gemm_add(h->g_b1, gemm_wgrad(h->x1, h->ldx, o, h->dZ1, h1, h1, G + h->W1, h1, B));
+    h->srows = SqnRows{h->Q, h->acts, h->rew, h->done, h->dQ, h->loss, B, A, h->ldq, (float)cfg->gamma, (float)cfg->alpha};
     h->rows = DqnRows{h->Q, h->acts, h->rew, h->done, h->dQ, h->loss, h->qsel, B, A, h->ldq, (float)cfg->gamma};
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, h->total_int, 0, 0,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
@@ -2513,7 +2588,8 @@ int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const
     launch_gemm(h->g_f1, s);
     launch_gemm(h->g_f2, s);
     launch_gemm(h->g_f3, s);
-    k_dqn_rows<<<1, 256, 0, s>>>(h->rows);
+    if (h->cfg.variant == DDRL_SQN) k_sqn_rows<<<1, 256, 0, s>>>(h->srows);
+    else k_dqn_rows<<<1, 256, 0, s>>>(h->rows);
     launch_gemm(h->g_b3, s);
     launch_gemm(h->g_b2, s);
     launch_gemm(h->g_b1, s);

@@ -12,12 +12,15 @@ import torch
 from . import _lib
 
 
-def param_specs(obs_dim, n_actions, hidden_size):
-    """(name, shape) in TF variable-creation order: tf.make_template('q1', vf_mlp) under scope 'main'."""
+def param_specs(obs_dim, n_actions, hidden_size, nets=("q1",)):
+    """(name, shape) in TF variable-creation order: tf.make_template('q1', vf_mlp) [, 'q2'] under scope 'main'."""
     h1, h2 = hidden_size
-    return [("main/q1/dense/kernel", (obs_dim, h1)), ("main/q1/dense/bias", (h1,)),
-            ("main/q1/dense_1/kernel", (h1, h2)), ("main/q1/dense_1/bias", (h2,)),
-            ("main/q1/dense_2/kernel", (h2, n_actions)), ("main/q1/dense_2/bias", (n_actions,))]
+    specs = []
+    for q in nets:
+        specs += [("main/%s/dense/kernel" % q, (obs_dim, h1)), ("main/%s/dense/bias" % q, (h1,)),
+                  ("main/%s/dense_1/kernel" % q, (h1, h2)), ("main/%s/dense_1/bias" % q, (h2,)),
+                  ("main/%s/dense_2/kernel" % q, (h2, n_actions)), ("main/%s/dense_2/bias" % q, (n_actions,))]
+    return specs
 
 
 def glorot_init(specs, seed):
@@ -33,6 +36,9 @@ def glorot_init(specs, seed):
 
 
 class Learner:
+    NETS = ("q1",)
+    VARIANT = 0  # DDRL_DDQN
+
     def __init__(self, opt, job="learner", batch=None):
         _lib.require_gpu()
         self._lib = _lib.load()
@@ -40,7 +46,7 @@ class Learner:
         self.device = torch.device("cuda", torch.cuda.current_device())
         hs = list(opt.hidden_size)
         assert len(hs) == 2, "two hidden layers (algos/dqn/hyperparams.py:37)"
-        self.specs = param_specs(opt.obs_dim, opt.act_dim, hs)
+        self.specs = param_specs(opt.obs_dim, opt.act_dim, hs, self.NETS)
         self.keys = [n for n, _ in self.specs]
         self.table, off = {}, 0
         for n, s in self.specs:
@@ -49,7 +55,8 @@ class Learner:
             off += cnt
         self.n_params = off
         self.cfg = _lib.DqnConfig(opt.obs_dim, opt.act_dim, hs[0], hs[1], int(opt.batch_size if batch is None else batch),
-                                  gamma=opt.gamma, lr=opt.lr, polyak=opt.polyak)
+                                  gamma=opt.gamma, lr=opt.lr, polyak=opt.polyak, variant=self.VARIANT,
+                                  alpha=float(getattr(opt, "alpha", 0.1)))
         h = ctypes.c_void_p()
         _lib.check(self._lib.ddrl_dqn_create(ctypes.byref(h), self.device.index, ctypes.byref(self.cfg)))
         self._h = h
@@ -119,3 +126,27 @@ class Actor(Learner):
         if self._rs.uniform() < 0.97:
             return int(np.argmax(self.q_values(np.asarray(o, np.float32)[np.newaxis, :])[0].cpu().numpy()))
         return int(self._rs.randint(0, self.opt.act_dim))
+
+
+class LearnerSQN(Learner):
+    """algos/sqn/actor_learner.py:19-131 (twin soft-Q networks main/q1, main/q2; step_ops = [q_loss, q1, q2, ...]):
+    same surface as Learner; `opt.alpha` is the softmax policy's temperature (hyperparams.py:27)."""
+    NETS = ("q1", "q2")
+    VARIANT = 1  # DDRL_SQN
+
+
+class ActorSQN(LearnerSQN):
+    """algos/sqn/actor_learner.py:134-201: get_action(o, deterministic) = argmax of / a sample from
+    softmax(q1(o) / alpha) (core.py:30-42; tf.random.multinomial there, a seeded RandomState here)."""
+
+    def __init__(self, opt, job="worker", max_rows=1):
+        super().__init__(opt, job, batch=max_rows)
+        self._rs = np.random.RandomState(getattr(opt, "seed", 0))
+
+    def get_action(self, o, deterministic=False):
+        q = self.q_values(np.asarray(o, np.float32)[np.newaxis, :])[0].cpu().numpy().astype(np.float64)
+        if deterministic:
+            return int(np.argmax(q))
+        z = q / float(self.opt.alpha)
+        p = np.exp(z - z.max())
+        return int(self._rs.choice(len(p), p=p / p.sum()))

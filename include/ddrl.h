@@ -348,12 +348,15 @@ int ddrl_env_set_state(ddrl_env_t *h, const float *state_d, void *stream);
 /* mlp(obs -> hidden1 -> hidden2 -> n_actions), variables main/q1/dense{,_1,_2}/{kernel,bias}) */
 /* ===================================================================================== */
 typedef struct ddrl_dqn ddrl_dqn_t;
+#define DDRL_DDQN 0
+#define DDRL_SQN 1   /* algos/sqn/actor_learner.py:19-78 on algos/sqn/core.py:30-79: twin soft-Q networks main/q1, main/q2 */
 typedef struct {
-    int32_t obs_dim, n_actions, hidden1, hidden2, batch, reserved;
+    int32_t obs_dim, n_actions, hidden1, hidden2, batch, variant;
     double gamma;      /* 0.99   algos/dqn/hyperparams.py:26 */
     double lr;         /* 1e-3   :57 */
     double polyak;     /* 0.995  :58 */
     double beta1, beta2, adam_eps;  /* tf.train.AdamOptimizer defaults */
+    double alpha;      /* SQN only: 0.1  algos/sqn/hyperparams.py:27 (temperature of the softmax policy, > 0) */
 } ddrl_dqn_config_t;
 int ddrl_dqn_param_count(const ddrl_dqn_config_t *cfg, int64_t *n_h);
 int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg);
@@ -367,7 +370,7 @@ int ddrl_dqn_export(ddrl_dqn_t *h, int which, float *flat_d, void *stream);
  * (either may be NULL) receive q_loss and self.q from the pre-update variables. */
 int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
                   const float *done_d, float *loss_d, float *q_d, void *stream);
-/* self.q of the main network for n <= batch observations (Actor.get_action, actor_learner.py:193-198). */
+/* self.q of the main network (SQN: q1) for n <= batch observations (Actor.get_action, actor_learner.py:193-198). */
 int ddrl_dqn_q(ddrl_dqn_t *h, const float *obs_d, int64_t n, float *q_d, void *stream);
 
 /* ===================================================================================== */

@@ -105,3 +105,59 @@ def synthetic_batch(cfg, seed=0):
     return dict(obs1=rs.randn(n, cfg.obs_dim).astype(np.float32), obs2=rs.randn(n, cfg.obs_dim).astype(np.float32),
                 acts=rs.randint(0, cfg.n_actions, n).astype(np.float32), rews=rs.randn(n).astype(np.float32),
                 done=(rs.rand(n) < 0.05).astype(np.float32))
+
+
+# ---- SQN (algos/sqn/actor_learner.py:19-78, algos/sqn/core.py:30-79) -----------------------------------
+def sqn_param_specs(cfg):
+    out = []
+    for q in ("q1", "q2"):
+        out += [(n.replace("/q1/", "/%s/" % q), s) for n, s in param_specs(cfg)]
+    return out
+
+
+def sqn_init_params(cfg, seed=0):
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for name, shape in sqn_param_specs(cfg):
+        if name.endswith("kernel"):
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            out[name] = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
+    return out
+
+
+def _mlp(p, prefix, x):
+    h = torch.relu(x @ p[prefix + "/dense/kernel"] + p[prefix + "/dense/bias"])
+    h = torch.relu(h @ p[prefix + "/dense_1/kernel"] + p[prefix + "/dense_1/bias"])
+    return h @ p[prefix + "/dense_2/kernel"] + p[prefix + "/dense_2/bias"]
+
+
+class SqnOracle(DqnOracle):
+    def __init__(self, cfg, params, alpha=0.1, dtype=torch.float32):
+        self.cfg, self.dtype, self.alpha = cfg, dtype, alpha
+        self.names = [n for n, _ in sqn_param_specs(cfg)]
+        self.main = OrderedDict((n, torch.tensor(np.asarray(params[n]), dtype=dtype).clone()) for n in self.names)
+        self.target = OrderedDict((n.replace("main/", "target/", 1), v.clone()) for n, v in self.main.items())
+        self.m = OrderedDict((n, torch.zeros_like(v)) for n, v in self.main.items())
+        self.v = OrderedDict((n, torch.zeros_like(v)) for n, v in self.main.items())
+        one = torch.tensor(1.0, dtype=dtype)
+        self.b1p, self.b2p = one * cfg.beta1, one * cfg.beta2
+        self.grads = None
+
+    def forward_loss(self, batch, main=None, frozen=None):
+        c = self.cfg
+        p = self.main if main is None else main
+        x, x2, r, d = self._t(batch["obs1"]), self._t(batch["obs2"]), self._t(batch["rews"]), self._t(batch["done"])
+        a = torch.as_tensor(np.asarray(batch["acts"])).to(torch.int64)
+        q1, q1_x2, q2 = _mlp(p, "main/q1", x), _mlp(p, "main/q1", x2), _mlp(p, "main/q2", x)
+        pi_log = torch.log_softmax(q1_x2 / self.alpha, dim=1)
+        entropy_x2 = (torch.exp(pi_log) * pi_log).sum(1)                     # core.py:41 ("exact entropy", sign as in the source)
+        q1_t, q2_t = _mlp(self.target, "target/q1", x2), _mlp(self.target, "target/q2", x2)
+        q1_mu_, q2_mu_ = q1_t.max(1).values, q2_t.max(1).values              # q * one_hot(argmax log_softmax(q / alpha))
+        one_hot = torch.nn.functional.one_hot(a, c.n_actions).to(self.dtype)
+        q1_a, q2_a = (q1 * one_hot).sum(1), (q2 * one_hot).sum(1)
+        v_backup = (torch.minimum(q1_mu_, q2_mu_) - self.alpha * entropy_x2).detach()
+        q_backup = r + c.gamma * (1 - d) * v_backup if frozen is None else frozen
+        q_loss = 0.5 * ((q_backup - q1_a) ** 2).mean() + 0.5 * ((q_backup - q2_a) ** 2).mean()
+        return dict(q_loss=q_loss, q=q1, q2=q2, q_backup=q_backup)

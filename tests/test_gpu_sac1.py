@@ -340,3 +340,42 @@ def test_ddqn_learner_matches_oracle(ddrl, obs, acts, hid, batch):
     x = b["obs1"][:1]
     qv = do.q_net(o64.main, "main", torch.as_tensor(x.astype(np.float64)))[0].numpy()
     np.testing.assert_allclose(actor.q_values(x)[0].cpu().numpy(), qv, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("obs,acts,hid,batch", [(8, 4, (400, 300), 128), (6, 5, (40, 28), 50)])
+def test_sqn_learner_matches_oracle(ddrl, obs, acts, hid, batch):
+    """N4: soft-Q learner (algos/sqn/actor_learner.py:19-78): q_loss (= q1_loss + q2_loss) within 1e-5 relative of the
+    float64 oracle on the first update (5e-5 over the next three), q1 output, gradients, parameters, targets."""
+    from distributed_drl_amd import _lib, dqn
+    from oracle import dqn_oracle as do
+
+    class Opt:
+        obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed, alpha = obs, acts, list(hid), 0.99, 1e-3, 0.995, batch, 2, 0.1
+    learner = dqn.LearnerSQN(Opt, "learner")
+    cfg = do.Config(obs_dim=obs, n_actions=acts, hidden1=hid[0], hidden2=hid[1], batch=batch)
+    keys, vals = learner.get_weights()
+    assert keys == [n for n, _ in do.sqn_param_specs(cfg)]
+    params = do.sqn_init_params(cfg, 2)
+    for k, v in zip(keys, vals):
+        np.testing.assert_array_equal(v, params[k])
+    rs = np.random.RandomState(3)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.1, 0.1, params[k].shape).astype(np.float32)
+    learner.set_weights(list(params.keys()), list(params.values()))
+    o64 = do.SqnOracle(cfg, params, 0.1, torch.float64)
+    for it in range(4):
+        b = do.synthetic_batch(cfg, 20 + it)
+        w = o64.step(b)
+        loss, q = learner.train(b, it, return_outputs=True)
+        tol = 1e-5 if it == 0 else 5e-5
+        assert _rel(loss.item(), w["q_loss"]) <= tol, (it, loss.item(), float(w["q_loss"]))
+        np.testing.assert_allclose(q.cpu().numpy(), w["q"].numpy(), rtol=10 * tol, atol=10 * tol)
+        if it == 0:
+            g, g64 = learner.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
+            assert np.abs(g - g64).max() <= 2e-4 * np.abs(g64).max()
+    for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target")):
+        assert np.abs(learner.export(which).cpu().numpy() - o64.flat(name)).max() <= 4 * 2e-2 * cfg.lr
+    actor = dqn.ActorSQN(Opt, "worker")
+    actor.set_weights(*learner.get_weights())
+    assert 0 <= actor.get_action(b["obs1"][0]) < acts and 0 <= actor.get_action(b["obs1"][0], True) < acts

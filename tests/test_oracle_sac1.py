@@ -214,3 +214,34 @@ def test_dqn_oracle_gradients_match_finite_differences():
         o.main[n] = keep
         fd = (vals[0] - vals[1]) / 2e-6
         assert abs(fd - g[idx]) <= 1e-7 + 1e-5 * abs(fd), (n, fd, g[idx])
+
+
+def test_sqn_oracle_gradients_match_finite_differences():
+    """algos/sqn/actor_learner.py:40-56: d q_loss / d (main/q1, main/q2) with v_backup frozen (tf.stop_gradient:
+    the softmax term at x2 depends on main/q1) agrees with central differences in float64."""
+    from oracle import dqn_oracle as do
+    cfg = do.Config(obs_dim=5, n_actions=3, hidden1=10, hidden2=7, batch=9)
+    params = do.sqn_init_params(cfg, 1)
+    rs = np.random.RandomState(0)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.3, 0.3, params[k].shape).astype(np.float32)
+    batch = do.synthetic_batch(cfg, 4)
+    o = do.SqnOracle(cfg, params, 0.1, torch.float64)
+    base = o.forward_loss(batch)
+    ref = do.SqnOracle(cfg, params, 0.1, torch.float64)
+    ref.step(batch)
+    assert len(o.names) == 12
+    for n in o.names:
+        g = ref.grads[n].numpy().reshape(-1)
+        idx = rs.randint(0, g.size)
+        keep = o.main[n].clone()
+        vals = []
+        for sgn in (+1, -1):
+            t = keep.clone().reshape(-1)
+            t[idx] += sgn * 1e-6
+            o.main[n] = t.reshape(keep.shape)
+            vals.append(float(o.forward_loss(batch, frozen=base["q_backup"])["q_loss"]))
+        o.main[n] = keep
+        fd = (vals[0] - vals[1]) / 2e-6
+        assert abs(fd - g[idx]) <= 1e-7 + 1e-5 * abs(fd), (n, fd, g[idx])
