@@ -1470,7 +1470,7 @@ struct ddrl_sac1 {
     ddrl_replay_dev::RingPtrs smp_ring;
     int smp_set;
     GemmJobs g_bpi_f;    // fused path: the policy backward launch also carries the Q layer-2/head wgrads
-    float *hp;           // head partials [NEVAL][FH][nt2][B]
+    float *hp;           // head partials [NEVAL][FH][B][F_MAXNT]
     float *w2snap;       // fused path: this update's copy of the policy W2 (read by the policy dgrad)
     bool fused_l1_wgrad;  // pi layer-1 wgrad via dgrad-epilogue partials + Adam (needs hidden1 % 4 == 0)
     // set by ddrl_sac1_fill_noise, consumed by the next compute_grads / apply_grads
@@ -1629,7 +1629,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(vo, B); ALLOC(vto, B); ALLOC(dq4, (size_t)3 * B * 4); ALLOC(dhead, (size_t)B * h->ldd);
     ALLOC(loss_part, (size_t)h->rows_b_blocks * 4); ALLOC(losses, 4);
     const int nt2 = (h2 + 31) / 32;
-    ALLOC(hp, (size_t)NEVAL * FH * nt2 * B);
+    ALLOC(hp, (size_t)NEVAL * FH * B * F_MAXNT);
     ALLOC(w2snap, (size_t)h1 * h2 + 64);
 #undef ALLOC
     const size_t opt_off = reserve((2 * sizeof(OptState) + 3) / 4);
@@ -1730,7 +1730,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     h->fused = fused_ok(*cfg, L) && getenv("DDRL_SAC1_GENERIC") == nullptr;
     for (int st = 0; st < 2 && h->fused; ++st) {
         float *x = h->in[st][0], *x2 = h->in[st][1], *ac = h->in[st][2];
-        const long long HP = (long long)FH * nt2 * B;
+        const long long HP = (long long)FH * B * F_MAXNT;
         auto base = [&](FwdArgs &F, int njobs) {
             F = FwdArgs{};
             F.njobs = njobs; F.tiles_n = nt2;

@@ -38,9 +38,9 @@ struct FwdJob {
                              // optimizer step: the policy dgrad must not read W2 while the wgrad tiles update it in place)
     const float *wh0, *wh1;  // head kernels — policy: Wmu, Wls ([h2][act]); Q: W3 ([h2]), unused
     int nh, hsplit, hstride; // heads; heads < hsplit come from wh0, the rest from wh1; element stride between rows of a head kernel
-    float *hp;               // head partials [nh][nt2][B]
+    float *hp;               // head partials [nh][B][F_MAXNT] (n-tile innermost: a consumer reads its row's partials as four float4; slots >= nt2 stay 0)
     // phase 1: the policy evaluation whose sampled action is this job's second input
-    const float *php;        // [2*act][nt2][B]
+    const float *php;        // [2*act][B][F_MAXNT]
     const float *pbmu, *pbls;
     const float *peps;       // [B][act]
     int side;                // n-tile-0 workgroups: 1 -> act0, logp0, save0   2 -> act2, and logp1 from the evaluation below
@@ -234,13 +234,13 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
         for (int e = 0; e < 2; ++e) {
             if (e == 0 || two) {
                 const float *hp = e == 0 ? jb.php : a.php1;
-                float v[F_MAXNT];
+                const float4 *p4 = reinterpret_cast<const float4 *>(hp + ((long long)(okc ? c : 0) * B + m0 + r) * F_MAXNT);
+                float4 v[F_MAXNT / 4];
 #pragma unroll
-                for (int q = 0; q < F_MAXNT; ++q)
-                    v[q] = hp[(okc && q < a.nt2) ? ((long long)c * a.nt2 + q) * B + m0 + r : 0];
+                for (int q = 0; q < F_MAXNT / 4; ++q) v[q] = p4[q];
                 float s = 0.f;
 #pragma unroll
-                for (int q = 0; q < F_MAXNT; ++q) s += (q < a.nt2) ? v[q] : 0.f;
+                for (int q = 0; q < F_MAXNT / 4; ++q) { s += v[q].x; s += v[q].y; s += v[q].z; s += v[q].w; }  // n-tile order; unused slots are 0
                 hsum[e] = s;
             }
         }
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
             float s = 0.f;
 #pragma unroll
             for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
-            jb.hp[((long long)c * a.nt2 + nt) * B + m0 + r] = s;
+            jb.hp[((long long)c * B + m0 + r) * F_MAXNT + nt] = s;
         }
     }
     STAMP(10);
@@ -469,7 +469,7 @@ struct BqHead {
 struct BqArgs {
     BqHead hd;
     int tiles_n, ks_max, op_lds, B, ldh1, ldh2, nt2;
-    const float *hp;   // head partials [NEVAL][FH][nt2][B]
+    const float *hp;   // head partials [NEVAL][FH][B][F_MAXNT]
     const float *b3q1, *b3q2, *b3q1t, *b3q2t;
     const float *rew, *done, *logp0, *logp1;
     float *q1o, *q2o, *dq4, *loss_part;
@@ -535,13 +535,13 @@ __global__ void __launch_bounds__(256) k_bwdq(const float *pbase, int tiles_m, i
     if (need_q) {
         const int c = tid >> 5, r = tid & 31;
         const bool okc = c < 5;
-        const long long HP = (long long)FH * a.nt2 * B;
-        const float *hp = a.hp + (3 + (okc ? c : 0)) * HP;
-        float v[F_MAXNT];
+        const long long HP = (long long)FH * B * F_MAXNT;
+        const float4 *p4 = reinterpret_cast<const float4 *>(a.hp + (3 + (okc ? c : 0)) * HP + (long long)(m0 + r) * F_MAXNT);
+        float4 v[F_MAXNT / 4];
 #pragma unroll
-        for (int q = 0; q < F_MAXNT; ++q) v[q] = hp[(q < a.nt2) ? (long long)q * B + m0 + r : m0 + r];
+        for (int q = 0; q < F_MAXNT / 4; ++q) v[q] = p4[q];
 #pragma unroll
-        for (int q = 0; q < F_MAXNT; ++q) qsum += (q < a.nt2) ? v[q] : 0.f;
+        for (int q = 0; q < F_MAXNT / 4; ++q) { qsum += v[q].x; qsum += v[q].y; qsum += v[q].z; qsum += v[q].w; }
         if (w == 0) { rew = a.rew[m0 + l31]; done = a.done[m0 + l31]; lp0 = a.logp0[m0 + l31]; lp1 = a.logp1[m0 + l31]; }
     }
     const float b3_1 = a.b3q1[0], b3_2 = a.b3q2[0], b3_1t = a.b3q1t[0], b3_2t = a.b3q2t[0];
