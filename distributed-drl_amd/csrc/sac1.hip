@@ -61,6 +61,8 @@ struct GemmJob {
     // parameter adam_off + i*ldc + j of the flat buffers (-1: none).  For the job with the fused
     // layer-1 partials, adam_off addresses row 0 of that layer-1 kernel (its bias row follows it).
     long long adam_off;
+    int vec_epi;  // plain wgrad-style epilogue (no bias / relu / mask / partials) with 16-B aligned rows: each thread owns four
+                  // consecutive columns of one row — C and the optimizer state move as float4 (5 + 4 wide accesses instead of 20 + 16)
 };
 // Adam + polyak applied by the workgroup that produced a gradient tile (every wgrad tile is complete
 // inside one workgroup: in-workgroup split-K).  The one gradient that is NOT complete inside a
@@ -596,7 +598,16 @@ __global__ void __launch_bounds__(256) k_gemm(int total_tiles, int ts1, int ts2,
         al_pi = jobs.ad.lr * sqrtf(1.0f - b2p_pi) / (1.0f - b1p_pi);
         al_q = jobs.ad.lr * sqrtf(1.0f - b2p_q) / (1.0f - b1p_q);
     }
-    if (do_adam) {
+    const bool vec = jb.vec_epi != 0;  // block-uniform
+    if (do_adam && vec) {
+        const int vrow = tid >> 3, vc4 = (tid & 7) * 4;
+        const bool vok = m0 + vrow < jb.M && n0 + vc4 < jb.N;
+        const long long ic = vok ? jb.adam_off + (long long)(m0 + vrow) * jb.ldc + n0 + vc4 : jb.adam_off;
+        const float4 m4 = *reinterpret_cast<const float4 *>(jobs.ad.m + ic), v4 = *reinterpret_cast<const float4 *>(jobs.ad.v + ic);
+        const float4 p4 = *reinterpret_cast<const float4 *>(jobs.ad.p + ic), t4 = *reinterpret_cast<const float4 *>(jobs.ad.t + ic);
+        am[0] = m4.x; am[1] = m4.y; am[2] = m4.z; am[3] = m4.w; av[0] = v4.x; av[1] = v4.y; av[2] = v4.z; av[3] = v4.w;
+        ap[0] = p4.x; ap[1] = p4.y; ap[2] = p4.z; ap[3] = p4.w; at[0] = t4.x; at[1] = t4.y; at[2] = t4.z; at[3] = t4.w;
+    } else if (do_adam) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o = tid + 256 * q;
@@ -631,6 +642,27 @@ __global__ void __launch_bounds__(256) k_gemm(int total_tiles, int ts1, int ts2,
     for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
     __syncthreads();
     float outv[4];
+    if (vec) {
+        const int vrow = tid >> 3, vc4 = (tid & 7) * 4;
+        const bool vok = m0 + vrow < jb.M && n0 + vc4 < jb.N;  // N % 4 == 0: the four columns are valid together
+        const long long vidx = jb.adam_off + (long long)(m0 + vrow) * jb.ldc + n0 + vc4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            outv[e] = ((red[0][vrow][vc4 + e] + red[1][vrow][vc4 + e]) + red[2][vrow][vc4 + e]) + red[3][vrow][vc4 + e];
+        if (vok) {
+            *reinterpret_cast<float4 *>(jb.C + (long long)(m0 + vrow) * jb.ldc + n0 + vc4) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+            if (do_adam) {
+                const float al = vidx < jobs.ad.n_pi ? al_pi : al_q;  // a tile never straddles the two optimizers (pairs are 16-B aligned)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    adam1(outv[e], am[e], av[e], ap[e], at[e], 1.0f - jobs.ad.b1, 1.0f - jobs.ad.b2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                *reinterpret_cast<float4 *>(jobs.ad.m + vidx) = make_float4(am[0], am[1], am[2], am[3]);
+                *reinterpret_cast<float4 *>(jobs.ad.v + vidx) = make_float4(av[0], av[1], av[2], av[3]);
+                *reinterpret_cast<float4 *>(jobs.ad.p + vidx) = make_float4(ap[0], ap[1], ap[2], ap[3]);
+                *reinterpret_cast<float4 *>(jobs.ad.t + vidx) = make_float4(at[0], at[1], at[2], at[3]);
+            }
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int o = tid + 256 * q;
@@ -653,6 +685,7 @@ __global__ void __launch_bounds__(256) k_gemm(int total_tiles, int ts1, int ts2,
             adam1(v, am[q], av[q], ap[q], at[q], 1.0f - jobs.ad.b1, 1.0f - jobs.ad.b2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
             jobs.ad.m[idx] = am[q]; jobs.ad.v[idx] = av[q]; jobs.ad.p[idx] = ap[q]; jobs.ad.t[idx] = at[q];
         }
+    }
     }
     if (jb.part) {  // block-uniform
         __syncthreads();
@@ -1352,6 +1385,7 @@ static size_t gemm_smem(const GemmJobs &js) {
     return a > b ? a : b;
 }
 static void gemm_add(GemmJobs &js, GemmJob j) {
+    j.vec_epi = (!j.bias && !j.mask && !j.relu && !j.part && j.N % 4 == 0 && j.ldc % 4 == 0 && (((uintptr_t)j.C) & 15) == 0) ? 1 : 0;
     j.tiles_n = (j.N + 31) / 32;
     j.ntiles = ((j.M + 31) / 32) * j.tiles_n;
     j.tile_start = js.total_tiles;
