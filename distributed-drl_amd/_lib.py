@@ -92,6 +92,7 @@ SIGNATURES = {
     "ddrl_sac1_step_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_apply_grads_and_sample": (c_int, [_P, _P, c_int, _P]),
     "ddrl_sac1_input_buffers": (c_int, [_P, c_int, POINTER(_P)]),
+    "ddrl_sac1_is_fused": (c_int, [_P]),
     "ddrl_sac1_batch": (c_int, [_P]),
     "ddrl_sac1_fill_noise": (c_int, [_P, c_uint32, _P]),
     "ddrl_sac1_stage_time": (c_int, [_P, c_int, c_int, POINTER(c_float), _P]),

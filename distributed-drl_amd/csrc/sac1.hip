@@ -2109,6 +2109,8 @@ int ddrl_sac1_input_buffers(ddrl_sac1_t *h, int set, float **bufs_h) {
 
 int ddrl_sac1_batch(ddrl_sac1_t *h) { return h ? h->cfg.batch : DDRL_ERR_BAD_ARG; }
 
+int ddrl_sac1_is_fused(ddrl_sac1_t *h) { return h ? (h->fused ? 1 : 0) : DDRL_ERR_BAD_ARG; }
+
 int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream) {
     // No kernel of its own: the next compute_grads / step generates eps_x, eps_x2, eps_t inside its
     // first kernel (k_l1) from hash(seed, device counter + i) and its Adam kernel advances the counter.

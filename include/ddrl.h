@@ -244,6 +244,8 @@ int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay,
 int ddrl_sac1_input_buffers(ddrl_sac1_t *h, int set, float **bufs_h);
 /* The batch size the learner was created with. */
 int ddrl_sac1_batch(ddrl_sac1_t *h);
+/* 1 when this handle's shape runs the fused 6-launch update (csrc/sac1_fused.h), 0 on the generic 9-launch path. */
+int ddrl_sac1_is_fused(ddrl_sac1_t *h);
 /* Arm noise generation for the NEXT ddrl_sac1_step / compute_grads: its first kernel fills the
  * three noise buffers of the input set in use with N(0,1) from the counter generator
  * (hash(seed, counter+i), same values as ddrl_normal_fill over a flat [3][B*act] buffer); the

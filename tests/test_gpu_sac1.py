@@ -153,6 +153,7 @@ def test_other_shapes(ddrl):
     """Ragged sizes: batch not a multiple of 32, hidden sizes not multiples of the tile, act_dim 3."""
     from distributed_drl_amd import _lib
     opt, learner, cfg = _mk(ddrl, 5, obs_dim=5, act_dim=3, hidden_sizes=(70, 45), batch_size=37)
+    assert learner._lib.ddrl_sac1_is_fused(learner._h) == 0
     params = so.init_params(cfg, 5)
     learner.set_weights(list(params.keys()), list(params.values()))
     batch, eps = so.synthetic_batch(cfg, seed=9)
@@ -379,3 +380,38 @@ def test_sqn_learner_matches_oracle(ddrl, obs, acts, hid, batch):
     actor = dqn.ActorSQN(Opt, "worker")
     actor.set_weights(*learner.get_weights())
     assert 0 <= actor.get_action(b["obs1"][0]) < acts and 0 <= actor.get_action(b["obs1"][0], True) < acts
+
+
+@pytest.mark.parametrize("obs,act,hid,batch", [(6, 1, (64, 96), 64), (9, 3, (128, 100), 96), (8, 4, (512, 512), 32), (3, 2, (36, 8), 32),
+                                               (8, 2, (400, 300), 128)])
+def test_fused_envelope_shapes(ddrl, obs, act, hid, batch):
+    """Shapes inside the fused path's envelope other than the headline one (1-4 action dims, K ranges that are not
+    multiples of the 32-unit layer-1 blocks, 1 to 16 column tiles, one sub-chunk per wave): first update vs the
+    float64 oracle — losses 1e-5 relative, gradients, parameters — and the per-row outputs."""
+    from distributed_drl_amd import _lib
+    import os
+    opt, learner, cfg = _mk(ddrl, 7, obs_dim=obs, act_dim=act, hidden_sizes=hid, batch_size=batch)
+    assert learner._lib.ddrl_sac1_is_fused(learner._h) == (0 if os.environ.get("DDRL_SAC1_GENERIC") else 1)
+    params = so.init_params(cfg, 7)
+    rs = np.random.RandomState(11)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.05, 0.05, params[k].shape).astype(np.float32)
+    learner.set_weights(list(params.keys()), list(params.values()))
+    o64 = so.Sac1Oracle(cfg, params, torch.float64)
+    for it in range(2):
+        b, eps = so.synthetic_batch(cfg, seed=90 + it)
+        w = o64.step(b, *eps)
+        losses, (q1, q2, lp) = learner.train(b, eps=eps, return_outputs=True)
+        tol = 1e-5 if it == 0 else 3e-5
+        for i, k in enumerate(("pi_loss", "q1_loss", "q2_loss")):
+            assert _rel(losses[i].item(), w[k]) <= tol, (it, k, losses[i].item(), float(w[k]))
+        np.testing.assert_allclose(q1.cpu().numpy(), w["q1"].numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(q2.cpu().numpy(), w["q2"].numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(lp.cpu().numpy(), w["logp_pi"].numpy(), rtol=1e-4, atol=2e-5)
+        if it == 0:
+            g, g64 = learner.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
+            assert np.abs(g - g64).max() <= 2e-4 * np.abs(g64).max()
+    for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target")):
+        assert np.abs(learner.export(which).cpu().numpy() - o64.flat(name)).max() <= 2 * 2e-2 * cfg.lr
+    assert learner.opt_steps() == (2, 2)
