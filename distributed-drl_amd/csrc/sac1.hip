@@ -954,8 +954,12 @@ struct RowsC {
     float alpha, scale;
     int nl;  // loss terms per row: 3 (SAC1) or 4 (SAC-v: + v_loss)
 };
-__global__ void __launch_bounds__(64) k_rows_c(int nrows, RowsC a) {
+// Leading scalars (preloaded SGPRs): one base pointer + offsets and packed sizes — what the row workgroups'
+// first (and only) burst of loads needs; the struct behind them arrives from the cold kernarg segment later.
+__global__ void __launch_bounds__(64) k_rows_c(const float *base, int dz1_off, int h2_off, int w1q_off, int wmu_off, int wls_off, int save_off,
+                                               int pk_h, int pk_l, int pk_a, RowsC a) {
     const int lane = threadIdx.x;
+    const int nrows = pk_a >> 16;
     if ((int)blockIdx.x == nrows) {  // (gridDim is a hidden-argument load)
         // reduce_mean over the batch: the extra last workgroup sums the per-row terms of k_rows_b in
         // a fixed order (lane-strided partial sums, then the xor-shuffle tree)
@@ -979,19 +983,20 @@ __global__ void __launch_bounds__(64) k_rows_c(int nrows, RowsC a) {
         return;
     }
     const int r = blockIdx.x;
-    if (r >= a.B) return;
+    if (r >= nrows) return;
     // everything this wave needs for the first two action dims, in one burst
     float dz[RV], hrow[RV], wq0[RV], wq1[RV], wm0[RV], wl0[RV], wm1[RV], wl1[RV];
-    const int cB = a.act > 1 ? 1 : 0;
-    load_row(a.dZ1q + (long long)r * a.h1, a.h1, lane, dz);
-    load_row(a.H2 + (long long)r * a.ldh2, a.h2, lane, hrow);
-    load_row(a.W1q1 + (long long)(a.obs + 0) * a.h1, a.h1, lane, wq0);
-    load_row(a.W1q1 + (long long)(a.obs + cB) * a.h1, a.h1, lane, wq1);
-    load_row(a.pi.Wmu, a.h2, lane, wm0, a.act, 0);
-    load_row(a.pi.Wls, a.h2, lane, wl0, a.act, 0);
-    load_row(a.pi.Wmu, a.h2, lane, wm1, a.act, cB);
-    load_row(a.pi.Wls, a.h2, lane, wl1, a.act, cB);
-    const float4 sv = *reinterpret_cast<const float4 *>(a.save0 + ((long long)r * a.act + (lane < a.act ? lane : 0)) * 4);
+    const int ph1 = pk_h & 0xffff, ph2 = pk_h >> 16, pldh2 = pk_l & 0xffff, pobs = pk_l >> 16, pact = pk_a & 0xffff;
+    const int cB = pact > 1 ? 1 : 0;
+    load_row(base + dz1_off + (long long)r * ph1, ph1, lane, dz);
+    load_row(base + h2_off + (long long)r * pldh2, ph2, lane, hrow);
+    load_row(base + w1q_off + (long long)(pobs + 0) * ph1, ph1, lane, wq0);
+    load_row(base + w1q_off + (long long)(pobs + cB) * ph1, ph1, lane, wq1);
+    load_row(base + wmu_off, ph2, lane, wm0, pact, 0);
+    load_row(base + wls_off, ph2, lane, wl0, pact, 0);
+    load_row(base + wmu_off, ph2, lane, wm1, pact, cB);
+    load_row(base + wls_off, ph2, lane, wl1, pact, cB);
+    const float4 sv = *reinterpret_cast<const float4 *>(base + save_off + ((long long)r * pact + (lane < pact ? lane : 0)) * 4);
     mask_row(dz, a.h1, lane);
     float ga = 0.f;
     {
@@ -1242,6 +1247,58 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     }
 }
 
+// The fused step's tail: Adam + polyak for the one parameter range whose gradient is a sum of row-tile partials
+// (the policy's layer 1) and the optimizer bookkeeping.  A few workgroups, pure latency: everything the first
+// burst of loads needs travels as preloaded scalars (base pointer + offsets into the slab).
+struct AdamL1Args {
+    float lr, b1, b2, eps, pk, pk1;
+    unsigned int noise_adv;
+    long long n_pi4;
+    OptState *opt_next;
+};
+__global__ void __launch_bounds__(256) k_adam_l1(const float *base, int p_off, int t_off, int m_off, int v_off, int g_off, int part_off, int i0,
+                                                 int cnt4, int nparts, int stride4, int opt_off, AdamL1Args a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;          // float4 element inside the range
+    const int jc = j < cnt4 ? j : 0;
+    const long long i = (long long)i0 + jc;
+    float *bw = const_cast<float *>(base);
+    float4 *P = reinterpret_cast<float4 *>(bw + p_off), *T = reinterpret_cast<float4 *>(bw + t_off);
+    float4 *M = reinterpret_cast<float4 *>(bw + m_off), *V = reinterpret_cast<float4 *>(bw + v_off);
+    const OptState *opt = reinterpret_cast<const OptState *>(base + opt_off);
+    float4 m = M[i], v = V[i], p = P[i], t = T[i];
+    const float b1p_pi = opt->b1p_pi, b2p_pi = opt->b2p_pi, b1p_q = opt->b1p_q, b2p_q = opt->b2p_q;
+    const float4 *PP = reinterpret_cast<const float4 *>(base + part_off) + jc;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = 0; q0 < nparts; q0 += 8) {  // 8 partials per round trip, summed in tile order (as k_adam_polyak)
+        float4 u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = PP[(long long)(q0 + q < nparts ? q0 + q : 0) * stride4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q0 + q < nparts) { g.x += u[q].x; g.y += u[q].y; g.z += u[q].z; g.w += u[q].w; }
+    }
+    const float one = 1.0f;
+    const float al_pi = a.lr * sqrtf(one - b2p_pi) / (one - b1p_pi);
+    const float al_q = a.lr * sqrtf(one - b2p_q) / (one - b1p_q);
+    const float omb1 = one - a.b1, omb2 = one - a.b2;
+    if (j < cnt4) {
+        const float al = i < a.n_pi4 ? al_pi : al_q;
+        adam1(g.x, m.x, v.x, p.x, t.x, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        adam1(g.y, m.y, v.y, p.y, t.y, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        adam1(g.z, m.z, v.z, p.z, t.z, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        adam1(g.w, m.w, v.w, p.w, t.w, omb1, omb2, al, a.eps, a.pk, a.pk1);
+        reinterpret_cast<float4 *>(bw + g_off)[i] = g;  // keep the gradient buffer complete (export)
+        M[i] = m; V[i] = v; P[i] = p; T[i] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        OptState n = *opt;
+        n.b1p_pi = b1p_pi * a.b1; n.b2p_pi = b2p_pi * a.b2; n.b1p_q = b1p_q * a.b1; n.b2p_q = b2p_q * a.b2;
+        n.t_pi += 1; n.t_q += 1;
+        n.noise_ctr += a.noise_adv;
+        *a.opt_next = n;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K: dense external layout <-> padded internal layout; staging of the caller's batch
 // ------------------------------------------------------------------------------------------
@@ -1453,6 +1510,7 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
     DDRL_REQUIRE(c->obs_dim > 0 && c->act_dim > 0 && c->hidden1 > 0 && c->hidden2 > 0 && c->batch > 0, "dims must be positive");
     DDRL_REQUIRE(c->act_dim <= MAXA, "act_dim > 8 unsupported");
     DDRL_REQUIRE(c->variant == DDRL_SAC1 || c->variant == DDRL_SAC_V, "variant must be DDRL_SAC1 or DDRL_SAC_V");
+    DDRL_REQUIRE(c->batch < 65536, "batch >= 65536 unsupported (packed kernel arguments)");
     DDRL_REQUIRE(c->obs_dim + c->act_dim <= L1_MAXD, "obs_dim + act_dim > 40 unsupported by the layer-1 kernel");
     DDRL_REQUIRE(c->hidden1 <= 64 * RV && c->hidden2 <= 64 * RV, "hidden sizes > 512 unsupported by the row kernels");
     return DDRL_OK;
@@ -1981,6 +2039,13 @@ int ddrl_sac1_opt_state_set(ddrl_sac1_t *h, int64_t t_pi, int64_t t_q, uint64_t 
     return DDRL_OK;
 }
 
+static void launch_rows_c(ddrl_sac1 *h, hipStream_t s) {
+    const RowsC &c = h->rc;
+    const float *b = h->slab;
+    k_rows_c<<<c.B + 1, 64, 0, s>>>(b, (int)(c.dZ1q - b), (int)(c.H2 - b), (int)(c.W1q1 - b), (int)(c.pi.Wmu - b), (int)(c.pi.Wls - b),
+                                    (int)(c.save0 - b), c.h1 | (c.h2 << 16), c.ldh2 | (c.obs << 16), c.act | (c.B << 16), c);
+}
+
 // One stage of the update (input set `st`).  Stage ids as documented for ddrl_sac1_stage_time.
 static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const ddrl_sac1_config_t &c = h->cfg;
@@ -2013,13 +2078,12 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
             J.ad.opt = h->opt + h->opt_cur;
             launch_gemm(J, s);
             if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
-                AdamArgs A = h->ad;
-                A.base4 = A.part_off4; A.n = (A.part_off4 + A.part_n4) * 4;
-                A.opt = h->opt + h->opt_cur; A.opt_next = h->opt + (h->opt_cur ^ 1);
-                A.noise_adv = h->noise_pending;
-                A.do_sample = 0;
-                A.adam_blocks = (int)((A.part_n4 + 255) / 256);
-                k_adam_polyak<<<A.adam_blocks, 256, 0, s>>>(A);
+                const AdamArgs &A = h->ad;
+                const float *b = h->slab;
+                const AdamL1Args L1{A.lr, A.b1, A.b2, A.eps, A.pk, A.pk1, h->noise_pending, A.n_pi >> 2, h->opt + (h->opt_cur ^ 1)};
+                k_adam_l1<<<(unsigned)((A.part_n4 + 255) / 256), 256, 0, s>>>(
+                    b, (int)(A.p - b), (int)(A.t - b), (int)(A.m - b), (int)(A.v - b), (int)(A.g - b), (int)(A.part - b), (int)A.part_off4,
+                    (int)A.part_n4, A.nparts, (int)A.part_stride4, (int)(reinterpret_cast<const float *>(h->opt + h->opt_cur) - b), L1);
                 h->opt_cur ^= 1;
             }
         }
@@ -2038,7 +2102,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
             else k_rows_b<<<B, 64, 0, s>>>(h->rb[st]);
             break;
         case 7: launch_gemm(h->g_bq, s); break;
-        case 8: k_rows_c<<<B + 1, 64, 0, s>>>(B, h->rc); break;  // +1: the loss-reduction workgroup
+        case 8: launch_rows_c(h, s); break;  // +1: the loss-reduction workgroup
         case 9: launch_gemm(h->g_bpi, s); break;
         case 10: if (h->g_last.total_tiles > 0) launch_gemm(h->g_last, s); break;
         case 11: {
