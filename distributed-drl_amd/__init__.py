@@ -26,7 +26,7 @@ def __getattr__(name):
         "Learner": "agent", "Actor": "agent", "Model": "agent", "HyperParameters": "agent",
         "VecLunarLander": "env",
         "worker_rollout": "workers", "worker_train": "workers", "worker_test": "workers",
-        "worker_rollout_sac1": "workers", "worker_train_sac1": "workers",
+        "worker_rollout_sac1": "workers", "worker_train_sac1": "workers", "worker_test_sac1": "workers",
         "RolloutDevice": "workers", "TrainDevice": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers", "ActorLearnerLoop": "workers",
     }
     if name in table:

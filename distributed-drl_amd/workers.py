@@ -216,6 +216,40 @@ def worker_train_sac1(ps, replay_buffer, opt, learner_index, make_agent=None):
         cnt += 1
 
 
+def worker_test_sac1(ps, replay_buffer, opt, make_env=None, make_agent=None, log=print, sleep=time.sleep, max_rounds=None, n=25):
+    """algos/sac1/sac1.py:214-252: pull, 25 deterministic episodes, print test_reward / counters / update frequency,
+    `ps.save_weights()` whenever the return beats the best so far, sleep 5 s, repeat."""
+    if make_env is None:
+        make_env = lambda name: _default_env(name, opt)
+    if make_agent is None:
+        from .agent import Actor
+        make_agent = lambda o: Actor(o, job="main")
+    agent = make_agent(opt)
+    keys, weights = agent.get_weights()
+    time0 = time1 = time.time()
+    sample_times1, steps, size = _get(_remote(replay_buffer.get_counts))
+    max_ret = -1000
+    env = make_env(opt.env_name)
+    rounds = 0
+    while True:
+        weights = _get(_remote(ps.pull, keys))
+        agent.set_weights(keys, weights)
+        ep_ret = agent.test(env, replay_buffer, n)
+        sample_times2, steps, size = _get(_remote(replay_buffer.get_counts))
+        time2 = time.time()
+        log("test_reward: %s sample_times: %s steps: %s buffer_size: %s" % (ep_ret, sample_times2, steps, size))
+        log("update frequency: %s total time: %s" % ((sample_times2 - sample_times1) / max(time2 - time1, 1e-9), time2 - time0))
+        if ep_ret > max_ret:
+            _remote(ps.save_weights, getattr(opt, "save_dir", "") and (opt.save_dir + "/") or "")
+            log("****** weights saved! ******")
+            max_ret = ep_ret
+        time1, sample_times1 = time2, sample_times2
+        rounds += 1
+        if (max_rounds is not None and rounds >= max_rounds) or _stop(opt):
+            return max_ret
+        sleep(5)
+
+
 # ------------------------------------------------------------------------------------------
 # device style: everything stays in HBM (plain objects, not actor handles)
 # ------------------------------------------------------------------------------------------
