@@ -1826,7 +1826,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         auto base = [&](FwdArgs &F, int njobs) {
             F = FwdArgs{};
             F.njobs = njobs; F.tiles_n = nt2;
-            F.hd.pbase = h->slab; F.hd.tiles_m = B / 32; F.hd.tpj = (B / 32) * nt2; F.hd.h1 = h1; F.hd.h2 = h2;
+            F.hd.pbase = h->slab; F.hd.tiles_m = B / 32; F.hd.tpj = (B / 32) * nt2; F.hd.h1 = h1; F.hd.h2 = h2; F.hd.hp_off = (int)(h->hp - h->slab);
             {   // LDS tile geometry: sub-chunks of up to 64 (two 32-unit layer-1 blocks)
                 const int chunk = ((h1 + 15) >> 4) << 2;
                 F.ks_max = chunk < 64 ? (chunk < KS ? KS : chunk) : 64;

@@ -55,6 +55,7 @@ struct FwdHead {
     const float *pbase;        // parameters are addressed as pbase + offset (main and target live in one slab)
     int tiles_m, tpj, h1, h2;  // tpj = tiles_m * tiles_n: tiles per job
     int w2_off[5], w1_off[5];  // per job
+    int hp_off;                // head partial buffer (phase 1 passes it in the scalar slot of job 3)
 };
 struct FwdArgs {
     FwdHead hd;
@@ -166,6 +167,32 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
     STAMP(15);
 
     // ---- every independent load of the kernel, up front --------------------------------------
+    // Phase 1 first issues what its longest chain starts with: the policy-head partials of this tile's rows
+    // (-> action -> layer-1 input).  Three jobs only, so the scalar slots of jobs 3 / 4 carry the offset of the
+    // partial buffer and batch | act << 16; the policy evaluation is fixed by the job order (job 0: pi(x) = eval 0;
+    // jobs 1, 2: pi_targ(x2) = eval 2; log-prob of pi(x2) = eval 1 for job 1's first column tile).
+    float hsum[2] = {0.f, 0.f};
+    if (PH == 1) {
+        const int Bq = w2o4 & 0xffff, actq = w2o4 >> 16;
+        const long long HPq = (long long)FH * Bq * F_MAXNT;
+        const int c = tid >> 5, r = tid & 31;
+        const bool okc = c < 2 * actq;
+        const bool two_q = ji == 1 && first_n;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 0 || two_q) {
+                const float *hp = pbase + w2o3 + (e == 0 ? (ji == 0 ? 0 : 2) : 1) * HPq;
+                const float4 *p4 = reinterpret_cast<const float4 *>(hp + ((long long)(okc ? c : 0) * Bq + m0 + r) * F_MAXNT);
+                float4 v[F_MAXNT / 4];
+#pragma unroll
+                for (int q = 0; q < F_MAXNT / 4; ++q) v[q] = p4[q];
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < F_MAXNT / 4; ++q) { s += v[q].x; s += v[q].y; s += v[q].z; s += v[q].w; }  // n-tile order; unused slots are 0
+                hsum[e] = s;
+            }
+        }
+    }
     // (1) + (2) need only the preloaded part of the arguments
     const int w2o = ji == 0 ? w2o0 : (ji == 1 ? w2o1 : (ji == 2 ? w2o2 : (ji == 3 ? w2o3 : w2o4)));
     const int w1o = ji == 0 ? w1o0 : (ji == 1 ? w1o1 : (ji == 2 ? w1o2 : (ji == 3 ? w1o3 : w1o4)));
@@ -223,27 +250,10 @@ __global__ void __launch_bounds__(256) k_fwd(const float *pbase, int tiles_m, in
         inv[u] = p[inok[u] ? off : 0];
     }
     STAMP(14);
-    // (5) phase 1: head partials of the policy evaluation(s), summed over the n-tiles in a fixed order
-    float hsum[2] = {0.f, 0.f};
+    // (5) phase 1: the noise of the policy evaluation(s)
     float epsv[4] = {0.f, 0.f, 0.f, 0.f};
     const bool two = PH == 1 && jb.side == 2 && first_n;  // block-uniform
     if (PH == 1) {
-        const int c = tid >> 5, r = tid & 31;
-        const bool okc = c < 2 * a.act;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (e == 0 || two) {
-                const float *hp = e == 0 ? jb.php : a.php1;
-                const float4 *p4 = reinterpret_cast<const float4 *>(hp + ((long long)(okc ? c : 0) * B + m0 + r) * F_MAXNT);
-                float4 v[F_MAXNT / 4];
-#pragma unroll
-                for (int q = 0; q < F_MAXNT / 4; ++q) v[q] = p4[q];
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < F_MAXNT / 4; ++q) { s += v[q].x; s += v[q].y; s += v[q].z; s += v[q].w; }  // n-tile order; unused slots are 0
-                hsum[e] = s;
-            }
-        }
         if (w < 2) {  // wave 0: the action-giving evaluation; wave 1: pi_main @ x2 (side == 2)
             const float *pe = w == 0 ? jb.peps : a.peps1;
 #pragma unroll
@@ -438,8 +448,9 @@ static size_t fwd_smem(const FwdArgs &a) {
 template <int PH>
 static void launch_fwd(const FwdArgs &F, hipStream_t s) {
     const FwdHead &d = F.hd;
-    k_fwd<PH><<<F.njobs * d.tpj + ((PH == 1 && F.do_sample) ? 1 : 0), 256, fwd_smem(F), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.w2_off[0], d.w2_off[1], d.w2_off[2], d.w2_off[3],
-                                                        d.w2_off[4], d.w1_off[0], d.w1_off[1], d.w1_off[2], d.w1_off[3], d.w1_off[4], F);
+    const int s3 = PH == 1 ? d.hp_off : d.w2_off[3], s4 = PH == 1 ? (F.B | (F.act << 16)) : d.w2_off[4];
+    k_fwd<PH><<<F.njobs * d.tpj + ((PH == 1 && F.do_sample) ? 1 : 0), 256, fwd_smem(F), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.w2_off[0], d.w2_off[1], d.w2_off[2], s3, s4,
+                                                        d.w1_off[0], d.w1_off[1], d.w1_off[2], d.w1_off[3], d.w1_off[4], F);
 }
 
 // ==========================================================================================
