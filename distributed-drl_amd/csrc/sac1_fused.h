@@ -489,7 +489,7 @@ struct BqArgs {
 };
 
 __global__ void __launch_bounds__(256) k_bwdq(const float *pbase, int tiles_m, int tpj, int h1_, int h2_, int h2o0, int h2o1, int h2o2, int w2o0,
-                                              int w2o1, int w2o2, BqArgs a) {
+                                              int w2o1, int w2o2, int hp_off, int batch, BqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float s_q[8][32];
     __shared__ float s_g[32];
@@ -513,7 +513,20 @@ __global__ void __launch_bounds__(256) k_bwdq(const float *pbase, int tiles_m, i
     const int ks_a = half < kw ? half : kw, ks_b = kw - ks_a;
     const bool first_n = nt == 0;
 
-    // ---- loads that need only the preloaded scalars: both operand tiles of the first sub-chunk
+    // ---- loads that need only the preloaded scalars.  First what the longest chain starts with: the Q-head partials of
+    // this tile's rows (-> dq -> the generated A operand); job order is fixed (0: q1(x,pi), which needs none; 1, 2: q1, q2 at (x,a)).
+    float qsum = 0.f;
+    if (ji != 0) {  // c = 0..4 <-> evaluations 3,4,5,6,7
+        const int c = tid >> 5, r = tid & 31;
+        const long long HP = (long long)FH * batch * F_MAXNT;
+        const float4 *p4 = reinterpret_cast<const float4 *>(pbase + hp_off + (3 + (c < 5 ? c : 0)) * HP + (long long)(m0 + r) * F_MAXNT);
+        float4 v[F_MAXNT / 4];
+#pragma unroll
+        for (int q = 0; q < F_MAXNT / 4; ++q) v[q] = p4[q];
+#pragma unroll
+        for (int q = 0; q < F_MAXNT / 4; ++q) { qsum += v[q].x; qsum += v[q].y; qsum += v[q].z; qsum += v[q].w; }
+    }
+    // both operand tiles of the first sub-chunk
     const float *H2 = pbase + (ji == 0 ? h2o0 : (ji == 1 ? h2o1 : h2o2));
     const float *W2 = pbase + (ji == 0 ? w2o0 : (ji == 1 ? w2o1 : w2o2));
     Op2<true> oa, ob;
@@ -541,18 +554,8 @@ __global__ void __launch_bounds__(256) k_bwdq(const float *pbase, int tiles_m, i
     }
     // Q-head partials of this tile's rows: c = 0..4 <-> evaluations 3,4,5,6,7
     const bool need_q = slot != 2;  // block-uniform: the q1(x,pi) path has dq = -1/B
-    float qsum = 0.f;
     float rew = 0.f, done = 0.f, lp0 = 0.f, lp1 = 0.f;
     if (need_q) {
-        const int c = tid >> 5, r = tid & 31;
-        const bool okc = c < 5;
-        const long long HP = (long long)FH * B * F_MAXNT;
-        const float4 *p4 = reinterpret_cast<const float4 *>(a.hp + (3 + (okc ? c : 0)) * HP + (long long)(m0 + r) * F_MAXNT);
-        float4 v[F_MAXNT / 4];
-#pragma unroll
-        for (int q = 0; q < F_MAXNT / 4; ++q) v[q] = p4[q];
-#pragma unroll
-        for (int q = 0; q < F_MAXNT / 4; ++q) { qsum += v[q].x; qsum += v[q].y; qsum += v[q].z; qsum += v[q].w; }
         if (w == 0) { rew = a.rew[m0 + l31]; done = a.done[m0 + l31]; lp0 = a.logp0[m0 + l31]; lp1 = a.logp1[m0 + l31]; }
     }
     const float b3_1 = a.b3q1[0], b3_2 = a.b3q2[0], b3_1t = a.b3q1t[0], b3_2t = a.b3q2t[0];
@@ -647,5 +650,5 @@ static size_t bq_smem(const BqArgs &a) {
 static void launch_bwdq(const BqArgs &A, hipStream_t s) {
     const BqHead &d = A.hd;
     k_bwdq<<<3 * d.tpj, 256, bq_smem(A), s>>>(d.pbase, d.tiles_m, d.tpj, d.h1, d.h2, d.h2_off[0], d.h2_off[1], d.h2_off[2], d.w2_off[0], d.w2_off[1],
-                                              d.w2_off[2], A);
+                                              d.w2_off[2], (int)(A.hp - d.pbase), A.B, A);
 }
