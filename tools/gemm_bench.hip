@@ -2,6 +2,7 @@
 // with per-phase cycle stamps of wave 0 of every workgroup.  hipcc -DDDRL_STAMPS.
 #include "../distributed-drl_amd/csrc/sac1.hip"
 #include "../distributed-drl_amd/csrc/common.hip"
+#include "../distributed-drl_amd/csrc/replay.hip"
 #include <algorithm>
 __global__ void k_touch(float *p, int n) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n) p[i] += 1e-9f; }
 int main() {
