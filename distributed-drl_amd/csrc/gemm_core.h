@@ -90,8 +90,11 @@ struct GemmJobs {
     GemmJob job[MAX_GEMM_JOBS];
 };
 
-struct Seg {  // one tensor: dense external offset <-> padded internal offset
+struct Seg {  // one tensor: dense external offset <-> internal offset
     long long ext, in, n;
+    // cols > 0: the tensor is a [n / cols][cols] kernel stored k4-interleaved (sac1_direct.h): element (k, j) lives at
+    // in + ((k / 4) * ld + j) * 4 + k % 4;  cols == 0: contiguous
+    int cols, ld;
 };
 
 struct OptState {  // device-resident Adam bookkeeping (running beta powers like TF's beta*_power)
@@ -720,12 +723,17 @@ __global__ void __launch_bounds__(256) k_pack(const Seg *__restrict__ segs, cons
                                               float *__restrict__ dst2, int to_internal) {
     const Seg s = segs[blockIdx.y];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.n; i += (long long)gridDim.x * 256) {
+        long long ii = i;
+        if (s.cols > 0) {
+            const long long k = i / s.cols, j = i - k * s.cols;
+            ii = ((k >> 2) * s.ld + j) * 4 + (k & 3);
+        }
         if (to_internal) {
             const float v = src[s.ext + i];
-            dst[s.in + i] = v;
-            if (dst2) dst2[s.in + i] = v;
+            dst[s.in + ii] = v;
+            if (dst2) dst2[s.in + ii] = v;
         } else {
-            dst[s.ext + i] = src[s.in + i];
+            dst[s.ext + i] = src[s.in + ii];
         }
     }
 }

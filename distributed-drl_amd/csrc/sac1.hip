@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64) k_rows_b_v(RowsBV a) {
     }
 }
 
-#include "sac1_fused.h"
+#include "sac1_direct.h"
 
 // The fused step's tail: Adam + polyak for the one parameter range whose gradient is a sum of row-tile partials
 // (the policy's layer 1) and the optimizer bookkeeping.  A few workgroups, pure latency: everything the first
@@ -603,6 +603,11 @@ __global__ void __launch_bounds__(256) k_stage(StageArgs a) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[w]; i += gridDim.x * 256) a.dst[w][i] = a.src[w][i];
 }
 
+__global__ void k_fill_col4(float *p, long long groups, int ld, int col) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g < groups) *reinterpret_cast<float4 *>(p + (g * ld + col) * 4) = make_float4(1.f, 1.f, 1.f, 1.f);
+}
+
 __global__ void k_copy3(const float *a, const float *b, const float *c, float *oa, float *ob, float *oc, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
@@ -657,14 +662,19 @@ struct Layout {
     long long n_pi_int, total_int;
     long long n_pi, n_q, total_ext;
     std::vector<Seg> segs;  // 20 tensors in external order
+    bool direct;            // layer-2 kernels k4-interleaved [Kp1/4][Np2][4] with a zero-padded bias [Np2] (sac1_direct.h)
+    int Kp1, Np2;
 };
 
-static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only) {
+static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only, bool direct = false) {
     // Internal layout: every kernel is followed IMMEDIATELY by its bias (so that a bias gradient
     // is just one more row of the kernel's wgrad GEMM); each (kernel, bias) pair starts on a
-    // 16-byte boundary.
+    // 16-byte boundary.  Direct path: the layer-2 kernels are stored k4-interleaved and padded to
+    // whole 32-wide tiles instead (pads are zero and stay zero: their gradient is never written).
     Layout L;
     const long long o = c.obs_dim, a = c.act_dim, h1 = c.hidden1, h2 = c.hidden2;
+    L.direct = direct;
+    L.Kp1 = (int)((h1 + 31) & ~31ll); L.Np2 = (int)((h2 + 31) & ~31ll);
     long long in = 0, ext = 0;
     auto add = [&](long long &slot, long long n, bool pad_after) {
         slot = in;
@@ -673,12 +683,22 @@ static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only) {
         if (pad_after) in = pad4(in);
         ext += n;
     };
-    add(L.pi_W1, o * h1, false); add(L.pi_b1, h1, true); add(L.pi_W2, h1 * h2, false); add(L.pi_b2, h2, true);
+    auto add_w2 = [&](long long &wslot, long long &bslot) {
+        if (!direct) { add(wslot, h1 * h2, false); add(bslot, h2, true); return; }
+        in = pad4(in);
+        wslot = in;
+        L.segs.push_back(Seg{ext, in, h1 * h2, (int)h2, L.Np2});
+        in += (long long)L.Kp1 * L.Np2; ext += h1 * h2;
+        bslot = in;
+        L.segs.push_back(Seg{ext, in, h2});
+        in += L.Np2; ext += h2;
+    };
+    add(L.pi_W1, o * h1, false); add(L.pi_b1, h1, true); add_w2(L.pi_W2, L.pi_b2);
     add(L.pi_Wmu, h2 * a, false); add(L.pi_bmu, a, true); add(L.pi_Wls, h2 * a, false); add(L.pi_bls, a, true);
     L.n_pi_int = in;
     L.n_pi = ext;
     for (int q = 0; q < 2 && !pi_only; ++q) {
-        add(L.q_W1[q], (o + a) * h1, false); add(L.q_b1[q], h1, true); add(L.q_W2[q], h1 * h2, false); add(L.q_b2[q], h2, true);
+        add(L.q_W1[q], (o + a) * h1, false); add(L.q_b1[q], h1, true); add_w2(L.q_W2[q], L.q_b2[q]);
         add(L.q_W3[q], h2, false); add(L.q_b3[q], 1, true);
     }
     L.v_W1 = L.v_b1 = L.v_W2 = L.v_b2 = L.v_W3 = L.v_b3 = -1;
@@ -721,12 +741,11 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
     return DDRL_OK;
 }
 
-// Envelope of the fused forward stages (sac1_fused.h); everything else takes the generic kernels.
-static bool fused_ok(const ddrl_sac1_config_t &c, const Layout &L) {
-    const bool al = (L.pi_W2 % 4 == 0) && (L.q_W2[0] % 4 == 0) && (L.q_W2[1] % 4 == 0) && (L.pi_W1 % 4 == 0) && (L.q_W1[0] % 4 == 0) &&
-                    (L.q_W1[1] % 4 == 0);
-    return c.variant == DDRL_SAC1 && c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * F_MAXNT &&
-           c.obs_dim + c.act_dim <= FD && 2 * c.act_dim <= FH && c.act_dim <= 4 && c.batch % 32 == 0 && al;
+// Envelope of the direct-operand path (sac1_direct.h); everything else takes the generic kernels.
+static bool direct_ok(const ddrl_sac1_config_t &c) {
+    return c.variant == DDRL_SAC1 && c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * DNT &&
+           c.obs_dim + c.act_dim <= 12 && 2 * c.act_dim <= DFH && c.act_dim <= 4 && c.batch % 32 == 0 && c.batch <= 32768 &&
+           getenv("DDRL_SAC1_GENERIC") == nullptr;
 }
 
 }  // namespace
@@ -757,18 +776,22 @@ struct ddrl_sac1 {
     float *vo, *vto;
     AdamArgs ad;
     int rows_b_blocks;
-    bool fused;          // fused forward stages (sac1_fused.h) instead of k_l1 / k_gemm / k_rows_a
-    FwdArgs f_a[2], f_b[2];
-    BqArgs bq[2];
+    bool fused;          // direct-operand path (sac1_direct.h) instead of the generic kernels
+    DFHead fh_a[2], fh_b[2];
+    DFArgs f_a[2], f_b[2];
+    DGJobs dg_bq[2], dg_mid, dg_pi;
+    // direct-path activations (x4 images, see sac1_direct.h) and the dgrad images of the main layer-2 kernels
+    int Lp1, Lp2;
+    float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq;
+    float *c4_pi[2], *c4_q[2];
+    int sh_cur;          // which copy of the policy dgrad image is current (the optimizer epilogue writes the other one)
     bool fuse_apply;     // this launch_grads also applies the optimizer (Adam in the wgrad epilogues)
     // sampler riding in k_fwd<1> (ddrl_sac1_step_and_sample)
     bool sample_armed;
     ddrl_replay_dev::RingState *smp_rs;
     ddrl_replay_dev::RingPtrs smp_ring;
     int smp_set;
-    GemmJobs g_bpi_f;    // fused path: the policy backward launch also carries the Q layer-2/head wgrads
-    float *hp;           // head partials [NEVAL][FH][B][F_MAXNT]
-    float *w2snap;       // fused path: this update's copy of the policy W2 (read by the policy dgrad)
+    float *hp;           // head partials [NEVAL][DFH][B][DNT]
     bool fused_l1_wgrad;  // pi layer-1 wgrad via dgrad-epilogue partials + Adam (needs hidden1 % 4 == 0)
     // set by ddrl_sac1_fill_noise, consumed by the next compute_grads / apply_grads
     bool noise_armed;
@@ -776,6 +799,8 @@ struct ddrl_sac1 {
     unsigned int noise_pending;
     bool grad_imported;  // the gradient buffer was overwritten by import(GRAD): Adam must not re-sum partials
 };
+
+static void refresh_shadows(ddrl_sac1 *h, hipStream_t s);
 
 static int sac1_free(ddrl_sac1 *h) {
     (void)hipFree(h->slab);
@@ -897,10 +922,13 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     ddrl_sac1 *h = new ddrl_sac1();  // value-initialised: every pointer/job table starts zeroed
     h->device = device;
     h->cfg = *cfg;
-    h->L = make_layout(*cfg, false);
+    h->fused = direct_ok(*cfg);
+    h->L = make_layout(*cfg, false, h->fused);
     const Layout &L = h->L;
     const int B = cfg->batch, o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
     const size_t NT = (size_t)L.total_int;
+    const int Kp1 = L.Kp1, Np2 = L.Np2;
+    h->Lp1 = rup32(h1 + 1); h->Lp2 = rup32(h2 + 1);  // activation images keep room for the ones column
     // ONE slab for every buffer of the learner (parameters, optimizer state, activations, job
     // tables): a single large allocation is mapped with large page fragments, so the ~30 buffers a
     // stage touches share a handful of TLB entries instead of missing on one 4 KB page each.
@@ -919,15 +947,24 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         for (int i = 0; i < 8; ++i) items.push_back(Item{&h->in[st][i], reserve(cnt[i])});
     }
     ALLOC(part, (size_t)((B + 31) / 32) * (o + 1) * h1);
-    ALLOC(H1, (size_t)NEVAL * B * h->ldh1); ALLOC(H2, (size_t)NEVAL * B * h->ldh2);
-    ALLOC(dZ2, (size_t)5 * B * h2); ALLOC(dZ1, (size_t)5 * B * h1);
+    if (!h->fused) {
+        ALLOC(H1, (size_t)NEVAL * B * h->ldh1); ALLOC(H2, (size_t)NEVAL * B * h->ldh2);
+        ALLOC(dZ2, (size_t)5 * B * h2); ALLOC(dZ1, (size_t)5 * B * h1);
+    } else {
+        ALLOC(H1r4, (size_t)4 * B * h->Lp1); ALLOC(H2c4, (size_t)4 * Np2 * B); ALLOC(H2r4, (size_t)3 * B * h->Lp2);
+        ALLOC(dZ1r4, (size_t)2 * B * h->Lp1); ALLOC(dzpi_c4, (size_t)Np2 * B); ALLOC(dzpi_r4, (size_t)B * h->Lp2);
+        ALLOC(dhead_r4, (size_t)B * 32); ALLOC(xa_r4, (size_t)B * 32); ALLOC(da_part, (size_t)16 * B * 4); ALLOC(dq, (size_t)2 * B + 256);
+        for (int i = 0; i < 2; ++i) {
+            items.push_back(Item{&h->c4_pi[i], reserve((size_t)Np2 * Kp1)});
+            items.push_back(Item{&h->c4_q[i], reserve((size_t)Np2 * Kp1)});
+        }
+    }
     ALLOC(xa, (size_t)B * h->ldxa); ALLOC(xp, (size_t)B * h->ldxp);
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
     ALLOC(q1o, B); ALLOC(q2o, B); ALLOC(vo, B); ALLOC(vto, B); ALLOC(dq4, (size_t)3 * B * 4); ALLOC(dhead, (size_t)B * h->ldd);
     ALLOC(loss_part, (size_t)h->rows_b_blocks * 4); ALLOC(losses, 4);
     const int nt2 = (h2 + 31) / 32;
-    ALLOC(hp, (size_t)NEVAL * FH * B * F_MAXNT);
-    ALLOC(w2snap, (size_t)h1 * h2 + 64);
+    ALLOC(hp, (size_t)NEVAL * DFH * B * DNT);
 #undef ALLOC
     const size_t opt_off = reserve((2 * sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((L.segs.size() * sizeof(Seg) + 3) / 4);
@@ -947,8 +984,14 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     if (rc != DDRL_OK) { sac1_free(h); return rc; }
 
     // the physical ones columns (never overwritten: kernels write columns < h1 / h2 / obs(+act) only)
-    k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H1, (long long)NEVAL * B, h->ldh1, h1, 1.0f);
-    k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H2, (long long)NEVAL * B, h->ldh2, h2, 1.0f);
+    if (!h->fused) {
+        k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H1, (long long)NEVAL * B, h->ldh1, h1, 1.0f);
+        k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H2, (long long)NEVAL * B, h->ldh2, h2, 1.0f);
+    } else {  // x4 images [row/4][ld][4]: "column" c of every row = four consecutive floats per row group
+        k_fill_col4<<<(4 * B / 4 + 255) / 256, 256>>>(h->H1r4, (long long)4 * B / 4, h->Lp1, h1);
+        k_fill_col4<<<(3 * B / 4 + 255) / 256, 256>>>(h->H2r4, (long long)3 * B / 4, h->Lp2, h2);
+        k_fill_col4<<<(B / 4 + 255) / 256, 256>>>(h->xa_r4, (long long)B / 4, 32, o + a);
+    }
     k_fill_col<<<(B + 255) / 256, 256>>>(h->xa, B, h->ldxa, o + a, 1.0f);
     k_fill_col<<<(B + 255) / 256, 256>>>(h->xp, B, h->ldxp, o, 1.0f);
     DDRL_LAUNCH_CHECK();
@@ -963,6 +1006,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     const float *Pm = h->main_p, *Pt = h->target_p;
     const int ldh1 = h->ldh1, ldh2 = h->ldh2;
     const long long BH1 = (long long)B * ldh1, BH2 = (long long)B * ldh2, BZ1 = (long long)B * h1, BZ2 = (long long)B * h2;
+    if (!h->fused) {
     // ---- layer-1 jobs (one table per input set).  evals: 0 pi(x) 1 pi(x2) 2 piT(x2) 3 q1(x,a) 4 q2(x,a) |
     // 5 q1(x,pi) 6 q1T(x2,piT) 7 q2T(x2,piT): observation part only here, finished by k_rows_a
     for (int st = 0; st < 2; ++st) {
@@ -1023,101 +1067,143 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     // launch "last" (only when the fused form is unavailable): needs dZ1[3]
     if (!h->fused_l1_wgrad) gemm_add(h->g_last, gemm_wgrad(h->xp, h->ldxp, o, h->dZ1 + 3 * BZ1, h1, h1, G + L.pi_W1, h1, B));               // pi W1, b1
 
-    // ---- fused forward stages (sac1_fused.h)
-    h->fused = fused_ok(*cfg, L) && getenv("DDRL_SAC1_GENERIC") == nullptr;
-    for (int st = 0; st < 2 && h->fused; ++st) {
-        float *x = h->in[st][0], *x2 = h->in[st][1], *ac = h->in[st][2];
-        const long long HP = (long long)FH * B * F_MAXNT;
-        auto base = [&](FwdArgs &F, int njobs) {
-            F = FwdArgs{};
-            F.njobs = njobs; F.tiles_n = nt2;
-            F.hd.pbase = h->slab; F.hd.tiles_m = B / 32; F.hd.tpj = (B / 32) * nt2; F.hd.h1 = h1; F.hd.h2 = h2; F.hd.hp_off = (int)(h->hp - h->slab);
-            {   // LDS tile geometry: sub-chunks of up to 64 (two 32-unit layer-1 blocks)
-                const int chunk = ((h1 + 15) >> 4) << 2;
-                F.ks_max = chunk < 64 ? (chunk < KS ? KS : chunk) : 64;
-                const int ta = 32 * (F.ks_max + 2), tb = F.ks_max * 36;
-                F.op_lds = ta > tb ? ta : tb;
-            }
-            F.B = B; F.ldh1 = ldh1; F.ldh2 = ldh2; F.act = a; F.nt2 = nt2;
-            F.scale = (float)cfg->act_scale;
-            F.act0 = h->act0; F.act2 = h->act2; F.logp0 = h->logp0; F.logp1 = h->logp1; F.save0 = h->save0;
-            F.php1 = h->hp + 1 * HP; F.pbmu1 = Pm + L.pi_bmu; F.pbls1 = Pm + L.pi_bls; F.peps1 = h->in[st][6];
-            F.noise_on = 0; F.n_each = B * a; F.noise_seed = 0;
-            F.e0 = h->in[st][5]; F.e1 = h->in[st][6]; F.e2 = h->in[st][7]; F.opt = h->opt;
-        };
-        auto pij = [&](const float *P, const float *in0, int ev, bool keep_h1) {
-            FwdJob j{};
-            j.in = FIn{in0, nullptr, P + L.pi_W1, P + L.pi_b1, o, 0};
-            j.W2 = P + L.pi_W2; j.b2 = P + L.pi_b2; j.H2 = h->H2 + ev * BH2; j.H1 = keep_h1 ? h->H1 + ev * BH1 : nullptr;
-            j.wh0 = P + L.pi_Wmu; j.wh1 = P + L.pi_Wls; j.nh = 2 * a; j.hsplit = a; j.hstride = a;
-            j.hp = h->hp + ev * HP;
-            return j;
-        };
-        auto qj = [&](const float *P, int q, const float *in0, const float *in1, int ev, bool keep_h1) {
-            FwdJob j{};
-            j.in = FIn{in0, in1, P + L.q_W1[q], P + L.q_b1[q], o, in1 ? a : 0};
-            j.W2 = P + L.q_W2[q]; j.b2 = P + L.q_b2[q]; j.H2 = h->H2 + ev * BH2; j.H1 = keep_h1 ? h->H1 + ev * BH1 : nullptr;
-            j.wh0 = P + L.q_W3[q]; j.wh1 = j.wh0; j.nh = 1; j.hsplit = 1; j.hstride = 1;
-            j.hp = h->hp + ev * HP;
-            return j;
-        };
-        FwdArgs &FA = h->f_a[st], &FB = h->f_b[st];
-        base(FA, 5);
-        FA.job[0] = pij(Pm, x, 0, true);   FA.job[0].aug = h->xp; FA.job[0].aug_ld = h->ldxp; FA.job[0].w2snap = h->w2snap;
-        FA.job[1] = pij(Pm, x2, 1, false);
-        FA.job[2] = pij(Pt, x2, 2, false);
-        FA.job[3] = qj(Pm, 0, x, ac, 3, true); FA.job[3].aug = h->xa; FA.job[3].aug_ld = h->ldxa;
-        FA.job[4] = qj(Pm, 1, x, ac, 4, true);
-        auto offs = [&](FwdArgs &F) {
-            for (int i = 0; i < F.njobs; ++i) { F.hd.w2_off[i] = (int)(F.job[i].W2 - h->slab); F.hd.w1_off[i] = (int)(F.job[i].in.W1 - h->slab); }
-        };
-        offs(FA);
-        base(FB, 3);
-        auto from_pi = [&](FwdJob &j, int pev, const float *Ppi, const float *eps, int side) {
-            j.php = h->hp + pev * HP; j.pbmu = Ppi + L.pi_bmu; j.pbls = Ppi + L.pi_bls; j.peps = eps; j.side = side;
-        };
-        FB.job[0] = qj(Pm, 0, x, nullptr, 5, true);   from_pi(FB.job[0], 0, Pm, h->in[st][5], 1);
-        FB.job[1] = qj(Pt, 0, x2, nullptr, 6, false); from_pi(FB.job[1], 2, Pt, h->in[st][7], 2);
-        FB.job[2] = qj(Pt, 1, x2, nullptr, 7, false); from_pi(FB.job[2], 2, Pt, h->in[st][7], 0);
-        offs(FB);
-        BqArgs &Q = h->bq[st];
-        Q = BqArgs{};
-        Q.hd.pbase = h->slab; Q.hd.tiles_m = B / 32; Q.tiles_n = (h1 + 31) / 32; Q.hd.tpj = Q.hd.tiles_m * Q.tiles_n; Q.hd.h1 = h1; Q.hd.h2 = h2;
-        {
-            const int chunk = ((h2 + 15) >> 4) << 2;
-            int half = ((chunk + 7) >> 3) << 2;
-            if (half > chunk) half = chunk;
-            Q.ks_max = half < KS ? KS : half;
-            const int ta = 32 * (Q.ks_max + 2), tb = Q.ks_max * 36;
-            Q.op_lds = ta > tb ? ta : tb;
-        }
-        Q.B = B; Q.ldh1 = ldh1; Q.ldh2 = ldh2; Q.nt2 = nt2; Q.hp = h->hp;
-        Q.b3q1 = Pm + L.q_b3[0]; Q.b3q2 = Pm + L.q_b3[1]; Q.b3q1t = Pt + L.q_b3[0]; Q.b3q2t = Pt + L.q_b3[1];
-        Q.rew = h->in[st][3]; Q.done = h->in[st][4]; Q.logp0 = h->logp0; Q.logp1 = h->logp1;
-        Q.q1o = h->q1o; Q.q2o = h->q2o; Q.dq4 = h->dq4; Q.loss_part = h->loss_part;
-        Q.alpha = (float)cfg->alpha; Q.gamma = (float)cfg->gamma;
-        // slot 2 first: its dZ1 is what k_rows_c waits for
-        Q.job[0] = BqJob{h->H2 + 5 * BH2, Pm + L.q_W3[0], Pm + L.q_W2[0], h->H1 + 5 * BH1, h->dZ1 + 2 * BZ1, nullptr, 2};
-        Q.job[1] = BqJob{h->H2 + 3 * BH2, Pm + L.q_W3[0], Pm + L.q_W2[0], h->H1 + 3 * BH1, h->dZ1 + 0 * BZ1, h->dZ2 + 0 * BZ2, 0};
-        Q.job[2] = BqJob{h->H2 + 4 * BH2, Pm + L.q_W3[1], Pm + L.q_W2[1], h->H1 + 4 * BH1, h->dZ1 + 1 * BZ1, h->dZ2 + 1 * BZ2, 1};
-        for (int i = 0; i < 3; ++i) { Q.hd.h2_off[i] = (int)(Q.job[i].H2 - h->slab); Q.hd.w2_off[i] = (int)(Q.job[i].W2 - h->slab); }
     }
-    if (h->fused) {  // the policy backward launch + the Q wgrads whose B operands (dZ2, dq) k_bwdq wrote
-        h->g_bpi_f = h->g_bpi;
-        for (int q = 0; q < 2; ++q) {
-            gemm_add(h->g_bpi_f, gemm_wgrad(h->H1 + (3 + q) * BH1, ldh1, h1, h->dZ2 + q * BZ2, h2, h2, G + L.q_W2[q], h2, B));
-            gemm_add(h->g_bpi_f, gemm_wgrad(h->H2 + (3 + q) * BH2, ldh2, h2, h->dq4 + (long long)q * B * 4, 4, 1, G + L.q_W3[q], 1, B));
+    // ---- direct-operand path (sac1_direct.h)
+    if (h->fused) {
+        h->fused_l1_wgrad = true;
+        h->sh_cur = 0;
+        const float *S = h->slab;
+        const long long HP = (long long)DFH * B * DNT;
+        const long long H1I = (long long)B * h->Lp1, H2C = (long long)Np2 * B, H2R = (long long)B * h->Lp2;
+        // image slots — H1r4: 0 pi(x) 1 q1(x,a) 2 q2(x,a) 3 q1(x,pi);  H2c4: same;  H2r4: 0 pi(x) 1 q1(x,a) 2 q2(x,a)
+        auto steps = [](int D) { return D <= 8 ? 4 : (D <= 10 ? 5 : 6); };
+        for (int st = 0; st < 2; ++st) {
+            auto head = [&](DFHead &d) {
+                d = DFHead{};
+                d.base = S; d.tiles_m = B / 32; d.tpj = (B / 32) * nt2; d.K = h1; d.Np = Np2; d.B = B; d.d0 = o;
+                d.dw2_pi = (int)(L.pi_W2 - L.pi_W1); d.dw2_q = (int)(L.q_W2[0] - L.q_W1[0]);
+                d.x_off = (int)(h->in[st][0] - S); d.x2_off = (int)(h->in[st][1] - S); d.a_off = (int)(h->in[st][2] - S);
+            };
+            auto args = [&](DFArgs &F, int njobs) {
+                F = DFArgs{};
+                F.njobs = njobs; F.tiles_n = nt2; F.act = a; F.Lp1 = h->Lp1; F.Lp2 = h->Lp2; F.h2 = h2;
+                F.scale = (float)cfg->act_scale;
+                F.act0 = h->act0; F.act2 = h->act2; F.logp0 = h->logp0; F.logp1 = h->logp1; F.save0 = h->save0;
+                F.php1 = h->hp + 1 * HP; F.pbmu1 = Pm + L.pi_bmu; F.pbls1 = Pm + L.pi_bls; F.peps1 = h->in[st][6];
+                F.noise_on = 0; F.n_each = B * a; F.noise_seed = 0;
+                F.e0 = h->in[st][5]; F.e1 = h->in[st][6]; F.e2 = h->in[st][7]; F.opt = h->opt;
+            };
+            auto pij = [&](const float *P, int ev) {
+                DFJob j{};
+                j.b2 = P + L.pi_b2; j.wh0 = P + L.pi_Wmu; j.wh1 = P + L.pi_Wls; j.nh = 2 * a; j.hsplit = a; j.hstride = a;
+                j.hp = h->hp + ev * HP;
+                return j;
+            };
+            auto qj = [&](const float *P, int q, int ev) {
+                DFJob j{};
+                j.b2 = P + L.q_b2[q]; j.wh0 = P + L.q_W3[q]; j.wh1 = j.wh0; j.nh = 1; j.hsplit = 1; j.hstride = 1;
+                j.hp = h->hp + ev * HP;
+                return j;
+            };
+            const int ns_pi = steps(o) - 4, ns_q = steps(o + a) - 4;
+            DFHead &HA = h->fh_a[st], &HB = h->fh_b[st];
+            DFArgs &FA = h->f_a[st], &FB = h->f_b[st];
+            head(HA); args(FA, 5);
+            FA.job[0] = pij(Pm, 0); FA.job[0].H2c4 = h->H2c4; FA.job[0].H2r4 = h->H2r4; FA.job[0].H1r4 = h->H1r4;
+            FA.job[0].aug = h->xp; FA.job[0].aug_ld = h->ldxp;
+            FA.job[1] = pij(Pm, 1);
+            FA.job[2] = pij(Pt, 2);
+            FA.job[3] = qj(Pm, 0, 3); FA.job[3].H2c4 = h->H2c4 + 1 * H2C; FA.job[3].H2r4 = h->H2r4 + 1 * H2R; FA.job[3].H1r4 = h->H1r4 + 1 * H1I;
+            FA.job[3].xr4 = h->xa_r4;
+            FA.job[4] = qj(Pm, 1, 4); FA.job[4].H2c4 = h->H2c4 + 2 * H2C; FA.job[4].H2r4 = h->H2r4 + 2 * H2R; FA.job[4].H1r4 = h->H1r4 + 2 * H1I;
+            HA.w1o[0] = (int)(Pm + L.pi_W1 - S); HA.w1o[1] = HA.w1o[0]; HA.w1o[2] = (int)(Pt + L.pi_W1 - S);
+            HA.w1o[3] = (int)(Pm + L.q_W1[0] - S); HA.w1o[4] = (int)(Pm + L.q_W1[1] - S);
+            HA.pack = (ns_pi) | ((ns_pi | 4) << 6) | ((ns_pi | 4) << 12) | ((ns_q | 8 | 16) << 18) | ((ns_q | 8 | 16) << 24);
+            head(HB); args(FB, 3);
+            auto from_pi = [&](DFJob &j, int pev, const float *Ppi, const float *eps, int side) {
+                j.php = h->hp + pev * HP; j.pbmu = Ppi + L.pi_bmu; j.pbls = Ppi + L.pi_bls; j.peps = eps; j.side = side;
+            };
+            FB.job[0] = qj(Pm, 0, 5); from_pi(FB.job[0], 0, Pm, h->in[st][5], 1);
+            FB.job[0].H2c4 = h->H2c4 + 3 * H2C; FB.job[0].H1r4 = h->H1r4 + 3 * H1I;
+            FB.job[1] = qj(Pt, 0, 6); from_pi(FB.job[1], 2, Pt, h->in[st][7], 2);
+            FB.job[2] = qj(Pt, 1, 7); from_pi(FB.job[2], 2, Pt, h->in[st][7], 0);
+            HB.w1o[0] = (int)(Pm + L.q_W1[0] - S); HB.w1o[1] = (int)(Pt + L.q_W1[0] - S); HB.w1o[2] = (int)(Pt + L.q_W1[1] - S);
+            HB.w1o[3] = (int)(h->hp - S); HB.w1o[4] = 0;
+            HB.pack = (ns_q | 16) | ((ns_q | 4 | 16) << 6) | ((ns_q | 4 | 16) << 12);
+            // ---- backward launch 1: the three Q dgrads (slot 2 first: its dQ/da partials are what the next launch waits for)
+            DGJobs &Q = h->dg_bq[st];
+            Q = DGJobs{};
+            Q.hp = h->hp; Q.B = B;
+            Q.b3q1 = Pm + L.q_b3[0]; Q.b3q2 = Pm + L.q_b3[1]; Q.b3q1t = Pt + L.q_b3[0]; Q.b3q2t = Pt + L.q_b3[1];
+            Q.rew = h->in[st][3]; Q.done = h->in[st][4]; Q.logp0 = h->logp0; Q.logp1 = h->logp1;
+            Q.q1o = h->q1o; Q.q2o = h->q2o; Q.dq = h->dq; Q.loss_part = h->loss_part;
+            Q.alpha = (float)cfg->alpha; Q.gamma = (float)cfg->gamma;
+            auto dq_job = [&](int slot, int img, int q, float *C) {
+                DGJob j{};
+                j.type = DG_DGRAD_Q; j.M = B; j.N = h1; j.K = h2; j.slot = slot;
+                j.A = h->H2c4 + img * H2C; j.lda = B; j.B = h->c4_q[q]; j.ldb = Kp1;
+                j.gw = Pm + L.q_W3[q]; j.gdq = nullptr; j.gconst = -1.0f / (float)B;
+                j.mask = h->H1r4 + img * H1I; j.ldmask = h->Lp1; j.C = C; j.ldc = h->Lp1; j.adam_off = -1;
+                return j;
+            };
+            {
+                DGJob j = dq_job(2, 3, 0, nullptr);
+                j.wa = Pm + L.q_W1[0] + (long long)o * h1; j.da_part = h->da_part; j.nact = a;
+                dg_add(Q, j);
+            }
+            dg_add(Q, dq_job(0, 1, 0, h->dZ1r4));
+            dg_add(Q, dq_job(1, 2, 1, h->dZ1r4 + H1I));
         }
-        GemmJobs &J = h->g_bpi_f;
-        DDRL_REQUIRE(J.job[0].B == Pm + L.pi_W2 && J.job[0].part != nullptr, "internal: job 0 of the policy backward launch must be the pi dgrad");
-        J.job[0].B = h->w2snap;  // the wgrad tiles of this launch update pi W2 in place: read this update's copy instead
-        for (int i = 0; i < J.njobs; ++i) {
-            GemmJob &j = J.job[i];
-            if (!j.part && j.C >= G && j.C < G + L.total_int) j.adam_off = j.C - G;  // wgrads write straight into the gradient buffer
+        float *G = h->grad;
+        const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, L.n_pi_int,
+                          (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
+                          (float)cfg->polyak, (float)(1.0 - cfg->polyak), 0u};
+        auto wgrad_j4 = [&](const float *A, const float *Bm, long long w_off, long long b_off, float *shadow) {
+            DGJob j{};
+            j.type = DG_WGRAD_J4; j.M = h1 + 1; j.N = h2; j.K = B;
+            j.A = A; j.lda = h->Lp1; j.B = Bm; j.ldb = h->Lp2;
+            j.adam_off = w_off; j.ldc = Np2; j.bias_off = b_off; j.bias_row = h1; j.shadow = shadow; j.ld_sh = Kp1;
+            return j;
+        };
+        auto wgrad_rm = [&](const float *A, int lda, int M, const float *Bm, int ldb, int N, long long off) {
+            DGJob j{};
+            j.type = DG_WGRAD_RM; j.M = M; j.N = N; j.K = B; j.A = A; j.lda = lda; j.B = Bm; j.ldb = ldb; j.adam_off = off; j.ldc = N;
+            return j;
+        };
+        {   // ---- backward launch 2: policy-head backward tiles, loss means, Q layer-2 + head wgrads (optimizer in the epilogue)
+            DGJobs &M = h->dg_mid;
+            M = DGJobs{};
+            M.B = B; M.ad = ctx;
+            DGJob rc{};
+            rc.type = DG_ROWS_C; rc.M = B; rc.N = h2; rc.K = 0; rc.nact = a; rc.adam_off = -1;
+            rc.h2c4 = h->H2c4; rc.dap = h->da_part; rc.nparts = (h1 + 31) / 32; rc.save0 = h->save0;
+            rc.wmu = Pm + L.pi_Wmu; rc.wls = Pm + L.pi_Wls; rc.dz_c4 = h->dzpi_c4; rc.dz_r4 = h->dzpi_r4; rc.dhead_r4 = h->dhead_r4;
+            rc.ld_r4 = h->Lp2; rc.alpha = (float)cfg->alpha; rc.scale = (float)cfg->act_scale;
+            dg_add(M, rc);
+            DGJob ls{};
+            ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 3;
+            dg_add(M, ls);
+            for (int q = 0; q < 2; ++q) {
+                DGJob j = wgrad_j4(h->H1r4 + (1 + q) * H1I, h->H2r4 + (1 + q) * H2R, L.q_W2[q], L.q_b2[q], h->c4_q[q]);
+                j.bgen = 1; j.gw = Pm + L.q_W3[q]; j.gdq = h->dq + (long long)q * B;
+                dg_add(M, j);
+            }
+            for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
         }
-        J.ad = AdamCtx{0, h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, L.n_pi_int,
-                       (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
-                       (float)cfg->polyak, (float)(1.0 - cfg->polyak), 0u};
+        {   // ---- backward launch 3: policy dgrad (+ layer-1 wgrad partials), policy wgrads, Q layer-1 wgrads
+            DGJobs &P = h->dg_pi;
+            P = DGJobs{};
+            P.B = B; P.ad = ctx;
+            DGJob d{};
+            d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->dzpi_c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
+            d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = nullptr; d.ldc = h->Lp1; d.adam_off = -1;
+            d.part_x = h->xp; d.part = h->part; d.part_nk = o + 1; d.part_ldx = h->ldxp;
+            dg_add(P, d);
+            dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));
+            dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4, 32, a, L.pi_Wmu));
+            dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4 + (long long)a * 4, 32, a, L.pi_Wls));
+            for (int q = 0; q < 2; ++q) dg_add(P, wgrad_rm(h->xa_r4, 32, o + a + 1, h->dZ1r4 + q * H1I, h->Lp1, h1, L.q_W1[q]));
+        }
     }
 
     // ---- row kernels
@@ -1183,6 +1269,7 @@ int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *strea
     DDRL_REQUIRE(buf != nullptr, "unknown buffer id");
     ddrl::DeviceGuard g(h->device);
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_d, buf, nullptr, 1);
+    if (which == DDRL_SAC1_MAIN) refresh_shadows(h, ddrl::as_stream(stream));
     DDRL_LAUNCH_CHECK();
     if (which == DDRL_SAC1_GRAD) h->grad_imported = true;
     return DDRL_OK;
@@ -1194,6 +1281,7 @@ int ddrl_sac1_set_weights(ddrl_sac1_t *h, const float *flat_main_d, void *stream
     // copy into main AND target: Learner.set_weights runs target_init (actor_learner.py:125-127)
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_main_d, h->main_p,
                                                                                     h->target_p, 1);
+    refresh_shadows(h, ddrl::as_stream(stream));
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
@@ -1244,6 +1332,17 @@ int ddrl_sac1_opt_state_set(ddrl_sac1_t *h, int64_t t_pi, int64_t t_q, uint64_t 
     return DDRL_OK;
 }
 
+// Direct path: the dgrad images [h2/4][h1][4] of the main layer-2 kernels, regenerated from the k4-interleaved parameters
+// whenever those change outside the optimizer epilogues (set_weights / import / the flat Adam kernel).
+static void refresh_shadows(ddrl_sac1 *h, hipStream_t s) {
+    if (!h->fused) return;
+    const Layout &L = h->L;
+    const int h1 = h->cfg.hidden1, h2 = h->cfg.hidden2;
+    const dim3 grid((h1 + 31) / 32, (h2 / 4 + 7) / 8);
+    k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.pi_W2, h->c4_pi[h->sh_cur], h1, h2, L.Np2, L.Kp1);
+    for (int q = 0; q < 2; ++q) k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.q_W2[q], h->c4_q[q], h1, h2, L.Np2, L.Kp1);
+}
+
 static void launch_rows_c(ddrl_sac1 *h, hipStream_t s) {
     const RowsC &c = h->rc;
     const float *b = h->slab;
@@ -1256,41 +1355,57 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const ddrl_sac1_config_t &c = h->cfg;
     const int B = c.batch;
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
-    if (h->fused && stage <= 5) {
+    if (h->fused) {
         switch (stage) {
-            case 2: h->f_a[st].opt = h->opt + h->opt_cur; launch_fwd<0>(h->f_a[st], s); break;
+            case 2: h->f_a[st].opt = h->opt + h->opt_cur; launch_dfwd<0>(h->fh_a[st], h->f_a[st], s); break;
             case 5: {
-                FwdArgs &F = h->f_b[st];
+                DFArgs &F = h->f_b[st];
                 F.do_sample = h->sample_armed ? 1 : 0;
                 if (h->sample_armed) {
                     F.rs = h->smp_rs; F.ring = h->smp_ring; F.sample_batch = h->cfg.batch;
                     float **b = h->in[h->smp_set];
                     F.sout = ddrl_replay_dev::BatchPtrs{{b[0], b[1], b[2], b[3], b[4], nullptr}};
                 }
-                launch_fwd<1>(F, s);
+                launch_dfwd<1>(h->fh_b[st], F, s);
                 break;
             }
-            default: break;  // 1, 3: folded into the fused forward kernels
-        }
-        return;
-    }
-    if (h->fused && (stage == 6 || stage == 7 || stage == 9)) {
-        if (stage == 7) launch_bwdq(h->bq[st], s);  // 6 (k_rows_b) is folded into it
-        if (stage == 9) {
-            GemmJobs &J = h->g_bpi_f;
-            J.ad.on = h->fuse_apply ? 1 : 0;
-            J.ad.noise_adv = h->noise_pending;
-            J.ad.opt = h->opt + h->opt_cur;
-            launch_gemm(J, s);
-            if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
-                const AdamArgs &A = h->ad;
-                const float *b = h->slab;
-                const AdamL1Args L1{A.lr, A.b1, A.b2, A.eps, A.pk, A.pk1, h->noise_pending, A.n_pi >> 2, h->opt + (h->opt_cur ^ 1)};
-                k_adam_l1<<<(unsigned)((A.part_n4 + 255) / 256), 256, 0, s>>>(
-                    b, (int)(A.p - b), (int)(A.t - b), (int)(A.m - b), (int)(A.v - b), (int)(A.g - b), (int)(A.part - b), (int)A.part_off4,
-                    (int)A.part_n4, A.nparts, (int)A.part_stride4, (int)(reinterpret_cast<const float *>(h->opt + h->opt_cur) - b), L1);
-                h->opt_cur ^= 1;
+            case 7: launch_dg(h->dg_bq[st], s); break;
+            case 8: {
+                DGJobs &J = h->dg_mid;
+                J.ad.on = h->fuse_apply ? 1 : 0;
+                J.ad.opt = h->opt + h->opt_cur;
+                launch_dg(J, s);
+                break;
             }
+            case 9: {
+                DGJobs &J = h->dg_pi;
+                J.ad.on = h->fuse_apply ? 1 : 0;
+                J.ad.opt = h->opt + h->opt_cur;
+                J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image ...
+                J.job[1].shadow = h->c4_pi[h->sh_cur ^ 1];  // ... while the optimizer epilogue of the same launch writes the next one
+                launch_dg(J, s);
+                if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
+                    const AdamArgs &A = h->ad;
+                    const float *b = h->slab;
+                    const AdamL1Args L1{A.lr, A.b1, A.b2, A.eps, A.pk, A.pk1, h->noise_pending, A.n_pi >> 2, h->opt + (h->opt_cur ^ 1)};
+                    k_adam_l1<<<(unsigned)((A.part_n4 + 255) / 256), 256, 0, s>>>(
+                        b, (int)(A.p - b), (int)(A.t - b), (int)(A.m - b), (int)(A.v - b), (int)(A.g - b), (int)(A.part - b), (int)A.part_off4,
+                        (int)A.part_n4, A.nparts, (int)A.part_stride4, (int)(reinterpret_cast<const float *>(h->opt + h->opt_cur) - b), L1);
+                    h->opt_cur ^= 1;
+                    h->sh_cur ^= 1;
+                }
+                break;
+            }
+            case 11: {
+                const long long blocks = (h->L.total_int / 4 + 255) / 256;
+                h->ad.adam_blocks = (int)blocks;
+                h->ad.opt = h->opt + h->opt_cur; h->ad.opt_next = h->opt + (h->opt_cur ^ 1);
+                h->opt_cur ^= 1;
+                k_adam_polyak<<<(unsigned)(blocks + (h->ad.do_sample ? 1 : 0)), 256, 0, s>>>(h->ad);
+                refresh_shadows(h, s);
+                break;
+            }
+            default: break;  // 1, 3, 4, 6, 10: folded into the launches above
         }
         return;
     }
@@ -1474,11 +1589,18 @@ __global__ void k_opt_copy(const OptState *src, OptState *dst) { *dst = *src; }
 // captured graph starts and ends on the same copy whatever the number of updates it holds.
 int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
     DDRL_REQUIRE(h != nullptr, "handle is NULL");
-    if (h->opt_cur == 0) return DDRL_OK;
+    if (h->opt_cur == 0 && !(h->fused && h->sh_cur != 0)) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
-    k_opt_copy<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->opt + 1, h->opt);
-    DDRL_LAUNCH_CHECK();
-    h->opt_cur = 0;
+    if (h->opt_cur != 0) {
+        k_opt_copy<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->opt + 1, h->opt);
+        DDRL_LAUNCH_CHECK();
+        h->opt_cur = 0;
+    }
+    if (h->fused && h->sh_cur != 0) {  // same for the double-buffered dgrad image of the policy's layer-2 kernel
+        DDRL_HIP_CHECK(hipMemcpyAsync(h->c4_pi[0], h->c4_pi[1], (size_t)h->L.Np2 * h->L.Kp1 * sizeof(float), hipMemcpyDeviceToDevice,
+                                      ddrl::as_stream(stream)));
+        h->sh_cur = 0;
+    }
     return DDRL_OK;
 }
 

@@ -1,0 +1,862 @@
+// Direct-operand stages of the SAC1 update (included by sac1.hip, inside its anonymous namespace).
+//
+// Round-1's fused path staged every GEMM operand through LDS (coalesced float4 loads -> wave-private
+// transposition tile -> MFMA lane layout).  Measured on MI355X the matrix cores run at ~1.6 GHz under
+// this load and a stage is bounded by (MFMA issue) + (load -> LDS -> MFMA latency chain), so this path
+// removes the LDS hop altogether:
+//
+//   * every GEMM operand lives in memory in an "x4" layout — the CONTRACTION index interleaved by 4,
+//     the free index contiguous:  X4[k/4][i][k%4]  (ld = row stride of the free index).  One float4
+//     load per lane is then the operand of FOUR v_mfma_f32_32x32x2_f32 steps: in step e of group g
+//     the lanes of half h supply contraction index 8g + 4h + e (the order of a sum's terms is a free
+//     choice; both operands use the same one).  32 lanes x 16 B = 512 contiguous bytes per half-wave.
+//   * layer 1 is generated TRANSPOSED on the matrix cores: D = X1^T = W1^T x^T puts the batch row in
+//     the lane and the hidden unit in the register — exactly the A-operand layout of the layer-2
+//     MFMAs (unit (r&3) + 8(r>>2) + 4h in step r), so the accumulator registers feed the next MFMA
+//     after one v_max each; the matching W2 image is the k4-interleaved parameter layout itself.
+//   * a matrix that is contracted along different axes by different GEMMs is kept in both layouts
+//     (W2 of the main networks: [h1/4][h2][4] for the forward + [h2/4][h1][4] for the dgrad, both
+//     written by the optimizer epilogue; H1 / H2 / dZ: written in the layouts their consumers need
+//     by the epilogue that has the tile in LDS anyway).
+//
+// Launches of one update (all captured in the learner's hipGraph):
+//   k_dfwd<0>  evaluations 0-4 (layer 1 + layer 2 + head partials)            400 tiles
+//   k_dfwd<1>  evaluations 5-7, action from the policy-head partials (+ sampler workgroup)
+//   k_dg "bq"  the three Q dgrads, dZ2 generated from H2 on the fly; dQ/da partials
+//   k_dg "mid" policy-head backward as 32x32 tiles + the Q layer-2 / head wgrads with Adam + polyak
+//   k_dg "pi"  policy dgrad (+ layer-1 wgrad partials), policy wgrads, Q layer-1 wgrads, Adam + polyak
+//   k_adam_l1  the policy layer-1 step (sum of row-tile partials) + optimizer bookkeeping
+
+constexpr int DFH = 8;    // head slots per evaluation (2 * act_dim <= 8)
+constexpr int DNT = 16;   // n-tile slots of a head-partial row (hidden2 <= 512)
+constexpr int DGMAX = 16; // 8-deep contraction groups per wave (contraction <= 512)
+
+__device__ __forceinline__ int d_slot(int s, int h) { return s < 4 ? 4 * h + s : 8 + 2 * (s - 4) + h; }
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));  // fmaxf() costs a canonicalising v_max in front
+    return y;
+}
+static inline int rup32(int x) { return (x + 31) & ~31; }
+
+// One row of one policy evaluation, all action dims in one lane.  Same formulae and operation order
+// as policy_head() (core.py:49-87, 104-106); mu / log_std pre-activations arrive as sums of partials.
+struct PolRow {
+    float act[4], a[4], std[4], t[4];
+    float logp;
+};
+__device__ __forceinline__ PolRow policy_row(const float (&mu)[4], const float (&lsr)[4], const float (&eps)[4], int act, float scale) {
+    PolRow o;
+    float sp = 0.f, sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        o.act[c] = 0.f; o.a[c] = 0.f; o.std[c] = 0.f; o.t[c] = 0.f;
+        if (c < act) {
+            const float t = tanhf(lsr[c]);
+            const float log_std = -20.0f + 11.0f * (t + 1.0f);
+            const float std = expf(log_std);
+            const float e = eps[c];
+            const float u = mu[c] + e * std;
+            const float z = (e * std) / (std + STD_EPS);
+            const float pre = -0.5f * ((z * z + 2.0f * log_std) + LOG2PI);
+            const float a = tanhf(u);
+            const float om = 1.0f - a * a;
+            const float cl = fminf(fmaxf(om, 0.f), 1.f);
+            const float corr = logf(cl + 1e-6f);
+            sp += pre; sc += corr;
+            o.act[c] = a * scale; o.a[c] = a; o.std[c] = std; o.t[c] = t;
+        }
+    }
+    o.logp = sp - sc;
+    return o;
+}
+
+// ==========================================================================================
+// forward stages
+// ==========================================================================================
+struct DFJob {
+    const float *b2;         // [Np2] (pads are zero)
+    const float *wh0, *wh1;  // head kernels — policy: Wmu, Wls ([h2][act]); Q: W3 ([h2])
+    int nh, hsplit, hstride;
+    float *hp;               // head partials [DFH][B][DNT]
+    float *H2c4;             // [Np2/4][B][4]   (nullable)  A operand of the dgrads / relu mask of the policy head backward
+    float *H2r4;             // [B/4][Lp2][4]   (nullable)  A operand of the head wgrads, relu mask of the generated Q wgrad operand
+    float *H1r4;             // [B/4][Lp1][4]   (nullable, n-tile-0 workgroups)  A operand of the W2 wgrads, relu mask of the dgrads
+    float *aug;              // [B][aug_ld] row-major [in0 | in1] rows (nullable, n-tile-0): layer-1 wgrad partial operand (policy)
+    float *xr4;              // [B/4][32][4] augmented input rows (nullable, n-tile-0): A operand of the Q layer-1 wgrads
+    int aug_ld;
+    // phase 1: the policy evaluation whose sampled action is this job's second input
+    const float *php, *pbmu, *pbls, *peps;
+    int side;                // n-tile-0 workgroups: 1 -> act0, logp0, save0   2 -> act2, and logp1 from php1
+};
+struct DFArgs {
+    int njobs, tiles_n, act, Lp1, Lp2, h2;
+    float scale;
+    float *act0, *act2, *logp0, *logp1, *save0;
+    const float *php1, *pbmu1, *pbls1, *peps1;  // pi_main @ x2: only its log-prob is needed (actor_learner.py:62)
+    int noise_on, n_each;
+    uint32_t noise_seed;
+    float *e0, *e1, *e2;
+    const OptState *opt;
+    int do_sample, sample_batch;
+    ddrl_replay_dev::RingState *rs;
+    ddrl_replay_dev::RingPtrs ring;
+    ddrl_replay_dev::BatchPtrs sout;
+    DFJob job[5];
+};
+// leading scalars of k_dfwd (preloaded into SGPRs at wave launch: the first loads need nothing else)
+struct DFHead {
+    const float *base;  // every offset below is relative to the slab
+    int tpj, tiles_m;   // tiles per job, row tiles
+    int K, Np;          // hidden1, padded hidden2 (row stride of the k4-interleaved W2)
+    int B, d0;          // batch, obs_dim
+    int w1o[5];         // per job: [W1 ; b1] offset.  phase 1: [3] = head-partial buffer
+    int dw2_pi, dw2_q;  // W2 offset - W1 offset of a policy / Q network
+    int x_off, x2_off, a_off;
+    int pack;           // 6 bits per job: [1:0] layer-1 MFMA steps - 4, [2] input is x2, [3] second input from memory, [4] Q network
+};
+
+// One 32-unit block of the K loop: layer 1 (NS MFMA steps) -> relu -> 4 * nrq layer-2 MFMA steps.
+template <int NS>
+__device__ __forceinline__ void dblock(const float (&w1)[6], const float4 (&bia)[4], const float (&xin)[6], const float4 (&bq)[4], int nrq, floatx16 &x1,
+                                       floatx16 &acc) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) { x1[4 * rq + 0] = bia[rq].x; x1[4 * rq + 1] = bia[rq].y; x1[4 * rq + 2] = bia[rq].z; x1[4 * rq + 3] = bia[rq].w; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[s], xin[s], x1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x1[r] = relu1(x1[r]);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        if (rq < nrq) {  // wave-uniform
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[4 * rq + 0], bq[rq].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[4 * rq + 1], bq[rq].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[4 * rq + 2], bq[rq].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[4 * rq + 3], bq[rq].w, acc, 0, 0, 0);
+        }
+    }
+}
+
+// K loop of one wave: blocks [b0, b0 + nb) of 32 hidden-1 units.  Every load is issued before the first MFMA.
+// h1r4 != nullptr (n-tile-0 workgroups of a differentiated evaluation): X1 also goes to memory as [row/4][unit][4]
+// through a wave-private LDS tile (registers hold row-in-lane / unit-in-register; the image wants 4 rows per float4).
+template <int NS>
+__device__ __forceinline__ void dkloop(const float *__restrict__ W1, const float *__restrict__ W2p, int K, int D, int Np, int b0, int nb, int n0, int lane,
+                                       const float (&xin)[6], floatx16 &acc, float *__restrict__ h1r4, int Lp1, int m0, float *__restrict__ tr) {
+    const int l31 = lane & 31, h = lane >> 5;
+    float4 bq[4][4], bia[4][4];
+    float w1[4][6];
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {  // loads beyond nb re-read the last block (no branches before the loads)
+        const int u0 = (b0 + (bi < nb ? bi : nb - 1)) * 32;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+        const int u0 = (b0 + (bi < nb ? bi : nb - 1)) * 32;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w1[bi][s] = W1[(long long)d_slot(s, h) * K + u0 + l31];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) bia[bi][rq] = *reinterpret_cast<const float4 *>(W1 + (long long)D * K + u0 + 8 * rq + 4 * h);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+        if (bi < nb) {
+            const int u0 = (b0 + bi) * 32;
+            const int nrq = (K - u0 >= 32) ? 4 : ((K - u0 + 7) >> 3);
+            floatx16 x1;
+            dblock<NS>(w1[bi], bia[bi], xin, bq[bi], nrq, x1, acc);
+            if (h1r4) {  // block-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = x1[r];
+                wave_lds_sync();
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int rg = h + 2 * p;
+                    const float4 v = *reinterpret_cast<const float4 *>(tr + l31 * 36 + 4 * rg);
+                    if (u0 + l31 < K) *reinterpret_cast<float4 *>(h1r4 + ((long long)(m0 / 4 + rg) * Lp1 + u0 + l31) * 4) = v;
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+}
+
+template <int PH>
+__global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int w1o0, int w1o1, int w1o2, int w1o3, int w1o4, int dw2_pi,
+                                              int dw2_q, int x_off, int x2_off, int a_off, int pack, DFArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][32][33];
+    __shared__ __attribute__((aligned(16))) float tr[4][32 * 36];
+    __shared__ float s_wh[DFH][32];
+    const int tpj = tpj_tm & 0xffff, tiles_m = tpj_tm >> 16;
+    if (PH == 1 && (int)blockIdx.x == 3 * tpj) {  // only launched when a.do_sample
+        ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
+        return;
+    }
+    int t;
+    {   // XCD-aware, panel-major tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s); give each XCD a
+        // contiguous run of tiles so that a W2 panel is fetched by one or two L2s instead of all eight (speed only)
+        const int nwg = (PH == 0 ? 5 : 3) * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int ji = (t >= tpj) + (t >= 2 * tpj) + (t >= 3 * tpj) + (t >= 4 * tpj);
+    t -= ji * tpj;
+    const int nt = (t * (65536 / tiles_m + 1)) >> 16;  // t / tiles_m (t < 8192, tiles_m <= 2047)
+    const int m0 = (t - nt * tiles_m) * 32, n0 = nt * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int K = K_Np & 0xffff, Np = K_Np >> 16, B = B_d0 & 0xffff, d0 = (B_d0 >> 16) & 0xff, act = B_d0 >> 24;
+    const int jp = (pack >> (6 * ji)) & 63;
+    const int ns = 4 + (jp & 3);
+    const bool is_q = (jp & 16) != 0;
+    const int d1 = PH == 1 ? act : ((jp & 8) ? act : 0);
+    const int w1o = ji == 0 ? w1o0 : (ji == 1 ? w1o1 : (ji == 2 ? w1o2 : (PH == 0 ? (ji == 3 ? w1o3 : w1o4) : w1o2)));
+    const float *W1 = base + w1o, *W2p = W1 + (is_q ? dw2_q : dw2_pi);
+    const bool first_n = nt == 0;
+    // this wave's 32-unit blocks: the waves at the END get the extra (possibly partial) block
+    const int nblk = (K + 31) >> 5, bs = nblk >> 2, rem = nblk & 3;
+    const int nb = bs + (w >= 4 - rem ? 1 : 0);
+    const int b0 = w * bs + (w > 4 - rem ? w - (4 - rem) : 0);
+
+    // ---- phase 1: what its longest chain starts with — the policy-head partials of this tile's rows (-> action -> layer-1 input).
+    // Lanes of half 0 sum the mu heads, half 1 the log_std heads (n-tile order; unused slots are 0).
+    float hs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool two = PH == 1 && ji == 1 && first_n;  // block-uniform: pi_main @ x2 rides here (log-prob only)
+    if (PH == 1) {
+        const int actq = d1;
+        const long long HPq = (long long)DFH * B * DNT;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 0 || two) {
+                const float *hp = base + w1o3 + (e == 0 ? (ji == 0 ? 0 : 2) : 1) * HPq;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < actq) {
+                        const float4 *p4 = reinterpret_cast<const float4 *>(hp + ((long long)(h * actq + c) * B + m0 + l31) * DNT);
+                        float4 v[DNT / 4];
+#pragma unroll
+                        for (int q = 0; q < DNT / 4; ++q) v[q] = p4[q];
+                        float s = 0.f;
+#pragma unroll
+                        for (int q = 0; q < DNT / 4; ++q) { s += v[q].x; s += v[q].y; s += v[q].z; s += v[q].w; }
+                        hs[e][c] = s;
+                    }
+                }
+            }
+        }
+    }
+    // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
+    const int D = d0 + d1;
+    float xin[6];
+    {
+        const float *in0 = base + ((jp & 4) ? x2_off : x_off), *in1 = base + a_off;
+        const long long row = m0 + l31;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int d = d_slot(s, h);
+            const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
+            const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
+            const float v = *p;
+            xin[s] = (f0 || f1) ? v : 0.f;
+        }
+    }
+    const DFJob &jb = a.job[ji];
+    // ---- epilogue operands
+    const float4 b4 = *reinterpret_cast<const float4 *>(jb.b2 + n0 + 4 * (tid >> 5));
+    float whv = 0.f;
+    {
+        const int c = tid >> 5, col = n0 + (tid & 31);
+        const bool ok = c < jb.nh && col < a.h2;
+        const float *p = c < jb.hsplit ? jb.wh0 : jb.wh1;
+        const int cc = c < jb.hsplit ? c : c - jb.hsplit;
+        whv = ok ? p[(long long)col * jb.hstride + cc] : 0.f;
+    }
+    if (PH == 1) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
+        float mu[4], ls[4], ev[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float o = __shfl_xor(hs[0][c], 32);
+            const int cc = c < d1 ? c : 0;
+            mu[c] = (h ? o : hs[0][c]) + jb.pbmu[cc];
+            ls[c] = (h ? hs[0][c] : o) + jb.pbls[cc];
+            ev[c] = jb.peps[(long long)(m0 + l31) * d1 + cc];
+        }
+        const PolRow o = policy_row(mu, ls, ev, d1, a.scale);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int d = d_slot(s, h), c = d - d0;
+            if (d >= d0 && d < D) xin[s] = c == 0 ? o.act[0] : (c == 1 ? o.act[1] : (c == 2 ? o.act[2] : o.act[3]));
+        }
+        if (first_n && w == 0 && lane < 32) {
+            const int row = m0 + l31;
+            if (jb.side == 1) {
+                a.logp0[row] = o.logp;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < d1) {
+                        a.act0[row * d1 + c] = o.act[c];
+                        *reinterpret_cast<float4 *>(a.save0 + ((long long)row * d1 + c) * 4) = make_float4(o.a[c], o.std[c], o.t[c], ev[c]);
+                    }
+            } else if (jb.side == 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < d1) a.act2[row * d1 + c] = o.act[c];
+            }
+        }
+        if (two && w == 1) {  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float o2 = __shfl_xor(hs[1][c], 32);
+                const int cc = c < d1 ? c : 0;
+                mu[c] = (h ? o2 : hs[1][c]) + a.pbmu1[cc];
+                ls[c] = (h ? hs[1][c] : o2) + a.pbls1[cc];
+                ev[c] = a.peps1[(long long)(m0 + l31) * d1 + cc];
+            }
+            const PolRow o1 = policy_row(mu, ls, ev, d1, a.scale);
+            if (lane < 32) a.logp1[m0 + l31] = o1.logp;
+        }
+    }
+    s_wh[tid >> 5][tid & 31] = whv;
+    if (first_n && (jb.aug || jb.xr4)) {  // augmented input rows of the layer-1 wgrads (their ones column is set once at create)
+        for (int idx = tid; idx < 32 * D; idx += 256) {
+            const int r = idx / D, d = idx - r * D;
+            const long long row = m0 + r;
+            const float v = d < d0 ? (base + ((jp & 4) ? x2_off : x_off))[row * d0 + d] : (base + a_off)[row * d1 + (d - d0)];
+            if (jb.aug) jb.aug[row * jb.aug_ld + d] = v;
+            if (jb.xr4) jb.xr4[((row >> 2) * 32 + d) * 4 + (row & 3)] = v;
+        }
+    }
+    if (PH == 0 && a.noise_on && ji == 0 && first_n) {
+        // eps_x, eps_x2, eps_t of this tile's rows; element index as in one flat [3][B*act] fill
+        const unsigned long long nbase = a.opt->noise_ctr;
+        const int per_row = 3 * act;
+        for (int e = tid; e < 32 * per_row; e += 256) {
+            const int rr = e / per_row, q = e - rr * per_row;
+            const int wch = q / act, c = q - wch * act;
+            const int k = (m0 + rr) * act + c;
+            (wch == 0 ? a.e0 : (wch == 1 ? a.e1 : a.e2))[k] = normal_at(a.noise_seed, nbase + (unsigned long long)wch * a.n_each + k);
+        }
+    }
+
+    // ---- K loop
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
+    if (nb > 0) {
+        if (ns == 4) dkloop<4>(W1, W2p, K, D, Np, b0, nb, n0, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+        else if (ns == 5) dkloop<5>(W1, W2p, K, D, Np, b0, nb, n0, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+        else dkloop<6>(W1, W2p, K, D, Np, b0, nb, n0, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+    }
+
+    // ---- split-K combine, bias + relu, H2 in the layouts its consumers read, head partials
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+    __syncthreads();
+    const int r = tid & 31, cg = tid >> 5;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * cg + e;
+        const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+        v[e] = fmaxf(s + (e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w))), 0.f);
+    }
+    if (jb.H2c4) *reinterpret_cast<float4 *>(jb.H2c4 + ((long long)(n0 / 4 + cg) * B + m0 + r) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[0][r][4 * cg + e] = v[e];
+    __syncthreads();
+    if (jb.H2r4) {  // (column hidden2 of the image is the ones column: never written here)
+        const int c = tid & 31, rg = tid >> 5;
+        if (n0 + c < a.h2)
+            *reinterpret_cast<float4 *>(jb.H2r4 + ((long long)(m0 / 4 + rg) * a.Lp2 + n0 + c) * 4) =
+                make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
+    }
+    {
+        const int c = tid >> 5;
+        if (c < jb.nh) {
+            float s = 0.f;
+#pragma unroll
+            for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
+            jb.hp[((long long)c * B + m0 + r) * DNT + nt] = s;
+        }
+    }
+}
+
+template <int PH>
+static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s) {
+    k_dfwd<PH><<<F.njobs * d.tpj + ((PH == 1 && F.do_sample) ? 1 : 0), 256, 0, s>>>(d.base, d.tpj | (d.tiles_m << 16), d.K | (d.Np << 16), d.B | (d.d0 << 16) | (F.act << 24), d.w1o[0], d.w1o[1],
+                                                                                    d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+}
+
+// ==========================================================================================
+// k_dg: the backward launches.  One workgroup = one 32x32 output tile of one job; the four waves split the contraction
+// in 8-deep groups; both operands are x4 images read straight into the MFMA lane layout.
+// ==========================================================================================
+enum { DG_DGRAD_Q = 0, DG_DGRAD = 1, DG_WGRAD_J4 = 2, DG_WGRAD_RM = 3, DG_ROWS_C = 4, DG_LOSS = 5 };
+struct DGJob {
+    int type;
+    int M, N, K;             // output M x N, contraction length K
+    int tiles_m, tile_start, ntiles;
+    const float *A, *B;      // x4 images: [K/4][lda][4], [K/4][ldb][4]
+    int lda, ldb;
+    // generated operands
+    const float *gw;         // DGRAD_Q: W3[k] (A = dq[row] * W3[k] * (H2 > 0));  WGRAD with bgen: W3[n] (B = dq[r] * W3[n] * (H2 > 0))
+    const float *gdq;        // DGRAD_Q: nullptr -> the constant gconst;  bgen: dq[r] (flat [B])
+    float gconst;
+    int bgen;
+    int slot;                // DGRAD_Q: 0 q1(x,a)  1 q2(x,a)  2 q1(x,pi)
+    // dgrad epilogue
+    const float *mask;       // H1r4 [M/4][ldmask][4]
+    int ldmask;
+    float *C;                // dgrad: dZ1r4 [M/4][ldc][4] (nullable);  WGRAD_RM: gradient, row-major (row stride ldc)
+    int ldc;
+    const float *wa;         // DGRAD_Q slot 2: action rows of the main q1 layer-1 kernel [act][N]
+    float *da_part;          // ... dQ/da partials [tiles_n][B][4]
+    int nact;
+    const float *part_x;     // DGRAD: fused layer-1 wgrad partials (see gemm_core.h)
+    float *part;
+    int part_nk, part_ldx;
+    // wgrad epilogue (optimizer): offsets into the flat parameter-shaped buffers
+    long long adam_off;      // J4: the W2 image;  RM: element (0, 0)
+    long long bias_off;      // J4: b2
+    int bias_row;            // J4: contraction-side row that holds the bias gradient (= hidden1: the ones row of H1r4)
+    float *shadow;           // J4: the dgrad image [N/4][ld_sh][4] of the updated kernel (nullable)
+    int ld_sh;
+    // DG_ROWS_C (M = batch, N = hidden2): policy-head backward + dZ2 of the policy trunk as tiles
+    const float *h2c4;       // relu mask [N/4][B][4]
+    const float *dap;        // dQ/da partials [nparts][B][4]
+    int nparts;
+    const float *save0, *wmu, *wls;
+    float *dz_c4, *dz_r4, *dhead_r4;
+    int ld_r4;
+    float alpha, scale;
+    // DG_LOSS
+    const float *loss_part;
+    float *losses;
+    int nl;
+};
+constexpr int MAX_DG_JOBS = 8;
+struct DGJobs {
+    int njobs, total_tiles;
+    int tile_start[MAX_DG_JOBS];
+    AdamCtx ad;
+    // DGRAD_Q prologue (actor_learner.py:58-69)
+    const float *hp;   // head partials [NEVAL][DFH][B][DNT]
+    const float *b3q1, *b3q2, *b3q1t, *b3q2t;
+    const float *rew, *done, *logp0, *logp1;
+    float *q1o, *q2o, *dq, *loss_part;
+    float alpha, gamma;
+    int B;
+    DGJob job[MAX_DG_JOBS];
+};
+
+__device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+template <int GMAX>
+__global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, int ts3, int ts4, int ts5, int ts6, int ts7, int hp_off_unused, DGJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float red[4][32][33];
+    __shared__ float s_q[8][32];
+    __shared__ float s_g[32];
+    __shared__ float s_px[32][13];
+    __shared__ float s_wa[4][32];
+    int t, ji;
+    {
+        const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    static_assert(MAX_DG_JOBS == 8, "k_dg takes tile_start[1..7] as scalar arguments");
+    ji = (t >= ts1) + (t >= ts2) + (t >= ts3) + (t >= ts4) + (t >= ts5) + (t >= ts6) + (t >= ts7);
+    const DGJob &jb = jobs.job[ji];
+    t -= jb.tile_start;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int type = jb.type;
+    const int Bn = jobs.B;
+
+    if (type == DG_LOSS) {
+        // reduce_mean over the batch: per-row terms summed in a fixed order (lane-strided partial sums, then the xor tree)
+        if (w != 0) return;
+        float s3[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b0 = 0; b0 < Bn; b0 += 64) {
+            const int b = b0 + lane;
+            const bool ok = b < Bn;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = jb.loss_part[(ok ? b : 0) * jb.nl + (c < jb.nl ? c : 0)];
+                s3[c] += (ok && c < jb.nl) ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float tot = wave_sum(s3[c]);
+            const float mean = tot / (float)Bn;
+            if (lane == 0 && c < jb.nl) jb.losses[c] = c == 0 ? mean : 0.5f * mean;
+        }
+        return;
+    }
+    const int tiles_m = jb.tiles_m;
+    const int mt = t % tiles_m, nt = t / tiles_m;
+    const int m0 = mt * 32, n0 = nt * 32;
+    const int r = tid & 31, cg = tid >> 5;
+
+    if (type == DG_ROWS_C) {
+        // Policy-head backward for the 32 rows of this tile (d pi_loss / d (mu_raw, log_std_raw), through tanh-squash,
+        // reparameterisation and clip-pass-gradient) — every thread for its row, eight-fold redundant, no exchange —
+        // then dZ2[r][c] = (H2[r][c] > 0) * sum_a (dmu[a] Wmu[c][a] + dls[a] Wls[c][a]) for four consecutive c.
+        const int act = jb.nact, row = m0 + r;
+        float4 dp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dp[q] = *reinterpret_cast<const float4 *>(jb.dap + ((long long)(q < jb.nparts ? q : 0) * Bn + row) * 4);
+        float4 sv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sv[c] = *reinterpret_cast<const float4 *>(jb.save0 + ((long long)row * act + (c < act ? c : 0)) * 4);
+        const float4 hm = *reinterpret_cast<const float4 *>(jb.h2c4 + ((long long)(n0 / 4 + cg) * Bn + row) * 4);
+        float wm[4][4], wl[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = n0 + 4 * cg + e;
+            const bool okc = c < jb.N;
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2) {
+                const long long o = (long long)(okc ? c : 0) * act + (a2 < act ? a2 : 0);
+                const float vm = jb.wmu[o], vl = jb.wls[o];
+                wm[e][a2] = (okc && a2 < act) ? vm : 0.f;
+                wl[e][a2] = (okc && a2 < act) ? vl : 0.f;
+            }
+        }
+        float ga[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < jb.nparts) { ga[0] += dp[q].x; ga[1] += dp[q].y; ga[2] += dp[q].z; ga[3] += dp[q].w; }
+        float dmu[4], dls[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float av = sv[c].x, std = sv[c].y, tt = sv[c].z, e = sv[c].w;
+            const float glp = jb.alpha / (float)Bn;  // d pi_loss / d logp_pi
+            const float om = 1.0f - av * av;
+            const float cl = fminf(fmaxf(om, 0.f), 1.f);
+            const float du = (ga[c] * jb.scale) * om + glp * ((2.0f * av * om) / (cl + 1e-6f));
+            const float sd = std + STD_EPS;
+            const float z = (e * std) / sd;
+            const float dzdl = ((e * std) * STD_EPS) / (sd * sd);
+            const float dl = du * (e * std) + glp * (-(z * dzdl) - 1.0f);
+            dmu[c] = c < act ? du : 0.f;
+            dls[c] = c < act ? dl * (11.0f * (1.0f - tt * tt)) : 0.f;
+        }
+        float z4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float acc = fmaf(dls[0], wl[e][0], dmu[0] * wm[e][0]);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { acc = fmaf(dmu[c], wm[e][c], acc); acc = fmaf(dls[c], wl[e][c], acc); }
+            z4[e] = f4e(hm, e) > 0.f ? acc : 0.f;
+        }
+        *reinterpret_cast<float4 *>(jb.dz_c4 + ((long long)(n0 / 4 + cg) * Bn + row) * 4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[0][r][4 * cg + e] = z4[e];
+        if (nt == 0 && cg == 0) {  // dhead image [row/4][32][4]: columns [dmu | dls]
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < act) {
+                    jb.dhead_r4[((long long)(row >> 2) * 32 + c) * 4 + (row & 3)] = dmu[c];
+                    jb.dhead_r4[((long long)(row >> 2) * 32 + act + c) * 4 + (row & 3)] = dls[c];
+                }
+        }
+        __syncthreads();
+        {
+            const int c = tid & 31, rg = tid >> 5;
+            *reinterpret_cast<float4 *>(jb.dz_r4 + ((long long)(m0 / 4 + rg) * jb.ld_r4 + n0 + c) * 4) =
+                make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
+        }
+        return;
+    }
+
+    // ---- GEMM tiles.  This wave's 8-deep contraction groups: the waves at the END get the extra ones
+    const int G = (jb.K + 7) >> 3, gs = G >> 2, grem = G & 3;
+    const int ng = gs + (w >= 4 - grem ? 1 : 0);
+    const int g0 = w * gs + (w > 4 - grem ? w - (4 - grem) : 0);
+    const bool first_n = nt == 0;
+
+    // DGRAD_Q: the Q-head partials of this tile's rows first (-> dq -> the generated A operand); c = 0..4 <-> evaluations 3..7
+    float qsum = 0.f;
+    const bool need_q = type == DG_DGRAD_Q && jb.slot != 2;
+    if (need_q) {
+        const int c = tid >> 5;
+        const long long HP = (long long)DFH * Bn * DNT;
+        const float4 *p4 = reinterpret_cast<const float4 *>(jobs.hp + (3 + (c < 5 ? c : 0)) * HP + (long long)(m0 + r) * DNT);
+        float4 v[DNT / 4];
+#pragma unroll
+        for (int q = 0; q < DNT / 4; ++q) v[q] = p4[q];
+#pragma unroll
+        for (int q = 0; q < DNT / 4; ++q) { qsum += v[q].x; qsum += v[q].y; qsum += v[q].z; qsum += v[q].w; }
+    }
+    // both operand streams of this wave
+    float4 a4[GMAX], b4[GMAX];
+    {
+        const float *Ap = jb.A + (long long)(m0 + l31) * 4, *Bp = jb.B + (long long)(n0 + l31) * 4;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < ng) {  // wave-uniform
+                const long long kg = 2 * (g0 + g) + h;
+                a4[g] = *reinterpret_cast<const float4 *>(Ap + kg * jb.lda * 4);
+                b4[g] = *reinterpret_cast<const float4 *>(Bp + kg * jb.ldb * 4);
+            }
+        }
+    }
+    // ---- epilogue operands, fetched behind the operand streams
+    const bool is_dgrad = type == DG_DGRAD_Q || type == DG_DGRAD;
+    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (is_dgrad) mk = *reinterpret_cast<const float4 *>(jb.mask + ((long long)(m0 / 4 + cg) * jb.ldmask + n0 + r) * 4);  // mapping C: (col r, row group cg)
+    if (is_dgrad && jb.da_part) {
+        const int c = tid >> 5, col = n0 + (tid & 31);
+        if (c < 4) s_wa[c][tid & 31] = (c < jb.nact && col < jb.N) ? jb.wa[(long long)c * jb.N + col] : 0.f;
+    }
+    if (type == DG_DGRAD && jb.part) {
+        for (int idx = tid; idx < 32 * 12; idx += 256) {
+            const int rr = idx / 12, k = idx - rr * 12;
+            const bool ok = k < jb.part_nk;
+            const float v = jb.part_x[(long long)(m0 + rr) * jb.part_ldx + (ok ? k : 0)];
+            s_px[rr][k] = ok ? v : 0.f;
+        }
+    }
+    const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || type == DG_WGRAD_RM) && jb.adam_off >= 0;
+    float al_pi = 0.f, al_q = 0.f;
+    if (jobs.ad.on) {
+        const float b1p_pi = jobs.ad.opt->b1p_pi, b2p_pi = jobs.ad.opt->b2p_pi, b1p_q = jobs.ad.opt->b1p_q, b2p_q = jobs.ad.opt->b2p_q;
+        al_pi = jobs.ad.lr * sqrtf(1.0f - b2p_pi) / (1.0f - b1p_pi);
+        al_q = jobs.ad.lr * sqrtf(1.0f - b2p_q) / (1.0f - b1p_q);
+    }
+    // optimizer state of this tile: J4 — thread (col r, row group cg) owns rows 4cg..4cg+3 of column r as one float4;
+    // RM — thread owns elements (o >> 5, o & 31), o = tid + 256 q
+    float4 j_m, j_v, j_p, j_t;
+    float bm = 0.f, bv = 0.f, bp = 0.f, bt = 0.f;
+    float am[4], av[4], ap[4], at[4];
+    bool okv[4];
+    long long j_idx = 0, b_idx = 0;
+    bool j_ok = false, b_ok = false;
+    if (type == DG_WGRAD_J4) {
+        j_ok = m0 + 4 * cg < jb.bias_row && n0 + r < jb.N;
+        j_idx = jb.adam_off + ((long long)(m0 / 4 + cg) * jb.ldc + n0 + r) * 4;
+        b_ok = m0 + 4 * cg == jb.bias_row && n0 + r < jb.N;  // (hidden1 % 4 == 0: the bias row opens a group)
+        b_idx = jb.bias_off + n0 + r;
+        if (do_adam) {
+            const long long ic = j_ok ? j_idx : jb.adam_off;
+            j_m = *reinterpret_cast<const float4 *>(jobs.ad.m + ic); j_v = *reinterpret_cast<const float4 *>(jobs.ad.v + ic);
+            j_p = *reinterpret_cast<const float4 *>(jobs.ad.p + ic); j_t = *reinterpret_cast<const float4 *>(jobs.ad.t + ic);
+            const long long bc = b_ok ? b_idx : jb.bias_off;
+            bm = jobs.ad.m[bc]; bv = jobs.ad.v[bc]; bp = jobs.ad.p[bc]; bt = jobs.ad.t[bc];
+        }
+    } else if (type == DG_WGRAD_RM) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = tid + 256 * q;
+            const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+            okv[q] = gi < jb.M && gj < jb.N;
+            if (do_adam) {
+                const long long idx = okv[q] ? jb.adam_off + (long long)gi * jb.ldc + gj : jb.adam_off;
+                am[q] = jobs.ad.m[idx]; av[q] = jobs.ad.v[idx]; ap[q] = jobs.ad.p[idx]; at[q] = jobs.ad.t[idx];
+            }
+        }
+    }
+    // generated-operand inputs
+    float4 gw4[GMAX];
+    float gwn = 0.f;
+    if (type == DG_DGRAD_Q) {
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g)
+            if (g < ng) gw4[g] = *reinterpret_cast<const float4 *>(jb.gw + 8 * (g0 + g) + 4 * h);
+    } else if (jb.bgen) {
+        gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g)
+            if (g < ng) gw4[g] = *reinterpret_cast<const float4 *>(jb.gdq + 8 * (g0 + g) + 4 * h);
+    }
+    // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
+    float dqr = jb.gconst;
+    if (type == DG_DGRAD_Q) {
+        if (need_q) {
+            float rew = 0.f, done = 0.f, lp0 = 0.f, lp1 = 0.f;
+            if (w == 0) { rew = jobs.rew[m0 + l31]; done = jobs.done[m0 + l31]; lp0 = jobs.logp0[m0 + l31]; lp1 = jobs.logp1[m0 + l31]; }
+            const float b3_1 = jobs.b3q1[0], b3_2 = jobs.b3q2[0], b3_1t = jobs.b3q1t[0], b3_2t = jobs.b3q2t[0];
+            s_q[tid >> 5][tid & 31] = qsum;
+            __syncthreads();
+            if (w == 0) {
+                const int row = m0 + l31;
+                const float q1v = s_q[0][l31] + b3_1, q2v = s_q[1][l31] + b3_2, q1pi = s_q[2][l31] + b3_1;
+                const float q1t = s_q[3][l31] + b3_1t, q2t = s_q[4][l31] + b3_2t;
+                const float minq = fminf(q1t, q2t);                             // actor_learner.py:59
+                const float vb = minq - jobs.alpha * lp1;                       // :62
+                const float backup = rew + (jobs.gamma * (1.0f - done)) * vb;   // :63
+                const float e1 = backup - q1v, e2 = backup - q2v;
+                const float inv_b = 1.0f / (float)Bn;
+                const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b;
+                if (lane < 32) {
+                    s_g[l31] = jb.slot == 0 ? dq1 : dq2;
+                    if (first_n && jb.slot == 0) {
+                        jobs.q1o[row] = q1v; jobs.q2o[row] = q2v;
+                        jobs.loss_part[row * 3 + 0] = jobs.alpha * lp0 - q1pi;  // :66
+                        jobs.loss_part[row * 3 + 1] = e1 * e1;                  // :67
+                        jobs.loss_part[row * 3 + 2] = e2 * e2;                  // :68
+                        jobs.dq[row] = dq1;
+                        jobs.dq[Bn + row] = dq2;
+                    }
+                }
+            }
+            __syncthreads();
+            dqr = s_g[l31];
+        }
+    }
+    // ---- K loop
+    floatx16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        if (g < ng) {
+            float4 av4 = a4[g], bv4 = b4[g];
+            if (type == DG_DGRAD_Q) {
+                const float4 w3 = gw4[g];
+                av4 = make_float4(av4.x > 0.f ? dqr * w3.x : 0.f, av4.y > 0.f ? dqr * w3.y : 0.f, av4.z > 0.f ? dqr * w3.z : 0.f, av4.w > 0.f ? dqr * w3.w : 0.f);
+            } else if (jb.bgen) {
+                const float4 d4 = gw4[g];
+                bv4 = make_float4(bv4.x > 0.f ? d4.x * gwn : 0.f, bv4.y > 0.f ? d4.y * gwn : 0.f, bv4.z > 0.f ? d4.z * gwn : 0.f, bv4.w > 0.f ? d4.w * gwn : 0.f);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av4.x, bv4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av4.y, bv4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av4.z, bv4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av4.w, bv4.w, acc, 0, 0, 0);
+        }
+    }
+    // ---- split-K combine.  D layout: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[q];
+    __syncthreads();
+
+    if (is_dgrad) {
+        // mapping C: thread (col r, row group cg): rows m0 + 4cg .. + 3 of column n0 + r
+        float o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = ((red[0][4 * cg + i][r] + red[1][4 * cg + i][r]) + red[2][4 * cg + i][r]) + red[3][4 * cg + i][r];
+            o4[i] = f4e(mk, i) > 0.f ? s : 0.f;
+        }
+        const bool colok = n0 + r < jb.N;
+        if (jb.C && colok) *reinterpret_cast<float4 *>(jb.C + ((long long)(m0 / 4 + cg) * jb.ldc + n0 + r) * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        if (jb.da_part || (type == DG_DGRAD && jb.part)) {  // block-uniform
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[0][4 * cg + i][r] = colok ? o4[i] : 0.f;
+            __syncthreads();
+            if (jb.da_part) {  // dQ/da partial of this column tile: rows x action dims
+                const int c = tid >> 5;
+                if (c < 4) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wa[c][col], s);
+                    jb.da_part[((long long)nt * Bn + m0 + r) * 4 + c] = s;
+                }
+            } else {
+                for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
+                    const int k = idx >> 5, col = idx & 31;
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 32; ++rr) sacc = fmaf(s_px[rr][k], red[0][rr][col], sacc);
+                    if (n0 + col < jb.N) jb.part[((long long)mt * jb.part_nk + k) * jb.N + n0 + col] = sacc;
+                }
+            }
+        }
+        return;
+    }
+    if (type == DG_WGRAD_J4) {
+        // gradient tile rows = hidden-1 index (the contraction axis of the forward), cols = hidden-2 index
+        float g4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g4[i] = ((red[0][4 * cg + i][r] + red[1][4 * cg + i][r]) + red[2][4 * cg + i][r]) + red[3][4 * cg + i][r];
+        const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
+        const float al = jb.adam_off < jobs.ad.n_pi ? al_pi : al_q;
+        if (j_ok) {
+            *reinterpret_cast<float4 *>(jobs.ad.g + j_idx) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+            if (do_adam) {
+                adam1(g4[0], j_m.x, j_v.x, j_p.x, j_t.x, omb1, omb2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                adam1(g4[1], j_m.y, j_v.y, j_p.y, j_t.y, omb1, omb2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                adam1(g4[2], j_m.z, j_v.z, j_p.z, j_t.z, omb1, omb2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                adam1(g4[3], j_m.w, j_v.w, j_p.w, j_t.w, omb1, omb2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                *reinterpret_cast<float4 *>(jobs.ad.m + j_idx) = j_m; *reinterpret_cast<float4 *>(jobs.ad.v + j_idx) = j_v;
+                *reinterpret_cast<float4 *>(jobs.ad.p + j_idx) = j_p; *reinterpret_cast<float4 *>(jobs.ad.t + j_idx) = j_t;
+            }
+        }
+        if (b_ok) {
+            jobs.ad.g[b_idx] = g4[0];
+            if (do_adam) {
+                adam1(g4[0], bm, bv, bp, bt, omb1, omb2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                jobs.ad.m[b_idx] = bm; jobs.ad.v[b_idx] = bv; jobs.ad.p[b_idx] = bp; jobs.ad.t[b_idx] = bt;
+            }
+        }
+        if (do_adam && jb.shadow) {  // block-uniform: the updated kernel in the dgrad layout [n/4][k][4]
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[0][4 * cg + i][r] = f4e(j_p, i);
+            __syncthreads();
+            // mapping R: thread (row r, col group cg): columns n0 + 4cg .. + 3 of row m0 + r
+            if (m0 + r < jb.bias_row && n0 + 4 * cg < jb.N)
+                *reinterpret_cast<float4 *>(jb.shadow + ((long long)(n0 / 4 + cg) * jb.ld_sh + m0 + r) * 4) =
+                    make_float4(red[0][r][4 * cg], red[0][r][4 * cg + 1], red[0][r][4 * cg + 2], red[0][r][4 * cg + 3]);
+        }
+        return;
+    }
+    // DG_WGRAD_RM: row-major gradient (layer-1 kernels with their bias row, head kernels)
+    {
+        const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = tid + 256 * q;
+            const int row = o >> 5, col = o & 31;
+            const float gv = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+            if (okv[q]) {
+                const long long idx = jb.adam_off + (long long)(m0 + row) * jb.ldc + n0 + col;
+                jobs.ad.g[idx] = gv;
+                if (do_adam) {
+                    const float al = idx < jobs.ad.n_pi ? al_pi : al_q;
+                    adam1(gv, am[q], av[q], ap[q], at[q], omb1, omb2, al, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                    jobs.ad.m[idx] = am[q]; jobs.ad.v[idx] = av[q]; jobs.ad.p[idx] = ap[q]; jobs.ad.t[idx] = at[q];
+                }
+            }
+        }
+    }
+}
+
+static void dg_add(DGJobs &js, DGJob j) {
+    j.tiles_m = (j.M + 31) / 32;
+    j.ntiles = j.type == DG_LOSS ? 1 : j.tiles_m * ((j.N + 31) / 32);
+    j.tile_start = js.total_tiles;
+    js.total_tiles += j.ntiles;
+    for (int i = js.njobs; i < MAX_DG_JOBS; ++i) js.tile_start[i] = 0x7fffffff;
+    js.tile_start[js.njobs] = j.tile_start;
+    js.job[js.njobs++] = j;
+}
+static void launch_dg(const DGJobs &J, hipStream_t s) {
+    const int *ts = J.tile_start;
+    int per_wave = 0;  // deepest 8-group count of a wave over the launch's GEMM jobs
+    for (int i = 0; i < J.njobs; ++i) {
+        const DGJob &j = J.job[i];
+        if (j.type == DG_ROWS_C || j.type == DG_LOSS) continue;
+        const int G = (j.K + 7) / 8, pw = (G + 3) / 4;
+        if (pw > per_wave) per_wave = pw;
+    }
+    if (per_wave <= 10) k_dg<10><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], 0, J);
+    else k_dg<DGMAX><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], 0, J);
+}
+
+// The dgrad image [N/4][ld][4] of a k4-interleaved kernel [K/4][Np][4] (after a set_weights / import / flat Adam step)
+__global__ void __launch_bounds__(256) k_shadow(const float *__restrict__ j4, float *__restrict__ c4, int K, int N, int Np, int ld_sh) {
+    const int k = blockIdx.x * 32 + (threadIdx.x & 31), ng = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (k >= K || 4 * ng >= N) return;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (4 * ng + e < N) ? j4[((long long)(k >> 2) * Np + 4 * ng + e) * 4 + (k & 3)] : 0.f;
+    *reinterpret_cast<float4 *>(c4 + ((long long)ng * ld_sh + k) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
