@@ -1076,7 +1076,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         const long long HP = (long long)DFH * B * DNT;
         const long long H1I = (long long)B * h->Lp1, H2C = (long long)Np2 * B, H2R = (long long)B * h->Lp2;
         // image slots — H1r4: 0 pi(x) 1 q1(x,a) 2 q2(x,a) 3 q1(x,pi);  H2c4: same;  H2r4: 0 pi(x) 1 q1(x,a) 2 q2(x,a)
-        auto steps = [](int D) { return D <= 8 ? 4 : (D <= 10 ? 5 : 6); };
+        auto steps = [](int D) { return D + 1 <= 8 ? 4 : 4 + (D + 1 - 8 + 1) / 2; };  // input columns + the bias column, two per MFMA step
         for (int st = 0; st < 2; ++st) {
             auto head = [&](DFHead &d) {
                 d = DFHead{};
@@ -1369,12 +1369,12 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 launch_dfwd<1>(h->fh_b[st], F, s);
                 break;
             }
-            case 7: launch_dg(h->dg_bq[st], s); break;
+            case 7: launch_dg(h->dg_bq[st], s, 2); break;
             case 8: {
                 DGJobs &J = h->dg_mid;
                 J.ad.on = h->fuse_apply ? 1 : 0;
                 J.ad.opt = h->opt + h->opt_cur;
-                launch_dg(J, s);
+                launch_dg(J, s, 3);
                 break;
             }
             case 9: {
@@ -1383,7 +1383,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 J.ad.opt = h->opt + h->opt_cur;
                 J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image ...
                 J.job[1].shadow = h->c4_pi[h->sh_cur ^ 1];  // ... while the optimizer epilogue of the same launch writes the next one
-                launch_dg(J, s);
+                launch_dg(J, s, 4);
                 if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
                     const AdamArgs &A = h->ad;
                     const float *b = h->slab;

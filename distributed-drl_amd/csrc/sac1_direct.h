@@ -27,6 +27,15 @@
 //   k_dg "pi"  policy dgrad (+ layer-1 wgrad partials), policy wgrads, Q layer-1 wgrads, Adam + polyak
 //   k_adam_l1  the policy layer-1 step (sum of row-tile partials) + optimizer bookkeeping
 
+#ifdef DDRL_STAMPS  // diagnostic builds only (tools/upd_bench.hip): per-workgroup cycle stamps of thread 0
+__device__ unsigned long long *g_st = nullptr;  // [kernel id][1024 workgroups][16]
+#define DST(kid, i) do { if (g_st && threadIdx.x == 0) g_st[((kid) * 1024 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DRT(kid, i) do { if (g_st && threadIdx.x == 0) g_st[((kid) * 1024 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DST(kid, i) do { } while (0)
+#define DRT(kid, i) do { } while (0)
+#endif
+
 constexpr int DFH = 8;    // head slots per evaluation (2 * act_dim <= 8)
 constexpr int DNT = 16;   // n-tile slots of a head-partial row (hidden2 <= 512)
 constexpr int DGMAX = 16; // 8-deep contraction groups per wave (contraction <= 512)
@@ -38,6 +47,20 @@ __device__ __forceinline__ float relu1(float x) {
     return y;
 }
 static inline int rup32(int x) { return (x + 31) & ~31; }
+
+// Kernel-argument records are fetched with scalar loads from the kernarg segment, cold after every kernel boundary: a
+// field first touched deep inside a kernel costs a full miss (~0.3 us) at that point, and the compiler issues such loads
+// one by one where the fields are used.  kline() starts one load per 64-byte line of a record at the top of the kernel;
+// ktouch() (placed behind the first vector loads) waits for them, so that every later field load hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ int kline(const void *rec) {
+    const int *q = reinterpret_cast<const int *>(rec);
+    int acc = q[(BYTES - 4) / 4];
+#pragma unroll
+    for (int o = 0; o < BYTES - 4; o += 64) acc |= q[o / 4];
+    return acc;
+}
+__device__ __forceinline__ void ktouch(int v) { asm volatile("" ::"s"(v)); }
 
 // One row of one policy evaluation, all action dims in one lane.  Same formulae and operation order
 // as policy_head() (core.py:49-87, 104-106); mu / log_std pre-activations arrive as sums of partials.
@@ -113,15 +136,14 @@ struct DFHead {
     int w1o[5];         // per job: [W1 ; b1] offset.  phase 1: [3] = head-partial buffer
     int dw2_pi, dw2_q;  // W2 offset - W1 offset of a policy / Q network
     int x_off, x2_off, a_off;
-    int pack;           // 6 bits per job: [1:0] layer-1 MFMA steps - 4, [2] input is x2, [3] second input from memory, [4] Q network
+    int pack;           // 6 bits per job: [1:0] layer-1 MFMA steps - 4 (input columns + the bias column, in pairs), [2] input is x2, [3] second input from memory, [4] Q network
 };
 
 // One 32-unit block of the K loop: layer 1 (NS MFMA steps) -> relu -> 4 * nrq layer-2 MFMA steps.
 template <int NS>
-__device__ __forceinline__ void dblock(const float (&w1)[6], const float4 (&bia)[4], const float (&xin)[6], const float4 (&bq)[4], int nrq, floatx16 &x1,
-                                       floatx16 &acc) {
+__device__ __forceinline__ void dblock(const float (&w1)[7], const float (&xin)[7], const float4 (&bq)[4], int nrq, floatx16 &x1, floatx16 &acc) {
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) { x1[4 * rq + 0] = bia[rq].x; x1[4 * rq + 1] = bia[rq].y; x1[4 * rq + 2] = bia[rq].z; x1[4 * rq + 3] = bia[rq].w; }
+    for (int r = 0; r < 16; ++r) x1[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[s], xin[s], x1, 0, 0, 0);
 #pragma unroll
@@ -137,59 +159,77 @@ __device__ __forceinline__ void dblock(const float (&w1)[6], const float4 (&bia)
     }
 }
 
-// K loop of one wave: blocks [b0, b0 + nb) of 32 hidden-1 units.  Every load is issued before the first MFMA.
-// h1r4 != nullptr (n-tile-0 workgroups of a differentiated evaluation): X1 also goes to memory as [row/4][unit][4]
-// through a wave-private LDS tile (registers hold row-in-lane / unit-in-register; the image wants 4 rows per float4).
-template <int NS>
-__device__ __forceinline__ void dkloop(const float *__restrict__ W1, const float *__restrict__ W2p, int K, int D, int Np, int b0, int nb, int n0, int lane,
-                                       const float (&xin)[6], floatx16 &acc, float *__restrict__ h1r4, int Lp1, int m0, float *__restrict__ tr) {
+// The operand streams of one wave for its blocks [b0, b0 + nb) of 32 hidden-1 units: W2 groups and [W1 ; b1] columns.
+// The bias row follows the kernel rows in memory, so it is simply input column D of the layer-1 MFMAs (its input is the
+// constant 1; rows beyond it meet a zero input, whatever finite values they hold) — no bias loads: a per-lane broadcast
+// load costs the fetch path as much as a tile load.  Issued first thing in the kernel from preloaded scalars only;
+// loads beyond nb re-read the last block (no branches in front of a load).
+struct DOps {
+    float4 bq[4][4];
+    float w1[4][7];
+};
+__device__ __forceinline__ void dops_load(DOps &o, const float *__restrict__ W1, const float *__restrict__ W2p, int K, int Np, int b0, int nb,
+                                          int n0, int lane) {
     const int l31 = lane & 31, h = lane >> 5;
-    float4 bq[4][4], bia[4][4];
-    float w1[4][6];
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi) {  // loads beyond nb re-read the last block (no branches before the loads)
-        const int u0 = (b0 + (bi < nb ? bi : nb - 1)) * 32;
+    for (int bi = 0; bi < 4; ++bi) {
+        const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
+        for (int rq = 0; rq < 4; ++rq) o.bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
     }
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
-        const int u0 = (b0 + (bi < nb ? bi : nb - 1)) * 32;
+        const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) w1[bi][s] = W1[(long long)d_slot(s, h) * K + u0 + l31];
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) bia[bi][rq] = *reinterpret_cast<const float4 *>(W1 + (long long)D * K + u0 + 8 * rq + 4 * h);
+        for (int s = 0; s < 7; ++s) o.w1[bi][s] = W1[(long long)d_slot(s, h) * K + u0 + l31];
     }
+}
+
+// K loop of one wave over MT row tiles that share the wave's W2 / W1 registers.  h1r4 != nullptr (n-tile-0 workgroups of
+// a differentiated evaluation): X1 also goes to memory as [row/4][unit][4] through a wave-private LDS tile (registers hold
+// row-in-lane / unit-in-register; the image wants 4 rows per float4).
+template <int NS, int MT>
+__device__ __forceinline__ void dkloop(const DOps &o, int K, int b0, int nb, int lane, const float (&xin)[MT][7], floatx16 (&acc)[MT],
+                                       float *__restrict__ h1r4, int Lp1, int m0, float *__restrict__ tr) {
+    const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
         if (bi < nb) {
             const int u0 = (b0 + bi) * 32;
             const int nrq = (K - u0 >= 32) ? 4 : ((K - u0 + 7) >> 3);
-            floatx16 x1;
-            dblock<NS>(w1[bi], bia[bi], xin, bq[bi], nrq, x1, acc);
-            if (h1r4) {  // block-uniform
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = x1[r];
-                wave_lds_sync();
+            for (int tt = 0; tt < MT; ++tt) {
+                floatx16 x1;
+                dblock<NS>(o.w1[bi], xin[tt], o.bq[bi], nrq, x1, acc[tt]);
+                if (h1r4) {  // block-uniform
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int rg = h + 2 * p;
-                    const float4 v = *reinterpret_cast<const float4 *>(tr + l31 * 36 + 4 * rg);
-                    if (u0 + l31 < K) *reinterpret_cast<float4 *>(h1r4 + ((long long)(m0 / 4 + rg) * Lp1 + u0 + l31) * 4) = v;
+                    for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = x1[r];
+                    wave_lds_sync();
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int rg = h + 2 * p;
+                        const float4 v = *reinterpret_cast<const float4 *>(tr + l31 * 36 + 4 * rg);
+                        if (u0 + l31 < K) *reinterpret_cast<float4 *>(h1r4 + ((long long)((m0 + 32 * tt) / 4 + rg) * Lp1 + u0 + l31) * 4) = v;
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
             }
         }
     }
 }
 
-template <int PH>
+// MT = 2 (phase 0: 400 tiles of 32 rows would put two workgroups on most CUs, each fetching its own copy of a W2 tile —
+// the fetch phase, not the MFMAs, is what a stage waits for): one workgroup = 64 rows x 32 columns, the wave's W2 / W1
+// registers serve both row tiles.
+template <int PH, int MT>
 __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int w1o0, int w1o1, int w1o2, int w1o3, int w1o4, int dw2_pi,
                                               int dw2_q, int x_off, int x2_off, int a_off, int pack, DFArgs a) {
+    static_assert(PH == 0 || MT == 1, "phase 1 computes one policy row per lane");
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ __attribute__((aligned(16))) float tr[4][32 * 36];
     __shared__ float s_wh[DFH][32];
     const int tpj = tpj_tm & 0xffff, tiles_m = tpj_tm >> 16;
+    DRT(PH, 14); DST(PH, 0);
     if (PH == 1 && (int)blockIdx.x == 3 * tpj) {  // only launched when a.do_sample
         ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
         return;
@@ -203,7 +243,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     const int ji = (t >= tpj) + (t >= 2 * tpj) + (t >= 3 * tpj) + (t >= 4 * tpj);
     t -= ji * tpj;
     const int nt = (t * (65536 / tiles_m + 1)) >> 16;  // t / tiles_m (t < 8192, tiles_m <= 2047)
-    const int m0 = (t - nt * tiles_m) * 32, n0 = nt * 32;
+    const int m0 = (t - nt * tiles_m) * (32 * MT), n0 = nt * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -220,49 +260,60 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     const int nb = bs + (w >= 4 - rem ? 1 : 0);
     const int b0 = w * bs + (w > 4 - rem ? w - (4 - rem) : 0);
 
-    // ---- phase 1: what its longest chain starts with — the policy-head partials of this tile's rows (-> action -> layer-1 input).
-    // Lanes of half 0 sum the mu heads, half 1 the log_std heads (n-tile order; unused slots are 0).
-    float hs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // ---- every load whose address needs only the preloaded scalars, in the order of need.
+    // Phase 1: what its longest chain starts with — the policy-head partials of this tile's rows (-> action -> layer-1 input);
+    // lanes of half 0 fetch the mu heads, half 1 the log_std heads (head index clamped: no branch in front of a load).
+    const int D = d0 + d1;
     const bool two = PH == 1 && ji == 1 && first_n;  // block-uniform: pi_main @ x2 rides here (log-prob only)
+    float4 hv[2][4][DNT / 4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < DNT / 4; ++q) hv[e][c][q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PH == 1) {
-        const int actq = d1;
         const long long HPq = (long long)DFH * B * DNT;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (e == 0 || two) {
+            if (e == 0 || two) {  // block-uniform
                 const float *hp = base + w1o3 + (e == 0 ? (ji == 0 ? 0 : 2) : 1) * HPq;
+                const float4 *p0 = reinterpret_cast<const float4 *>(hp + ((long long)(h * d1) * B + m0 + l31) * DNT);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (c < actq) {
-                        const float4 *p4 = reinterpret_cast<const float4 *>(hp + ((long long)(h * actq + c) * B + m0 + l31) * DNT);
-                        float4 v[DNT / 4];
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int q = 0; q < DNT / 4; ++q) v[q] = p4[q];
-                        float s = 0.f;
+                    for (int q = 0; q < DNT / 4; ++q) hv[e][c][q] = p0[(long long)(c < d1 ? c : 0) * B * (DNT / 4) + q];
+                if (d1 > 2) {  // block-uniform
 #pragma unroll
-                        for (int q = 0; q < DNT / 4; ++q) { s += v[q].x; s += v[q].y; s += v[q].z; s += v[q].w; }
-                        hs[e][c] = s;
-                    }
+                    for (int c = 2; c < 4; ++c)
+#pragma unroll
+                        for (int q = 0; q < DNT / 4; ++q) hv[e][c][q] = p0[(long long)(c < d1 ? c : 2) * B * (DNT / 4) + q];
                 }
             }
         }
     }
+    DOps ops;
+    dops_load(ops, W1, W2p, K, Np, b0, nb, n0, lane);
     // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
-    const int D = d0 + d1;
-    float xin[6];
+    float xin[MT][7];
     {
         const float *in0 = base + ((jp & 4) ? x2_off : x_off), *in1 = base + a_off;
-        const long long row = m0 + l31;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const int d = d_slot(s, h);
-            const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
-            const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
-            const float v = *p;
-            xin[s] = (f0 || f1) ? v : 0.f;
+        for (int tt = 0; tt < MT; ++tt) {
+            const long long row = m0 + 32 * tt + l31;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const int d = d_slot(s, h);
+                const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
+                const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
+                const float v = *p;
+                xin[tt][s] = (f0 || f1) ? v : (d == D ? 1.0f : 0.f);  // column D: the bias row
+            }
         }
     }
+    DST(PH, 1);
     const DFJob &jb = a.job[ji];
+    ktouch(kline<sizeof(DFJob)>(&jb) | kline<offsetof(DFArgs, do_sample)>(&a));
     // ---- epilogue operands
     const float4 b4 = *reinterpret_cast<const float4 *>(jb.b2 + n0 + 4 * (tid >> 5));
     float whv = 0.f;
@@ -274,6 +325,16 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         whv = ok ? p[(long long)col * jb.hstride + cc] : 0.f;
     }
     if (PH == 1) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
+        float hs[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // n-tile order; unused slots are 0
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < DNT / 4; ++q) { s += hv[e][c][q].x; s += hv[e][c][q].y; s += hv[e][c][q].z; s += hv[e][c][q].w; }
+                hs[e][c] = s;
+            }
         float mu[4], ls[4], ev[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -285,9 +346,9 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         }
         const PolRow o = policy_row(mu, ls, ev, d1, a.scale);
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
+        for (int s = 0; s < 7; ++s) {
             const int d = d_slot(s, h), c = d - d0;
-            if (d >= d0 && d < D) xin[s] = c == 0 ? o.act[0] : (c == 1 ? o.act[1] : (c == 2 ? o.act[2] : o.act[3]));
+            if (d >= d0 && d < D) xin[0][s] = c == 0 ? o.act[0] : (c == 1 ? o.act[1] : (c == 2 ? o.act[2] : o.act[3]));
         }
         if (first_n && w == 0 && lane < 32) {
             const int row = m0 + l31;
@@ -318,9 +379,26 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
             if (lane < 32) a.logp1[m0 + l31] = o1.logp;
         }
     }
+    // ---- K loop
+    DST(PH, 2);
+    floatx16 acc[MT];
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+    float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
+    if (nb > 0) {
+        if (ns == 4) dkloop<4, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+        else if (ns == 5) dkloop<5, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+        else if (ns == 6) dkloop<6, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+        else dkloop<7, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+    }
+
+    DST(PH, 3);
+    // ---- side outputs of the n-tile-0 workgroups (off the critical path: nothing in this launch reads them)
     s_wh[tid >> 5][tid & 31] = whv;
     if (first_n && (jb.aug || jb.xr4)) {  // augmented input rows of the layer-1 wgrads (their ones column is set once at create)
-        for (int idx = tid; idx < 32 * D; idx += 256) {
+        for (int idx = tid; idx < 32 * MT * D; idx += 256) {
             const int r = idx / D, d = idx - r * D;
             const long long row = m0 + r;
             const float v = d < d0 ? (base + ((jp & 4) ? x2_off : x_off))[row * d0 + d] : (base + a_off)[row * d1 + (d - d0)];
@@ -332,7 +410,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         // eps_x, eps_x2, eps_t of this tile's rows; element index as in one flat [3][B*act] fill
         const unsigned long long nbase = a.opt->noise_ctr;
         const int per_row = 3 * act;
-        for (int e = tid; e < 32 * per_row; e += 256) {
+        for (int e = tid; e < 32 * MT * per_row; e += 256) {
             const int rr = e / per_row, q = e - rr * per_row;
             const int wch = q / act, c = q - wch * act;
             const int k = (m0 + rr) * act + c;
@@ -340,55 +418,65 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         }
     }
 
-    // ---- K loop
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
-    if (nb > 0) {
-        if (ns == 4) dkloop<4>(W1, W2p, K, D, Np, b0, nb, n0, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-        else if (ns == 5) dkloop<5>(W1, W2p, K, D, Np, b0, nb, n0, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-        else dkloop<6>(W1, W2p, K, D, Np, b0, nb, n0, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-    }
-
     // ---- split-K combine, bias + relu, H2 in the layouts its consumers read, head partials
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
-    __syncthreads();
     const int r = tid & 31, cg = tid >> 5;
-    float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = 4 * cg + e;
-        const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
-        v[e] = fmaxf(s + (e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w))), 0.f);
-    }
-    if (jb.H2c4) *reinterpret_cast<float4 *>(jb.H2c4 + ((long long)(n0 / 4 + cg) * B + m0 + r) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    __syncthreads();
+    for (int tt = 0; tt < MT; ++tt) {
+        const int mb = m0 + 32 * tt;
+        if (tt > 0) __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[0][r][4 * cg + e] = v[e];
-    __syncthreads();
-    if (jb.H2r4) {  // (column hidden2 of the image is the ones column: never written here)
-        const int c = tid & 31, rg = tid >> 5;
-        if (n0 + c < a.h2)
-            *reinterpret_cast<float4 *>(jb.H2r4 + ((long long)(m0 / 4 + rg) * a.Lp2 + n0 + c) * 4) =
-                make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
-    }
-    {
-        const int c = tid >> 5;
-        if (c < jb.nh) {
-            float s = 0.f;
+        for (int q = 0; q < 16; ++q) red[w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[tt][q];
+        __syncthreads();
+        if (tt == 0) DST(PH, 4);
+        float v[4];
 #pragma unroll
-            for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
-            jb.hp[((long long)c * B + m0 + r) * DNT + nt] = s;
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * cg + e;
+            const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+            v[e] = fmaxf(s + (e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w))), 0.f);
+        }
+        if (jb.H2c4) *reinterpret_cast<float4 *>(jb.H2c4 + ((long long)(n0 / 4 + cg) * B + mb + r) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[0][r][4 * cg + e] = v[e];
+        __syncthreads();
+        if (jb.H2r4) {  // (column hidden2 of the image is the ones column: never written here)
+            const int c = tid & 31, rg = tid >> 5;
+            if (n0 + c < a.h2)
+                *reinterpret_cast<float4 *>(jb.H2r4 + ((long long)(mb / 4 + rg) * a.Lp2 + n0 + c) * 4) =
+                    make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
+        }
+        {
+            const int c = tid >> 5;
+            if (c < jb.nh) {
+                float s = 0.f;
+#pragma unroll
+                for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
+                jb.hp[((long long)c * B + mb + r) * DNT + nt] = s;
+            }
         }
     }
+    DST(PH, 5); DRT(PH, 15);
+}
+
+// Row tiles per workgroup of a phase-0 launch.  Measured at the config-2 shape (400 tiles of 32 rows): MT = 2 halves the
+// W2 bytes a CU fetches, but leaves ONE wave per SIMD whose layer-1 -> relu -> layer-2 chain of dependent MFMAs has nobody
+// to fill its issue bubbles: 15.9 us per launch against 12.0 us with two 32-row workgroups per CU.  DDRL_FWD_MT=2 selects it.
+static int dfwd_mt(int B, int tiles_n) {
+    static const int want = getenv("DDRL_FWD_MT") ? atoi(getenv("DDRL_FWD_MT")) : 1;
+    return (want == 2 && B % 64 == 0 && 5 * (B / 32) * tiles_n > 256) ? 2 : 1;
 }
 
 template <int PH>
 static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s) {
-    k_dfwd<PH><<<F.njobs * d.tpj + ((PH == 1 && F.do_sample) ? 1 : 0), 256, 0, s>>>(d.base, d.tpj | (d.tiles_m << 16), d.K | (d.Np << 16), d.B | (d.d0 << 16) | (F.act << 24), d.w1o[0], d.w1o[1],
-                                                                                    d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+    const int mt = PH == 0 ? dfwd_mt(d.B, F.tiles_n) : 1;
+    const int tiles_m = d.B / (32 * mt), tpj = tiles_m * F.tiles_n;
+    const int grid = F.njobs * tpj + ((PH == 1 && F.do_sample) ? 1 : 0);
+    const int a1 = tpj | (tiles_m << 16), a2 = d.K | (d.Np << 16), a3 = d.B | (d.d0 << 16) | (F.act << 24);
+    if (PH == 0 && mt == 2)
+        k_dfwd<0, 2><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+    else
+        k_dfwd<PH, 1><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
 }
 
 // ==========================================================================================
@@ -456,13 +544,15 @@ struct DGJobs {
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 template <int GMAX>
-__global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, int ts3, int ts4, int ts5, int ts6, int ts7, int hp_off_unused, DGJobs jobs) {
+__global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, int ts3, int ts4, int ts5, int ts6, int ts7, int kid, DGJobs jobs) {
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ float s_q[8][32];
     __shared__ float s_g[32];
     __shared__ float s_px[32][13];
     __shared__ float s_wa[4][32];
+    __shared__ __attribute__((aligned(16))) float s_gw[512];
     int t, ji;
+    DRT(kid, 14); DST(kid, 0);
     {
         const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -470,6 +560,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     static_assert(MAX_DG_JOBS == 8, "k_dg takes tile_start[1..7] as scalar arguments");
     ji = (t >= ts1) + (t >= ts2) + (t >= ts3) + (t >= ts4) + (t >= ts5) + (t >= ts6) + (t >= ts7);
     const DGJob &jb = jobs.job[ji];
+    const int kl = kline<sizeof(DGJob)>(&jb) | kline<offsetof(DGJobs, job)>(&jobs);
     t -= jb.tile_start;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,55 +663,68 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             *reinterpret_cast<float4 *>(jb.dz_r4 + ((long long)(m0 / 4 + rg) * jb.ld_r4 + n0 + c) * 4) =
                 make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
         }
+        DST(kid, 5); DRT(kid, 15);
         return;
     }
 
     // ---- GEMM tiles.  This wave's 8-deep contraction groups: the waves at the END get the extra ones
-    const int G = (jb.K + 7) >> 3, gs = G >> 2, grem = G & 3;
+    const int Kc = jb.K, lda = jb.lda, ldb = jb.ldb;
+    const float *Aop = jb.A, *Bop = jb.B;
+    const int G = (Kc + 7) >> 3, gs = G >> 2, grem = G & 3;
     const int ng = gs + (w >= 4 - grem ? 1 : 0);
     const int g0 = w * gs + (w > 4 - grem ? w - (4 - grem) : 0);
     const bool first_n = nt == 0;
 
-    // DGRAD_Q: the Q-head partials of this tile's rows first (-> dq -> the generated A operand); c = 0..4 <-> evaluations 3..7
-    float qsum = 0.f;
+    // both operand streams of this wave: unconditional loads, groups beyond ng re-read the last one (a branch or a
+    // select in front of a load makes the compiler wait for the previous load before issuing the next)
+    float4 a4[GMAX], b4[GMAX];
+    {
+        const float *Ap = Aop + (long long)(m0 + l31) * 4, *Bp = Bop + (long long)(n0 + l31) * 4;
+        const int glast = ng > 0 ? g0 + ng - 1 : (G > 0 ? G - 1 : 0);
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            const int gg = g0 + g < glast ? g0 + g : glast;
+            const long long kg = 2 * gg + h;
+            a4[g] = *reinterpret_cast<const float4 *>(Ap + kg * lda * 4);
+            b4[g] = *reinterpret_cast<const float4 *>(Bp + kg * ldb * 4);
+        }
+    }
+    ktouch(kl);
+    // DGRAD_Q: the Q-head partials of this tile's rows (-> dq -> the generated A operand); c = 0..4 <-> evaluations 3..7.
     const bool need_q = type == DG_DGRAD_Q && jb.slot != 2;
-    if (need_q) {
+    float4 qv[DNT / 4];
+    {
         const int c = tid >> 5;
         const long long HP = (long long)DFH * Bn * DNT;
         const float4 *p4 = reinterpret_cast<const float4 *>(jobs.hp + (3 + (c < 5 ? c : 0)) * HP + (long long)(m0 + r) * DNT);
-        float4 v[DNT / 4];
 #pragma unroll
-        for (int q = 0; q < DNT / 4; ++q) v[q] = p4[q];
+        for (int q = 0; q < DNT / 4; ++q) qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (need_q) {  // block-uniform
 #pragma unroll
-        for (int q = 0; q < DNT / 4; ++q) { qsum += v[q].x; qsum += v[q].y; qsum += v[q].z; qsum += v[q].w; }
-    }
-    // both operand streams of this wave
-    float4 a4[GMAX], b4[GMAX];
-    {
-        const float *Ap = jb.A + (long long)(m0 + l31) * 4, *Bp = jb.B + (long long)(n0 + l31) * 4;
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            if (g < ng) {  // wave-uniform
-                const long long kg = 2 * (g0 + g) + h;
-                a4[g] = *reinterpret_cast<const float4 *>(Ap + kg * jb.lda * 4);
-                b4[g] = *reinterpret_cast<const float4 *>(Bp + kg * jb.ldb * 4);
-            }
+            for (int q = 0; q < DNT / 4; ++q) qv[q] = p4[q];
         }
     }
+    DST(kid, 1);
     // ---- epilogue operands, fetched behind the operand streams
     const bool is_dgrad = type == DG_DGRAD_Q || type == DG_DGRAD;
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     if (is_dgrad) mk = *reinterpret_cast<const float4 *>(jb.mask + ((long long)(m0 / 4 + cg) * jb.ldmask + n0 + r) * 4);  // mapping C: (col r, row group cg)
-    if (is_dgrad && jb.da_part) {
+    float wa_v = 0.f, px_v[2] = {0.f, 0.f};  // staged into LDS after the K loop (an LDS store here would wait for every load above)
+    const bool has_da = is_dgrad && jb.da_part, has_part = type == DG_DGRAD && jb.part;  // block-uniform
+    if (has_da) {
         const int c = tid >> 5, col = n0 + (tid & 31);
-        if (c < 4) s_wa[c][tid & 31] = (c < jb.nact && col < jb.N) ? jb.wa[(long long)c * jb.N + col] : 0.f;
+        const bool ok = c < jb.nact && col < jb.N;
+        const float v = jb.wa[ok ? (long long)c * jb.N + col : 0];
+        wa_v = ok ? v : 0.f;
     }
-    if (type == DG_DGRAD && jb.part) {
-        for (int idx = tid; idx < 32 * 12; idx += 256) {
+    if (has_part) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u;  // 32 * 12 = 384 slots
             const int rr = idx / 12, k = idx - rr * 12;
-            const bool ok = k < jb.part_nk;
-            const float v = jb.part_x[(long long)(m0 + rr) * jb.part_ldx + (ok ? k : 0)];
-            s_px[rr][k] = ok ? v : 0.f;
+            const bool ok = idx < 32 * 12 && k < jb.part_nk;
+            const float v = jb.part_x[ok ? (long long)(m0 + rr) * jb.part_ldx + k : 0];
+            px_v[u] = ok ? v : 0.f;
         }
     }
     const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || type == DG_WGRAD_RM) && jb.adam_off >= 0;
@@ -662,26 +766,30 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             }
         }
     }
-    // generated-operand inputs
-    float4 gw4[GMAX];
-    float gwn = 0.f;
-    if (type == DG_DGRAD_Q) {
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g)
-            if (g < ng) gw4[g] = *reinterpret_cast<const float4 *>(jb.gw + 8 * (g0 + g) + 4 * h);
-    } else if (jb.bgen) {
-        gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
-#pragma unroll
-        for (int g = 0; g < GMAX; ++g)
-            if (g < ng) gw4[g] = *reinterpret_cast<const float4 *>(jb.gdq + 8 * (g0 + g) + 4 * h);
+    // generated-operand inputs: W3 along the contraction (DGRAD_Q) or dq along it (generated wgrad operand).  The same 16
+    // bytes for all 32 lanes of a half-wave: a per-lane load of them would cost the fetch path as much as a tile load,
+    // so the vector is staged once per workgroup in LDS (two coalesced loads per thread) and read from there in the K loop.
+    const bool has_gen = type == DG_DGRAD_Q || jb.bgen;  // block-uniform
+    float gv0 = 0.f, gv1 = 0.f, gwn = 0.f;
+    if (has_gen) {
+        const float *gp = type == DG_DGRAD_Q ? jb.gw : jb.gdq;
+        const int glen = 8 * G;  // (W3 / dq are followed by readable memory up to the next multiple of 8)
+        gv0 = gp[tid < glen ? tid : 0];
+        gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
+        if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
     }
     // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
     float dqr = jb.gconst;
+    if (has_gen) { s_gw[tid] = gv0; s_gw[tid + 256] = gv1; }
+    if (has_gen && !need_q) __syncthreads();
     if (type == DG_DGRAD_Q) {
         if (need_q) {
             float rew = 0.f, done = 0.f, lp0 = 0.f, lp1 = 0.f;
             if (w == 0) { rew = jobs.rew[m0 + l31]; done = jobs.done[m0 + l31]; lp0 = jobs.logp0[m0 + l31]; lp1 = jobs.logp1[m0 + l31]; }
             const float b3_1 = jobs.b3q1[0], b3_2 = jobs.b3q2[0], b3_1t = jobs.b3q1t[0], b3_2t = jobs.b3q2t[0];
+            float qsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < DNT / 4; ++q) { qsum += qv[q].x; qsum += qv[q].y; qsum += qv[q].z; qsum += qv[q].w; }
             s_q[tid >> 5][tid & 31] = qsum;
             __syncthreads();
             if (w == 0) {
@@ -711,6 +819,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         }
     }
     // ---- K loop
+    DST(kid, 2);
     floatx16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -719,10 +828,10 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         if (g < ng) {
             float4 av4 = a4[g], bv4 = b4[g];
             if (type == DG_DGRAD_Q) {
-                const float4 w3 = gw4[g];
+                const float4 w3 = *reinterpret_cast<const float4 *>(&s_gw[8 * (g0 + g) + 4 * h]);
                 av4 = make_float4(av4.x > 0.f ? dqr * w3.x : 0.f, av4.y > 0.f ? dqr * w3.y : 0.f, av4.z > 0.f ? dqr * w3.z : 0.f, av4.w > 0.f ? dqr * w3.w : 0.f);
             } else if (jb.bgen) {
-                const float4 d4 = gw4[g];
+                const float4 d4 = *reinterpret_cast<const float4 *>(&s_gw[8 * (g0 + g) + 4 * h]);
                 bv4 = make_float4(bv4.x > 0.f ? d4.x * gwn : 0.f, bv4.y > 0.f ? d4.y * gwn : 0.f, bv4.z > 0.f ? d4.z * gwn : 0.f, bv4.w > 0.f ? d4.w * gwn : 0.f);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av4.x, bv4.x, acc, 0, 0, 0);
@@ -732,9 +841,19 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         }
     }
     // ---- split-K combine.  D layout: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
+    DST(kid, 3);
+    if (has_da && tid < 128) s_wa[tid >> 5][tid & 31] = wa_v;
+    if (has_part) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < 32 * 12) s_px[idx / 12][idx % 12] = px_v[u];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[q];
     __syncthreads();
+    DST(kid, 4);
 
     if (is_dgrad) {
         // mapping C: thread (col r, row group cg): rows m0 + 4cg .. + 3 of column n0 + r
@@ -746,12 +865,12 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         }
         const bool colok = n0 + r < jb.N;
         if (jb.C && colok) *reinterpret_cast<float4 *>(jb.C + ((long long)(m0 / 4 + cg) * jb.ldc + n0 + r) * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-        if (jb.da_part || (type == DG_DGRAD && jb.part)) {  // block-uniform
+        if (has_da || has_part) {  // block-uniform
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[0][4 * cg + i][r] = colok ? o4[i] : 0.f;
             __syncthreads();
-            if (jb.da_part) {  // dQ/da partial of this column tile: rows x action dims
+            if (has_da) {  // dQ/da partial of this column tile: rows x action dims
                 const int c = tid >> 5;
                 if (c < 4) {
                     float s = 0.f;
@@ -769,6 +888,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                 }
             }
         }
+        DST(kid, 5); DRT(kid, 15);
         return;
     }
     if (type == DG_WGRAD_J4) {
@@ -806,6 +926,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                 *reinterpret_cast<float4 *>(jb.shadow + ((long long)(n0 / 4 + cg) * jb.ld_sh + m0 + r) * 4) =
                     make_float4(red[0][r][4 * cg], red[0][r][4 * cg + 1], red[0][r][4 * cg + 2], red[0][r][4 * cg + 3]);
         }
+        DST(kid, 5); DRT(kid, 15);
         return;
     }
     // DG_WGRAD_RM: row-major gradient (layer-1 kernels with their bias row, head kernels)
@@ -827,6 +948,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             }
         }
     }
+    DST(kid, 5); DRT(kid, 15);
 }
 
 static void dg_add(DGJobs &js, DGJob j) {
@@ -838,7 +960,7 @@ static void dg_add(DGJobs &js, DGJob j) {
     js.tile_start[js.njobs] = j.tile_start;
     js.job[js.njobs++] = j;
 }
-static void launch_dg(const DGJobs &J, hipStream_t s) {
+static void launch_dg(const DGJobs &J, hipStream_t s, int kid = 0) {
     const int *ts = J.tile_start;
     int per_wave = 0;  // deepest 8-group count of a wave over the launch's GEMM jobs
     for (int i = 0; i < J.njobs; ++i) {
@@ -847,8 +969,8 @@ static void launch_dg(const DGJobs &J, hipStream_t s) {
         const int G = (j.K + 7) / 8, pw = (G + 3) / 4;
         if (pw > per_wave) per_wave = pw;
     }
-    if (per_wave <= 10) k_dg<10><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], 0, J);
-    else k_dg<DGMAX><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], 0, J);
+    if (per_wave <= 10) k_dg<10><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], kid, J);
+    else k_dg<DGMAX><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], kid, J);
 }
 
 // The dgrad image [N/4][ld][4] of a k4-interleaved kernel [K/4][Np][4] (after a set_weights / import / flat Adam step)
