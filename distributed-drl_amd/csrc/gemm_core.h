@@ -63,7 +63,8 @@ struct AdamCtx {
     int on;
     float *p, *t, *m, *v; // flat buffers in the internal layout, indexed like the gradient buffer
     float *g;
-    const OptState *opt;  // optimizer state read by this step (advanced into its other copy by the k_adam_polyak launch that follows)
+    const OptState *opt;  // optimizer state read by this step ...
+    OptState *opt_next;   // ... and the copy it is advanced into (by ONE workgroup of the last launch of the step; nobody reads it there)
     long long n_pi;       // elements below n_pi belong to the policy optimizer
     float lr, b1, b2, eps, pk, pk1;
     unsigned int noise_adv;

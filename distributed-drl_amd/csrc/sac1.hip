@@ -541,58 +541,6 @@ __global__ void __launch_bounds__(64) k_rows_b_v(RowsBV a) {
 
 #include "sac1_direct.h"
 
-// The fused step's tail: Adam + polyak for the one parameter range whose gradient is a sum of row-tile partials
-// (the policy's layer 1) and the optimizer bookkeeping.  A few workgroups, pure latency: everything the first
-// burst of loads needs travels as preloaded scalars (base pointer + offsets into the slab).
-struct AdamL1Args {
-    float lr, b1, b2, eps, pk, pk1;
-    unsigned int noise_adv;
-    long long n_pi4;
-    OptState *opt_next;
-};
-__global__ void __launch_bounds__(256) k_adam_l1(const float *base, int p_off, int t_off, int m_off, int v_off, int g_off, int part_off, int i0,
-                                                 int cnt4, int nparts, int stride4, int opt_off, AdamL1Args a) {
-    const int j = blockIdx.x * 256 + threadIdx.x;          // float4 element inside the range
-    const int jc = j < cnt4 ? j : 0;
-    const long long i = (long long)i0 + jc;
-    float *bw = const_cast<float *>(base);
-    float4 *P = reinterpret_cast<float4 *>(bw + p_off), *T = reinterpret_cast<float4 *>(bw + t_off);
-    float4 *M = reinterpret_cast<float4 *>(bw + m_off), *V = reinterpret_cast<float4 *>(bw + v_off);
-    const OptState *opt = reinterpret_cast<const OptState *>(base + opt_off);
-    float4 m = M[i], v = V[i], p = P[i], t = T[i];
-    const float b1p_pi = opt->b1p_pi, b2p_pi = opt->b2p_pi, b1p_q = opt->b1p_q, b2p_q = opt->b2p_q;
-    const float4 *PP = reinterpret_cast<const float4 *>(base + part_off) + jc;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q0 = 0; q0 < nparts; q0 += 8) {  // 8 partials per round trip, summed in tile order (as k_adam_polyak)
-        float4 u[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = PP[(long long)(q0 + q < nparts ? q0 + q : 0) * stride4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (q0 + q < nparts) { g.x += u[q].x; g.y += u[q].y; g.z += u[q].z; g.w += u[q].w; }
-    }
-    const float one = 1.0f;
-    const float al_pi = a.lr * sqrtf(one - b2p_pi) / (one - b1p_pi);
-    const float al_q = a.lr * sqrtf(one - b2p_q) / (one - b1p_q);
-    const float omb1 = one - a.b1, omb2 = one - a.b2;
-    if (j < cnt4) {
-        const float al = i < a.n_pi4 ? al_pi : al_q;
-        adam1(g.x, m.x, v.x, p.x, t.x, omb1, omb2, al, a.eps, a.pk, a.pk1);
-        adam1(g.y, m.y, v.y, p.y, t.y, omb1, omb2, al, a.eps, a.pk, a.pk1);
-        adam1(g.z, m.z, v.z, p.z, t.z, omb1, omb2, al, a.eps, a.pk, a.pk1);
-        adam1(g.w, m.w, v.w, p.w, t.w, omb1, omb2, al, a.eps, a.pk, a.pk1);
-        reinterpret_cast<float4 *>(bw + g_off)[i] = g;  // keep the gradient buffer complete (export)
-        M[i] = m; V[i] = v; P[i] = p; T[i] = t;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        OptState n = *opt;
-        n.b1p_pi = b1p_pi * a.b1; n.b2p_pi = b2p_pi * a.b2; n.b1p_q = b1p_q * a.b1; n.b2p_q = b2p_q * a.b2;
-        n.t_pi += 1; n.t_q += 1;
-        n.noise_ctr += a.noise_adv;
-        *a.opt_next = n;
-    }
-}
-
 struct StageArgs {
     const float *src[8];
     float *dst[8];
@@ -784,6 +732,7 @@ struct ddrl_sac1 {
     int Lp1, Lp2;
     float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq;
     float *c4_pi[2], *c4_q[2];
+    int *part_cnt;       // arrival counters of the policy layer-1 partials (one per column tile)
     int sh_cur;          // which copy of the policy dgrad image is current (the optimizer epilogue writes the other one)
     bool fuse_apply;     // this launch_grads also applies the optimizer (Adam in the wgrad epilogues)
     // sampler riding in k_fwd<1> (ddrl_sac1_step_and_sample)
@@ -966,6 +915,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     const int nt2 = (h2 + 31) / 32;
     ALLOC(hp, (size_t)NEVAL * DFH * B * DNT);
 #undef ALLOC
+    const size_t cnt_off = reserve(64);
     const size_t opt_off = reserve((2 * sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((L.segs.size() * sizeof(Seg) + 3) / 4);
     (void)reserve(2048);  // readable guard behind the last buffer (unclamped tile loads, see OpPre)
@@ -978,6 +928,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     }
     for (auto &it : items) *it.p = h->slab + it.off;
     h->opt = reinterpret_cast<OptState *>(h->slab + opt_off);
+    h->part_cnt = reinterpret_cast<int *>(h->slab + cnt_off);
     h->segs_d = reinterpret_cast<Seg *>(h->slab + segs_off);
     DDRL_HIP_CHECK(hipMemcpy(h->segs_d, L.segs.data(), L.segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
     rc = reset_opt(h, nullptr);
@@ -1155,7 +1106,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             dg_add(Q, dq_job(1, 2, 1, h->dZ1r4 + H1I));
         }
         float *G = h->grad;
-        const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, L.n_pi_int,
+        const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, nullptr, L.n_pi_int,
                           (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                           (float)cfg->polyak, (float)(1.0 - cfg->polyak), 0u};
         auto wgrad_j4 = [&](const float *A, const float *Bm, long long w_off, long long b_off, float *shadow) {
@@ -1198,6 +1149,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->dzpi_c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
             d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = nullptr; d.ldc = h->Lp1; d.adam_off = -1;
             d.part_x = h->xp; d.part = h->part; d.part_nk = o + 1; d.part_ldx = h->ldxp;
+            d.part_cnt = h->part_cnt; d.part_adam_off = L.pi_W1;
             dg_add(P, d);
             dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));
             dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4, 32, a, L.pi_Wmu));
@@ -1383,17 +1335,10 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 J.ad.opt = h->opt + h->opt_cur;
                 J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image ...
                 J.job[1].shadow = h->c4_pi[h->sh_cur ^ 1];  // ... while the optimizer epilogue of the same launch writes the next one
+                J.ad.opt_next = h->opt + (h->opt_cur ^ 1);  // the policy's layer-1 step + the optimizer bookkeeping ride in this launch
+                J.ad.noise_adv = h->noise_pending;          // (last-arriving row tile per column tile, see k_dg)
                 launch_dg(J, s, 4);
-                if (J.ad.on) {  // the policy's layer-1 parameters (gradient = sum of the row tiles' partials) + the optimizer bookkeeping
-                    const AdamArgs &A = h->ad;
-                    const float *b = h->slab;
-                    const AdamL1Args L1{A.lr, A.b1, A.b2, A.eps, A.pk, A.pk1, h->noise_pending, A.n_pi >> 2, h->opt + (h->opt_cur ^ 1)};
-                    k_adam_l1<<<(unsigned)((A.part_n4 + 255) / 256), 256, 0, s>>>(
-                        b, (int)(A.p - b), (int)(A.t - b), (int)(A.m - b), (int)(A.v - b), (int)(A.g - b), (int)(A.part - b), (int)A.part_off4,
-                        (int)A.part_n4, A.nparts, (int)A.part_stride4, (int)(reinterpret_cast<const float *>(h->opt + h->opt_cur) - b), L1);
-                    h->opt_cur ^= 1;
-                    h->sh_cur ^= 1;
-                }
+                if (J.ad.on) { h->opt_cur ^= 1; h->sh_cur ^= 1; }
                 break;
             }
             case 11: {

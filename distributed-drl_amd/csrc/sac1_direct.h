@@ -24,8 +24,8 @@
 //   k_dfwd<1>  evaluations 5-7, action from the policy-head partials (+ sampler workgroup)
 //   k_dg "bq"  the three Q dgrads, dZ2 generated from H2 on the fly; dQ/da partials
 //   k_dg "mid" policy-head backward as 32x32 tiles + the Q layer-2 / head wgrads with Adam + polyak
-//   k_dg "pi"  policy dgrad (+ layer-1 wgrad partials), policy wgrads, Q layer-1 wgrads, Adam + polyak
-//   k_adam_l1  the policy layer-1 step (sum of row-tile partials) + optimizer bookkeeping
+//   k_dg "pi"  policy dgrad (+ layer-1 wgrad partials; the last row tile of a column tile to arrive sums them and steps the
+//              policy's layer 1), policy wgrads, Q layer-1 wgrads, Adam + polyak, optimizer bookkeeping
 
 #ifdef DDRL_STAMPS  // diagnostic builds only (tools/upd_bench.hip): per-workgroup cycle stamps of thread 0
 __device__ unsigned long long *g_st = nullptr;  // [kernel id][1024 workgroups][16]
@@ -168,6 +168,7 @@ struct DOps {
     float4 bq[4][4];
     float w1[4][7];
 };
+// Issue order = order of need (a wave's loads return in order): the layer-1 columns of a block, then its W2 groups.
 __device__ __forceinline__ void dops_load(DOps &o, const float *__restrict__ W1, const float *__restrict__ W2p, int K, int Np, int b0, int nb,
                                           int n0, int lane) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -175,13 +176,9 @@ __device__ __forceinline__ void dops_load(DOps &o, const float *__restrict__ W1,
     for (int bi = 0; bi < 4; ++bi) {
         const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) o.bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
-    }
-#pragma unroll
-    for (int bi = 0; bi < 4; ++bi) {
-        const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
-#pragma unroll
         for (int s = 0; s < 7; ++s) o.w1[bi][s] = W1[(long long)d_slot(s, h) * K + u0 + l31];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) o.bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
     }
 }
 
@@ -292,8 +289,6 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
             }
         }
     }
-    DOps ops;
-    dops_load(ops, W1, W2p, K, Np, b0, nb, n0, lane);
     // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
     float xin[MT][7];
     {
@@ -311,6 +306,8 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
             }
         }
     }
+    DOps ops;
+    dops_load(ops, W1, W2p, K, Np, b0, nb, n0, lane);
     DST(PH, 1);
     const DFJob &jb = a.job[ji];
     ktouch(kline<sizeof(DFJob)>(&jb) | kline<offsetof(DFArgs, do_sample)>(&a));
@@ -507,6 +504,8 @@ struct DGJob {
     const float *part_x;     // DGRAD: fused layer-1 wgrad partials (see gemm_core.h)
     float *part;
     int part_nk, part_ldx;
+    int *part_cnt;           // ... arrival counters, one per column tile (zero between launches)
+    long long part_adam_off; // ... the layer-1 kernel [part_nk][N] (bias row last) in the flat buffers
     // wgrad epilogue (optimizer): offsets into the flat parameter-shaped buffers
     long long adam_off;      // J4: the W2 image;  RM: element (0, 0)
     long long bias_off;      // J4: b2
@@ -551,6 +550,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     __shared__ float s_px[32][13];
     __shared__ float s_wa[4][32];
     __shared__ __attribute__((aligned(16))) float s_gw[512];
+    __shared__ int s_last;
     int t, ji;
     DRT(kid, 14); DST(kid, 0);
     {
@@ -675,6 +675,32 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     const int g0 = w * gs + (w > 4 - grem ? w - (4 - grem) : 0);
     const bool first_n = nt == 0;
 
+    // DGRAD_Q: the Q-head partials of this tile's rows (-> dq -> the generated A operand); c = 0..4 <-> evaluations 3..7.
+    const bool need_q = type == DG_DGRAD_Q && jb.slot != 2;
+    float4 qv[DNT / 4];
+    {
+        const int c = tid >> 5;
+        const long long HP = (long long)DFH * Bn * DNT;
+        const float4 *p4 = reinterpret_cast<const float4 *>(jobs.hp + (3 + (c < 5 ? c : 0)) * HP + (long long)(m0 + r) * DNT);
+#pragma unroll
+        for (int q = 0; q < DNT / 4; ++q) qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (need_q) {  // block-uniform
+#pragma unroll
+            for (int q = 0; q < DNT / 4; ++q) qv[q] = p4[q];
+        }
+    }
+    // generated-operand inputs: W3 along the contraction (DGRAD_Q) or dq along it (generated wgrad operand).  The same 16
+    // bytes for all 32 lanes of a half-wave: a per-lane load of them would cost the fetch path as much as a tile load,
+    // so the vector is staged once per workgroup in LDS (two coalesced loads per thread) and read from there in the K loop.
+    const bool has_gen = type == DG_DGRAD_Q || jb.bgen;  // block-uniform
+    float gv0 = 0.f, gv1 = 0.f, gwn = 0.f;
+    if (has_gen) {
+        const float *gp = type == DG_DGRAD_Q ? jb.gw : jb.gdq;
+        const int glen = 8 * G;  // (W3 / dq are followed by readable memory up to the next multiple of 8)
+        gv0 = gp[tid < glen ? tid : 0];
+        gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
+        if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
+    }
     // both operand streams of this wave: unconditional loads, groups beyond ng re-read the last one (a branch or a
     // select in front of a load makes the compiler wait for the previous load before issuing the next)
     float4 a4[GMAX], b4[GMAX];
@@ -690,20 +716,6 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         }
     }
     ktouch(kl);
-    // DGRAD_Q: the Q-head partials of this tile's rows (-> dq -> the generated A operand); c = 0..4 <-> evaluations 3..7.
-    const bool need_q = type == DG_DGRAD_Q && jb.slot != 2;
-    float4 qv[DNT / 4];
-    {
-        const int c = tid >> 5;
-        const long long HP = (long long)DFH * Bn * DNT;
-        const float4 *p4 = reinterpret_cast<const float4 *>(jobs.hp + (3 + (c < 5 ? c : 0)) * HP + (long long)(m0 + r) * DNT);
-#pragma unroll
-        for (int q = 0; q < DNT / 4; ++q) qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (need_q) {  // block-uniform
-#pragma unroll
-            for (int q = 0; q < DNT / 4; ++q) qv[q] = p4[q];
-        }
-    }
     DST(kid, 1);
     // ---- epilogue operands, fetched behind the operand streams
     const bool is_dgrad = type == DG_DGRAD_Q || type == DG_DGRAD;
@@ -765,18 +777,6 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                 am[q] = jobs.ad.m[idx]; av[q] = jobs.ad.v[idx]; ap[q] = jobs.ad.p[idx]; at[q] = jobs.ad.t[idx];
             }
         }
-    }
-    // generated-operand inputs: W3 along the contraction (DGRAD_Q) or dq along it (generated wgrad operand).  The same 16
-    // bytes for all 32 lanes of a half-wave: a per-lane load of them would cost the fetch path as much as a tile load,
-    // so the vector is staged once per workgroup in LDS (two coalesced loads per thread) and read from there in the K loop.
-    const bool has_gen = type == DG_DGRAD_Q || jb.bgen;  // block-uniform
-    float gv0 = 0.f, gv1 = 0.f, gwn = 0.f;
-    if (has_gen) {
-        const float *gp = type == DG_DGRAD_Q ? jb.gw : jb.gdq;
-        const int glen = 8 * G;  // (W3 / dq are followed by readable memory up to the next multiple of 8)
-        gv0 = gp[tid < glen ? tid : 0];
-        gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
-        if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
     }
     // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
     float dqr = jb.gconst;
@@ -879,12 +879,63 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                     jb.da_part[((long long)nt * Bn + m0 + r) * 4 + c] = s;
                 }
             } else {
+                // Layer-1 wgrad of the same network from this tile's rows, as a per-row-tile partial.  With the optimizer
+                // in this launch the LAST of the row tiles of a column tile to arrive sums the partials in tile order and
+                // steps those parameters (no spinning: the arrival order only decides who does the work, not the result).
+                // Hand-off per MI355X guide "Valid forms": every partial leaves as a write-through (sc1) store, each storing
+                // wave drains, the workgroup's barrier, ONE agent-scope add; the workgroup whose add returned last reads
+                // the partials with sc1 loads behind a barrier that its adding wave joined.
+                const bool la = jobs.ad.on && jb.part_cnt != nullptr;  // block-uniform
                 for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
                     const int k = idx >> 5, col = idx & 31;
                     float sacc = 0.f;
 #pragma unroll
                     for (int rr = 0; rr < 32; ++rr) sacc = fmaf(s_px[rr][k], red[0][rr][col], sacc);
-                    if (n0 + col < jb.N) jb.part[((long long)mt * jb.part_nk + k) * jb.N + n0 + col] = sacc;
+                    if (n0 + col < jb.N) {
+                        float *dst = jb.part + ((long long)mt * jb.part_nk + k) * jb.N + n0 + col;
+                        if (la) __hip_atomic_store(dst, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else *dst = sacc;
+                    }
+                }
+                if (la) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) s_last = __hip_atomic_fetch_add(jb.part_cnt + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    if (s_last == tiles_m - 1) {
+                        const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
+                        for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
+                            const int k = idx >> 5, col = idx & 31;
+                            if (n0 + col < jb.N) {
+                                const long long e = (long long)k * jb.N + n0 + col, off = jb.part_adam_off + e;
+                                float am_ = jobs.ad.m[off], av_ = jobs.ad.v[off], ap_ = jobs.ad.p[off], at_ = jobs.ad.t[off];
+                                float g = 0.f;
+                                for (int q0 = 0; q0 < tiles_m; q0 += 8) {  // 8 partials per round trip, summed in tile order (as k_adam_polyak)
+                                    float u[8];
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q)
+                                        u[q] = __hip_atomic_load(jb.part + (long long)(q0 + q < tiles_m ? q0 + q : 0) * jb.part_nk * jb.N + e, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q)
+                                        if (q0 + q < tiles_m) g += u[q];
+                                }
+                                adam1(g, am_, av_, ap_, at_, omb1, omb2, al_pi, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                                jobs.ad.g[off] = g;
+                                jobs.ad.m[off] = am_; jobs.ad.v[off] = av_; jobs.ad.p[off] = ap_; jobs.ad.t[off] = at_;
+                            }
+                        }
+                        if (tid == 0) {
+                            jb.part_cnt[nt] = 0;  // for the next launch
+                            if (nt == 0) {        // optimizer bookkeeping of the whole step (running beta powers, step counts, noise counter)
+                                OptState nx = *jobs.ad.opt;
+                                nx.b1p_pi *= jobs.ad.b1; nx.b2p_pi *= jobs.ad.b2; nx.b1p_q *= jobs.ad.b1; nx.b2p_q *= jobs.ad.b2;
+                                nx.t_pi += 1; nx.t_q += 1;
+                                nx.noise_ctr += jobs.ad.noise_adv;
+                                *jobs.ad.opt_next = nx;
+                            }
+                        }
+                    }
                 }
             }
         }
