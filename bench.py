@@ -2,36 +2,41 @@
 """bench.py — env-steps/s + learner updates/s of the SAC1 actor-learner hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or plainly as
+     `python bench.py --gpus N`: without WORLD_SIZE in the environment this process only spawns the N ranks — before any
+     GPU call — relays rank 0's JSON line and exits with the worst return code)
 
-Workload (BASELINE.json configs[1]): SAC1 on the LunarLanderContinuous-v2 stand-in, 4096
-vectorised envs + 1M-transition device replay per GPU, batch 256, hidden (400, 300).
-One "step" = one pass of the hot path over one batch of environments:
+N = 1 — BASELINE.json configs[1]: SAC1 on the LunarLanderContinuous-v2 stand-in, 4096 vectorised envs + 1M-transition
+device replay, batch 256, hidden (400, 300).  One "step" = one pass of the hot path over one batch of environments:
     rollout : batched policy forward (4096 x 8->400->300->(2,2)) -> env.step kernel -> store 4096
-    learner : num_envs / a_l_ratio updates, each = MT19937 sample of 256 + gather -> SAC1 update
-              (the reference's actor/learner gate keeps steps / sample_times <= a_l_ratio,
-              algos/sac1/sac1.py:205; default a_l_ratio = 2, sac1.py:25)
+    learner : num_envs / a_l_ratio updates, each = MT19937 sample of 256 + gather -> SAC1 update, 50 per hipGraph
+              (the reference's actor/learner gate keeps steps / sample_times <= a_l_ratio, algos/sac1/sac1.py:205;
+              default a_l_ratio = 2, sac1.py:25)
     ps      : push of the flat parameter vector every 300 updates (sac1.py:149), pull by the actor
-Synthetic data: the ring is pre-filled to capacity with seeded synthetic transitions (SURVEY
-§8(d)); weights are glorot/zeros random init.  Inputs are resident in HBM when timing starts.
+N > 1 — the north star's rank-role partitioning (distributed-drl_amd/partition.py):
+    N = 2 (configs[2])  learner on rank 0, envs + a replay shard on BOTH ranks; per update the learner picks a shard on
+                        its seeded stream, a remote owner gathers and sends the packed 20 KB batch point-to-point,
+                        parameters travel as one RCCL broadcast every 300 updates
+    N = 8 (configs[3])  ranks 0-1 learners (gradient all-reduce per update), ranks 2-7 rollout ranks x 8192 envs + shard
+    other N             N // 4 learners (at least one), the rest rollout ranks
+  A step = one vector env step on every rollout rank + the same 2048 updates on every learner rank ("weak": per-rank
+  work fixed; the learner ranks bound the step, env-steps scale with the rollout ranks).
+Synthetic data: rings pre-filled to capacity with seeded synthetic transitions; glorot / zeros weights.
+Inputs are resident in HBM when timing starts.
 
-N > 1 (weak scaling, per-GPU work fixed): one process per GPU, each with its own envs, its own
-replay shard (local store, local sampling — the per-node buffers of algos/dqn/train.py:392-411)
-and its own learner (`num_learners` independent learners, example/dsac.py:233); the only exchange
-is ps.push/pull = ONE RCCL broadcast of the flat parameter vector per push (source rotates:
-deterministic last-writer-wins).  `--dp-learners` instead all-reduces the gradient every update
-(BASELINE config 4 semantics).
-
-Prints ONE JSON line on rank 0.  `value` = whole-job env-steps/s; `updates_per_s` rides along.
-`roofline` prices the four MFMA stage launches of an update (k_fwd<0>, k_fwd<1>, k_bwdq, k_gemm: layer 1
-on the matrix cores + the fc GEMMs + the fused head / loss / optimizer epilogues = all of an update's
-network FLOPs) from HIP-event stage timings taken right after the timed region; `cpu_baseline` times the oracle
-(CPU restatement of the reference path) on this box's host cores for a bounded sample.
+Prints ONE JSON line on rank 0.  `value` = whole-job env-steps/s over EXACTLY --steps steps; `updates_per_s` rides along.
+`roofline` prices the launches of one update (fp32 MFMA): algorithmic FLOPs of an update / launches per update, over the
+average launch time measured with HIP events on the launch stream around a learner-only block of graph replays (so
+launch gaps count).  `stages` adds the other rows of SURVEY §8(d): rollout-only, store, sample, the config-5 gather.
+`cpu_baseline` times the oracle (CPU restatement of the reference path) on this box's host cores for a bounded sample,
+BEFORE the GPU legs; the GPU legs run last and are repeated for ~10 s (`repeat_blocks`) so that a sampler sees them.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,17 +44,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-
-
-def gemm_flops_per_update(B, obs, act, h1, h2):
-    fwd = 8 * 2 * B * h1 * h2      # 8 network evaluations, layer 2
-    dgrad = 4 * 2 * B * h2 * h1    # q1(x,a), q2(x,a), q1(x,pi), pi
-    wgrad = 3 * 2 * h1 * B * h2    # q1, q2, pi
-    return fwd + dgrad + wgrad
+PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec (6 290 measured streaming)
 
 
 def update_flops(B, obs, act, h1, h2):
@@ -61,7 +57,139 @@ def update_flops(B, obs, act, h1, h2):
     return 2 * B * (fwd + bwd)
 
 
+def policy_flops(obs, act, h1, h2):
+    """124 400 MAC per policy-phase env step -> 248 800 FLOP."""
+    return 2 * (obs * h1 + h1 * h2 + 2 * h2 * act)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--num-envs", type=int, default=None, help="envs per rollout rank (default 4096; 8192 on dedicated rollout ranks)")
+    ap.add_argument("--capacity", type=int, default=10 ** 6, help="replay transitions in all (sharded over the rollout ranks)")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--a-l-ratio", type=float, default=2.0)
+    ap.add_argument("--updates-per-graph", type=int, default=50)  # divides push_freq = 300: no eager remainder between pushes
+    ap.add_argument("--num-learners", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the rollout / store / sample / config-5 stage measurements")
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds per CPU-baseline leg")
+    ap.add_argument("--gpu-seconds", type=float, default=10.0, help="keep repeating the timed block until the GPU legs lasted this long")
+    ap.add_argument("--stage-samples", type=int, default=200)
+    ap.add_argument("--cfg5-capacity", type=int, default=32768, help="transitions of the config-5 gather ring (225 804 B each)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks (nothing in this process has touched the GPU)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import torch  # device_count() does not initialise the GPU on this image
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ndev = torch.cuda.device_count()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if ndev < n:
+            env.setdefault("DDRL_DIST_BACKEND", "gloo")  # several ranks per GPU: functional run only (RCCL refuses duplicate devices)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores (kind "port")
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(a_l_ratio, budget_s):
+    """Single process like Ray local mode (configs[0]); ring pre-filled to 10^6.  Leg 1 pins torch to one
+    thread like the reference's session config (algos/sac1/actor_learner.py:110-111); leg 2 lets the learner use every core."""
+    import numpy as np
+    import torch
+    from oracle import sac1_oracle as so
+    from oracle.env_oracle import LanderOracle
+    from oracle.replay_oracle import ReplayBufferOracle
+    threads = torch.get_num_threads()
+    cores = os.cpu_count() or 1
+    cfg = so.Config()
+    params = so.init_params(cfg, 0)
+    rb = ReplayBufferOracle(8, 2, 10 ** 6, seed=0)
+    rs = np.random.RandomState(1234)
+    n0 = 10 ** 6
+    rb.obs1_buf[:], rb.obs2_buf[:] = rs.randn(n0, 8), rs.randn(n0, 8)
+    rb.acts_buf[:], rb.rews_buf[:] = rs.uniform(-1, 1, (n0, 2)), rs.randn(n0)
+    rb.done_buf[:] = rs.rand(n0) < 0.01
+    rb.ptr, rb.size, rb.steps = 0, n0, n0
+    rn = np.random.RandomState(1)
+
+    def learner_leg(nthreads):
+        torch.set_num_threads(nthreads)
+        learner = so.Sac1Oracle(cfg, params, torch.float32)
+        t0, n_upd = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s:
+            batch = rb.sample_batch(256)
+            eps = [rn.randn(256, 2).astype(np.float32) for _ in range(3)]
+            learner.step(batch, *eps)
+            n_upd += 1
+        return (time.perf_counter() - t0) / n_upd, n_upd
+
+    try:
+        torch.set_num_threads(1)
+        env = LanderOracle(1, seed=0)
+        o = env.obs()
+        # rollout leg: batch-of-1 policy forward + env.step + store, per transition
+        t0, n_env = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s:
+            for _ in range(50):
+                a = so.actor_act(cfg, params, o, rn.randn(1, 2).astype(np.float32))
+                o2, r, d, o_next, _ = env.step(a)
+                rb.store(o[0], a[0], r[0], o2[0], d[0])
+                o = o_next
+                n_env += 1
+        t_env = (time.perf_counter() - t0) / n_env
+        t_upd, n_upd = learner_leg(1)
+        # "all cores": torch's intra-op pool on matrices this small degrades badly when oversubscribed (256 threads: one update
+        # in 20 s), so the leg keeps the best of a short sweep up to every core and says which thread count that was
+        budget_all, budget_s = budget_s, budget_s / 3.0
+        t_upd_all, n_upd_all, nt_all = None, 0, 1
+        for nt in sorted({min(cores, 8), min(cores, 32), cores}):
+            tu, nu = learner_leg(nt)
+            if t_upd_all is None or tu < t_upd_all:
+                t_upd_all, n_upd_all, nt_all = tu, nu, nt
+        budget_s = budget_all
+    finally:
+        torch.set_num_threads(threads)
+
+    def combine(tu):
+        return 1.0 / (t_env + tu / a_l_ratio)
+
+    one = {"value": combine(t_upd), "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "updates_per_s": combine(t_upd) / a_l_ratio,
+           "rollout_only_env_steps_per_s": 1.0 / t_env, "learner_only_updates_per_s": 1.0 / t_upd,
+           "host_cores_available": cores,
+           "sample": "%d env steps (batch-of-1 policy forward + env.step + store) and %d updates (sample_batch(256) from a full 10^6 "
+                     "ring + SAC1 update), ~%.0f s each, 1 process, torch threads=1; combined at a_l_ratio=%g like the GPU leg"
+                     % (n_env, n_upd, budget_s, a_l_ratio)}
+    allc = {"value": combine(t_upd_all), "unit": "env-steps/s", "cores": nt_all, "kind": "port",
+            "updates_per_s": combine(t_upd_all) / a_l_ratio, "learner_only_updates_per_s": 1.0 / t_upd_all,
+            "host_cores_available": cores,
+            "sample": "same rollout leg (a Python loop: one core) + %d updates with torch threads=%d (best of a sweep over 8 / 32 / %d "
+                      "threads, ~%.0f s each)" % (n_upd_all, nt_all, cores, budget_s / 3.0)}
+    return one, allc
+
+
+# ------------------------------------------------------------------------------------------------
 def fill_replay(rb, capacity, seed):
+    import numpy as np
+    import torch
     rs = np.random.RandomState(seed)
     chunk = 1 << 17
     for s in range(0, capacity, chunk):
@@ -73,185 +201,193 @@ def fill_replay(rb, capacity, seed):
         rb.store_batch(*(torch.from_numpy(x).cuda() for x in (o, a, r, o2, d)))
 
 
-def cpu_baseline(a_l_ratio, budget_s=10.0):
-    """The oracle (CPU restatement of the reference path, kind "port") on the host cores, single
-    process like Ray local mode, torch pinned to 1 thread like the reference's session config
-    (algos/sac1/actor_learner.py:110-111)."""
-    from oracle import sac1_oracle as so
-    from oracle.env_oracle import LanderOracle
-    from oracle.replay_oracle import ReplayBufferOracle
-    threads = torch.get_num_threads()
-    torch.set_num_threads(1)
-    try:
-        cfg = so.Config()
-        params = so.init_params(cfg, 0)
-        rb = ReplayBufferOracle(8, 2, 10 ** 6, seed=0)
-        rs = np.random.RandomState(1234)
-        n0 = 20000
-        rb.obs1_buf[:n0], rb.obs2_buf[:n0] = rs.randn(n0, 8), rs.randn(n0, 8)
-        rb.acts_buf[:n0], rb.rews_buf[:n0] = rs.uniform(-1, 1, (n0, 2)), rs.randn(n0)
-        rb.ptr = rb.size = rb.steps = n0
-        env = LanderOracle(1, seed=0)
-        o = env.obs()
-        rn = np.random.RandomState(1)
-        # rollout leg: batch-of-1 policy forward + env.step + store, per transition
-        t0, n_env = time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget_s:
-            for _ in range(50):
-                a = so.actor_act(cfg, params, o, rn.randn(1, 2).astype(np.float32))
-                o2, r, d, o_next, _ = env.step(a)
-                rb.store(o[0], a[0], r[0], o2[0], d[0])
-                o = o_next
-                n_env += 1
-        t_env = (time.perf_counter() - t0) / n_env
-        # learner leg: sample_batch(256) + one SAC1 update
-        learner = so.Sac1Oracle(cfg, params, torch.float32)
-        t0, n_upd = time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget_s:
-            batch = rb.sample_batch(256)
-            eps = [rn.randn(256, 2).astype(np.float32) for _ in range(3)]
-            learner.step(batch, *eps)
-            n_upd += 1
-        t_upd = (time.perf_counter() - t0) / n_upd
-    finally:
-        torch.set_num_threads(threads)
-    env_rate = 1.0 / (t_env + t_upd / a_l_ratio)
-    return {"value": env_rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "updates_per_s": env_rate / a_l_ratio,
-            "rollout_only_env_steps_per_s": 1.0 / t_env, "learner_only_updates_per_s": 1.0 / t_upd,
-            "host_cores_available": os.cpu_count(),
-            "sample": "%d env steps (batch-of-1 policy forward + env.step + store) and %d updates "
-                      "(sample_batch(256) + SAC1 update), ~%.0f s each, 1 process, torch threads=1; "
-                      "combined at a_l_ratio=%g like the GPU leg" % (n_env, n_upd, budget_s, a_l_ratio)}
+def timed(fn, reps, warm=3):
+    """Mean seconds per call of fn(), HIP events on the current stream."""
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def stage_measurements(args, opt, rb, roll, d):
+    """The other rows of SURVEY §8(d), each against its own roof (algorithmic bytes / FLOPs per unit of work)."""
+    import torch
+    out = {}
+    n_env = int(opt.num_envs)
+    t = timed(roll.step, 200)
+    pf = policy_flops(opt.obs_dim, opt.act_dim, opt.hidden_sizes[0], opt.hidden_sizes[1])
+    out["rollout_only"] = {"env_steps_per_s": n_env / t, "us_per_vector_step": t * 1e6, "num_envs": n_env,
+                           "flop_per_env_step": pf, "achieved_TFLOPs": n_env * pf / t / 1e12,
+                           "frac_of_f32_mfma_peak": n_env * pf / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                           "what": "policy forward + env.step + store of %d envs per launch sequence (no learner)" % n_env}
+    o, o2 = torch.randn(n_env, 8, device="cuda"), torch.randn(n_env, 8, device="cuda")
+    a, r, dn = torch.rand(n_env, 2, device="cuda"), torch.randn(n_env, device="cuda"), torch.zeros(n_env, device="cuda")
+    t = timed(lambda: rb.store_batch(o, a, r, o2, dn), 200)
+    out["store"] = {"n": n_env, "us": t * 1e6, "bytes_per_transition": 160, "GBps": n_env * 160 / t / 1e9,
+                    "frac_of_hbm_peak": n_env * 160 / t / 1e9 / PEAK_HBM_GBPS, "transitions_per_s": n_env / t}
+    B = int(opt.batch_size)
+    t = timed(lambda: rb.sample_batch_device(B), 400)
+    out["sample"] = {"batch": B, "us": t * 1e6, "bytes_per_batch": B * 164, "GBps": B * 164 / t / 1e9,
+                     "frac_of_hbm_peak": B * 164 / t / 1e9 / PEAK_HBM_GBPS,
+                     "note": "stand-alone launch (latency-bound); inside the learner loop the sampler rides in a forward launch"}
+    if args.cfg5_capacity > 0:
+        try:
+            obs_dim, B5, cap = 84 * 84 * 4, 512, int(args.cfg5_capacity)
+
+            class O5:
+                pass
+            O5.obs_dim, O5.buffer_size, O5.batch_size, O5.save_dir = obs_dim, cap, B5, "."
+            rb5 = d.ReplayBufferDQN(O5, 0, seed=0)
+            g = torch.Generator(device="cuda").manual_seed(0)
+            z = torch.zeros(2048, device="cuda")
+            for s in range(0, cap, 2048):
+                n = min(2048, cap - s)
+                x = torch.randint(0, 256, (n, obs_dim), device="cuda", generator=g).float()
+                rb5.store_batch(x, z[:n], z[:n], x, z[:n])
+            T5 = 4 * (2 * obs_dim + 1 + 2)
+            t = timed(lambda: rb5.sample_batch_device(B5), 64)
+            out["config5_gather"] = {"batch": B5, "bytes_per_transition": T5, "ring_GB": cap * T5 / 1e9, "us": t * 1e6,
+                                     "bytes_per_batch": B5 * (2 * T5 + 4), "GBps": B5 * (2 * T5 + 4) / t / 1e9,
+                                     "frac_of_hbm_peak": B5 * (2 * T5 + 4) / t / 1e9 / PEAK_HBM_GBPS,
+                                     "what": "sample_batch(512) of 84x84x4 float32 transitions (MT19937 indices + five gathers), "
+                                             "ring well beyond the 256 MiB Infinity Cache"}
+            del rb5
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa  (an out-of-memory box must not lose the headline line)
+            out["config5_gather"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--num-envs", type=int, default=4096)
-    ap.add_argument("--capacity", type=int, default=10 ** 6)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--a-l-ratio", type=float, default=2.0)
-    ap.add_argument("--updates-per-graph", type=int, default=50)  # divides push_freq = 300: no eager remainder between pushes (32: -1.2 %)
-    ap.add_argument("--dp-learners", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=10.0)
-    ap.add_argument("--stage-samples", type=int, default=200)
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
+    import numpy as np
+    import torch
     import distributed_drl_amd as d
-    from distributed_drl_amd import _lib, comm
-    from distributed_drl_amd.agent import HyperParameters
+    from distributed_drl_amd import _lib, comm, partition
+    from distributed_drl_amd.agent import HyperParameters, Learner
     from distributed_drl_amd.workers import RolloutDevice, TrainDevice
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_one = cpu_all = None
+    if world_env == 1 and not args.no_cpu_baseline:
+        cpu_one, cpu_all = cpu_baseline(args.a_l_ratio, args.cpu_budget)   # before the GPU is touched: the GPU legs run last
+
     rank, world, local = comm.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local % ndev)
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
+    roles = partition.Roles(world, rank, args.num_learners)
+    dedicated = world > 1 and not (set(roles.learners) & set(roles.rollouts))
+    num_envs = args.num_envs if args.num_envs is not None else (8192 if dedicated else 4096)
 
     opt = HyperParameters(num_workers=1, a_l_ratio=args.a_l_ratio)
-    opt.num_envs, opt.batch_size = args.num_envs, args.batch
+    opt.num_envs, opt.batch_size = num_envs, args.batch
     opt.start_steps = -1          # policy phase from the first step (the expensive branch)
     opt.max_ep_len = 1000
     opt.seed = 0
-    updates_per_step = max(1, int(round(args.num_envs / args.a_l_ratio)))
+    updates_per_step = max(1, int(round(4096 / args.a_l_ratio)))   # per learner rank, the config-2 figure at every N
+    shard_cap = args.capacity // len(roles.shard_owner)
+    cfgd = dict(B=opt.batch_size, obs=opt.obs_dim, act=opt.act_dim, h1=opt.hidden_sizes[0], h2=opt.hidden_sizes[1])
 
-    rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, args.capacity, seed=rank)
-    fill_replay(rb, args.capacity, 1234 + rank)
-    bcast = None
-    push_no = [0]
+    run = trainer = roll = rb = None
+    if world == 1:
+        rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, args.capacity, seed=0)
+        fill_replay(rb, args.capacity, 1234)
+        trainer = TrainDevice(None, rb, opt, learner_index=0, updates_per_graph=args.updates_per_graph)
+        keys, values = trainer.agent.get_weights()
+        ps = d.ParameterServer(keys, values)
+        trainer.ps = ps
+        roll = RolloutDevice(ps, rb, opt, worker_index=0)
 
-    def on_push(flat):
-        if bcast is not None:
-            # last-writer-wins between the independent learners, in a fixed rotating order
-            bcast.src = push_no[0] % world
-            bcast.sync(flat)
-            push_no[0] += 1
-
-    trainer = TrainDevice(None, rb, opt, learner_index=rank, updates_per_graph=args.updates_per_graph, on_push=on_push)
-    keys, values = trainer.agent.get_weights()
-    ps = d.ParameterServer(keys, values)
-    trainer.ps = ps
-    if world > 1:
-        bcast = comm.ParamBroadcast(trainer.agent.n_params, dev, src=0)
-    roll = RolloutDevice(ps, rb, opt, worker_index=rank)
-    if bcast is not None:
-        n_pi = roll.actor.n_params
-        orig_pull = roll.pull
-
-        def pull_bcast():
-            if bcast.version != getattr(roll, "_bv", -1):
-                roll._bv = bcast.version
-                roll.actor.set_weights_flat(bcast.buf[:n_pi])
-                return True
-            return orig_pull()
-        roll.pull = pull_bcast
-
-    dp_flat = None
-
-    def one_step():
-        roll.step()
-        if args.dp_learners and world > 1:
-            for _ in range(updates_per_step):   # synchronous data-parallel learners (config 4)
-                batch = rb.sample_batch_device(opt.batch_size)
-                g = trainer.agent.compute_gradients(batch)
-                comm.allreduce_mean_(g)
-                trainer.agent.apply_gradients(g)
-        else:
+        def one_step():
+            roll.step()
             trainer.run(updates_per_step)
+    else:
+        def make_replay():
+            r = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, shard_cap, seed=1000 + rank)
+            fill_replay(r, shard_cap, 1234 + rank)
+            return r
+        run = partition.PartitionedRun(opt, roles, make_replay, lambda r_: RolloutDevice(None, r_, opt, worker_index=rank),
+                                       lambda: Learner(opt, job="learner", index=rank), seed=opt.seed)
+
+        def one_step():
+            run.step(updates_per_step)
+
+    def block():
+        torch.cuda.synchronize()
+        comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+        comm.barrier()
+        return comm.allreduce_max(time.perf_counter() - t0, device=dev)
 
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize()
-    comm.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = comm.allreduce_max(time.perf_counter() - t0, device=dev)
+    t_gpu0 = time.perf_counter()
+    dt = block()                                   # THE timed region: exactly --steps steps
+    blocks = [dt]
+    while True:   # every rank takes part in the decision (one collective per round)
+        more = time.perf_counter() - t_gpu0 < args.gpu_seconds and len(blocks) < 50
+        if comm.allreduce_max(1.0 if more else 0.0, device=dev) < 0.5:
+            break
+        blocks.append(block())
 
-    env_steps = args.steps * args.num_envs * world
-    updates = args.steps * updates_per_step * world
+    env_steps = args.steps * num_envs * len(roles.rollouts)
+    updates = args.steps * updates_per_step * len(roles.learners)
     if rank != 0:
         return
 
-    # ---- roofline of the dominant kernel (k_gemm), HIP events on the launch stream -------------
-    cfgd = dict(B=opt.batch_size, obs=opt.obs_dim, act=opt.act_dim, h1=opt.hidden_sizes[0], h2=opt.hidden_sizes[1])
+    # ---- roofline of the update's launches: HIP events on the launch stream around learner-only graph replays -------
     lib = _lib.load()
-    bufs = (ctypes.c_void_p * 8)()
-    _lib.check(lib.ddrl_sac1_input_buffers(trainer.agent._h, 0, bufs))
-    stage = np.zeros(_lib.SAC1_STAGES, np.float64)
-    ms = ctypes.c_float()
-    for st in range(1, 11):   # idempotent stages, `stage_samples` back-to-back launches between two HIP events
-        _lib.check(lib.ddrl_sac1_stage_time(trainer.agent._h, st, args.stage_samples, ctypes.byref(ms), _lib.stream_ptr()))
-        stage[st] = ms.value
-    gemm_ms = [stage[i] for i in (2, 5, 7, 9)]   # the four MFMA stage launches of one update
-    gemm_launch_s = float(np.mean(gemm_ms)) * 1e-3
-    # algorithmic FLOPs per launch = SURVEY §8(d)'s per-update figure / 4 launches (on the fused path the
-    # launches also carry layer 1, the heads, the losses and the optimizer step: nothing else computes)
+    launches_per_update = 5
     gf = update_flops(**cfgd)
-    achieved = gf / 4.0 / gemm_launch_s / 1e12
-    traffic = None
+    roofline = {"kernel": "the %d launches of one SAC1 update (k_dfwd<0>, k_dfwd<1>, k_dg x3: layer 1 + fc GEMMs + heads / losses / "
+                          "Adam / polyak in the epilogues), fp32 MFMA" % launches_per_update,
+                "bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "update_flops": gf,
+                "flops_per_launch": gf / launches_per_update}
+    if trainer is not None:
+        n_upd = 40 * args.updates_per_graph
+        t_upd = timed(lambda: trainer.run(n_upd), 3, warm=1) / n_upd
+        stage = np.zeros(_lib.SAC1_STAGES, np.float64)
+        ms = ctypes.c_float()
+        for st in (2, 5, 7, 8, 9):   # eager back-to-back launches of ONE stage (caches warm): a lower bound per launch
+            _lib.check(lib.ddrl_sac1_stage_time(trainer.agent._h, st, args.stage_samples, ctypes.byref(ms), _lib.stream_ptr()))
+            stage[st] = ms.value
+        launch_s = t_upd / launches_per_update
+        roofline.update({"achieved": gf / launches_per_update / launch_s / 1e12,   # per-launch FLOPs / per-launch time
+                         "frac": gf / launches_per_update / launch_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "avg_launch_us": launch_s * 1e6, "update_us_learner_only": t_upd * 1e6,
+                         "update_roofline_frac": (gf / (PEAK_F32_MFMA_TFLOPS * 1e12)) / t_upd,
+                         "stage_us_warm": {k: round(float(stage[i]) * 1e3, 3) for k, i in
+                                           (("k_dfwd<0>", 2), ("k_dfwd<1>", 5), ("k_dg bq", 7), ("k_dg mid", 8), ("k_dg pi", 9))}})
+    else:
+        upd_s = dt / (args.steps * updates_per_step)
+        roofline.update({"achieved": gf / upd_s / 1e12, "frac": gf / upd_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "avg_launch_us": upd_s / launches_per_update * 1e6,
+                         "note": "from the timed region (eager per-update stepping on the learner ranks, batch transfer included)"})
+    traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_gemm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "MFMA stage launches k_fwd<0> / k_fwd<1> / k_bwdq / k_gemm (4 per update, fp32 MFMA)", "bound": "mfma",
-                "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "flops_per_launch": gf / 4.0, "avg_launch_us": gemm_launch_s * 1e6,
-                "stage_us": [round(float(x) * 1e3, 3) for x in stage],
-                "stages_sum_us": float(stage.sum() * 1e3),
-                "update_flops": update_flops(**cfgd)}
-    upd_us_in_loop = dt / (args.steps * updates_per_step) * 1e6  # includes the rollout share
-    roofline["update_roofline_frac"] = (update_flops(**cfgd) / (PEAK_F32_MFMA_TFLOPS * 1e12)) / (upd_us_in_loop * 1e-6)
+            tj = json.load(open(tpath))
+            traffic, tsrc = tj.get("bytes_per_launch_mean"), tj.get("source")
+        except Exception:  # noqa
+            pass
+    roofline["traffic"] = traffic
+    roofline["traffic_source"] = ("static file profiles/traffic.json (%s) — regenerate with tools/pmc_summary.py whenever the kernels change" % tsrc) if traffic else None
 
     out = {
         "metric": "env-steps/s + learner updates/s, SAC1 LunarLanderContinuous-v2 @1/2/4/8 GPU",
@@ -261,23 +397,27 @@ def main():
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "SAC1 LunarLanderContinuous-v2 stand-in, %d vectorised envs + %d-transition "
-                               "device replay per GPU, batch=%d, hidden (400,300), a_l_ratio=%g -> %d updates "
-                               "per vector step, push every 300 updates" %
-                               (args.num_envs, args.capacity, args.batch, args.a_l_ratio, updates_per_step),
-                   "num_envs": args.num_envs, "replay_capacity": args.capacity, "batch": args.batch,
-                   "updates_per_step": updates_per_step, "updates_per_graph": args.updates_per_graph,
-                   "parallelism": ("dp-learners allreduce" if args.dp_learners else
-                                   "replicas: per-GPU envs + replay shard + learner; ps.push/pull = RCCL broadcast")
-                   if world > 1 else "single GPU"},
+        "config": {"workload": "SAC1 LunarLanderContinuous-v2 stand-in, %d vectorised envs per rollout rank + %d-transition device replay "
+                               "(%d shard(s)), batch=%d, hidden (400,300), %d updates per learner rank per step, push every 300 updates" %
+                               (num_envs, args.capacity, len(roles.shard_owner), args.batch, updates_per_step),
+                   "num_envs": num_envs, "replay_capacity": args.capacity, "batch": args.batch,
+                   "updates_per_step": updates_per_step, "updates_per_graph": args.updates_per_graph if world == 1 else 0,
+                   "env_steps_per_sample": env_steps / max(1, updates), "learner_ranks": roles.learners, "rollout_ranks": roles.rollouts,
+                   "backend": (torch.distributed.get_backend() if world > 1 else None), "devices": ndev,
+                   "parallelism": roles.describe()},
+        "repeat_blocks": {"n": len(blocks), "ms_per_step_median": float(np.median(blocks)) / args.steps * 1e3,
+                          "ms_per_step_min": float(np.min(blocks)) / args.steps * 1e3, "ms_per_step_max": float(np.max(blocks)) / args.steps * 1e3,
+                          "note": "`value` is block 0 (exactly --steps steps); the same block repeated to keep the GPU leg visible"},
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.a_l_ratio, args.cpu_budget)
-        out["gpu_over_cpu"] = {"env_steps": out["value"] / out["cpu_baseline"]["value"],
-                               "updates": out["updates_per_s"] / out["cpu_baseline"]["updates_per_s"]}
-    else:
-        out["cpu_baseline"] = None
+    if run is not None:
+        out["partition_stats"] = run.stats
+    if world == 1 and not args.no_stages:
+        out["stages"] = stage_measurements(args, opt, rb, roll, d)
+    out["cpu_baseline"] = cpu_one
+    out["cpu_baseline_all_cores"] = cpu_all
+    if cpu_one is not None:
+        out["gpu_over_cpu"] = {"env_steps": out["value"] / cpu_one["value"], "updates": out["updates_per_s"] / cpu_one["updates_per_s"]}
     print(json.dumps(out))
 
 

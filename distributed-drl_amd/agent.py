@@ -93,7 +93,7 @@ class HyperParameters:
 
 
 class _Net:
-    def _setup(self, opt, nets):
+    def _setup(self, opt, nets, job="", index=0):
         _lib.require_gpu()
         self._lib = _lib.load()
         self.opt = opt
@@ -107,7 +107,9 @@ class _Net:
             self.table[n] = (off, cnt, s)
             off += cnt
         self.n_params = off
-        self._noise_seed = int(getattr(opt, "seed", 0)) & 0xFFFFFFFF
+        # one noise stream per (seed, job, worker): workers / ranks that share opt.seed must not draw the same eps sequence
+        import zlib
+        self._noise_seed = (int(getattr(opt, "seed", 0)) * 2654435761 + zlib.crc32(str(job).encode()) + 97 * int(index)) & 0xFFFFFFFF
         self._noise_ctr = 0
 
     def _flat_get(self):
@@ -162,8 +164,8 @@ class Learner(_Net):
     VARIANT = 0   # _lib.SAC1
     N_LOSSES = 3
 
-    def __init__(self, opt, job="learner"):
-        self._setup(opt, self.NETS)
+    def __init__(self, opt, job="learner", index=0):
+        self._setup(opt, self.NETS, job, index)
         self.cfg = opt.config(variant=self.VARIANT)
         h = ctypes.c_void_p()
         _lib.check(self._lib.ddrl_sac1_create(ctypes.byref(h), self.device.index, ctypes.byref(self.cfg)))
@@ -241,6 +243,28 @@ class Learner(_Net):
         if return_outputs:
             return self.losses, outs
         return None  # the reference drops the fetched values (actor_learner.py:142)
+
+    def _device_args(self, batch):
+        """Pointers for a batch that already lives on the device, with the noise generated inside the update's first
+        kernel from the learner's device counter (ddrl_sac1_fill_noise): no noise launch, no host round trip."""
+        if getattr(self, "_in0", None) is None:
+            bufs = (ctypes.c_void_p * 8)()
+            _lib.check(self._lib.ddrl_sac1_input_buffers(self._h, 0, bufs))
+            self._in0 = [bufs[i] for i in range(8)]
+        B, a = self.cfg.batch, self.cfg.act_dim
+        keep = [self._dev(batch[k], s) for k, s in (("obs1", (B, -1)), ("obs2", (B, -1)), ("acts", (B, a)), ("rews", (B,)), ("done", (B,)))]
+        _lib.check(self._lib.ddrl_sac1_fill_noise(self._h, self._noise_seed, _lib.stream_ptr()))
+        return keep, [_lib.dptr(t) for t in keep] + self._in0[5:8] + [None, None, None, None]
+
+    def train_device(self, batch):
+        """train() for a device-resident batch with in-kernel noise (what the graph loop does per update, issued eagerly)."""
+        keep, ptrs = self._device_args(batch)
+        _lib.check(self._lib.ddrl_sac1_step(self._h, *ptrs, _lib.stream_ptr()))
+
+    def compute_gradients_device(self, batch):
+        keep, ptrs = self._device_args(batch)
+        _lib.check(self._lib.ddrl_sac1_compute_grads(self._h, *ptrs, _lib.stream_ptr()))
+        return self.export(_lib.SAC1_GRAD)
 
     def compute_gradients(self, batch, eps=None):
         """Forward + backward only (the stubbed compute_gradients of actor_learner.py:144-145)."""
@@ -326,8 +350,8 @@ class Model(Learner):
 class Actor(_Net):
     """algos/sac1/actor_learner.py:151-229 (policy-only graph)."""
 
-    def __init__(self, opt, job="worker", max_rows=None):
-        self._setup(opt, ("pi",))
+    def __init__(self, opt, job="worker", max_rows=None, index=0):
+        self._setup(opt, ("pi",), job, index)
         self.cfg = opt.config()
         self.max_rows = int(max_rows if max_rows is not None else max(1, getattr(opt, "num_envs", 1)))
         h = ctypes.c_void_p()

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_env_step(float *S, long long n, uint32_
 // done is the raw d).  The wrapper's np.random.random noise is the env's counter generator
 // (slots 2.. of the per-step stream; a stream of its own for the reset observation).
 constexpr uint32_t RESET_NOISE_STREAM = 0xFFFFFFEFu;
-__global__ void __launch_bounds__(256) k_env_step_wrapped(float *S, long long n, uint32_t seed, float limit_steps, const float *act,
+__global__ void __launch_bounds__(256) k_env_step_wrapped(float *S, long long n, uint32_t seed, float limit_steps, float *act,
                                                           float act_noise, float obs_noise, float reward_scale, int repeat,
                                                           float *obs2, float *rew_out, float *done_out, float *next_obs,
                                                           uint8_t *ended_out, EnvStats *stats) {
@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(256) k_env_step_wrapped(float *S, long long n,
         const float2 a = *reinterpret_cast<const float2 *>(act + i * 2);
         const float a0 = a.x + act_noise * (-2.0f * e.rng(st0, 2) + 1.0f);   // hyperparams.py:124
         const float a1 = a.y + act_noise * (-2.0f * e.rng(st0, 3) + 1.0f);
+        *reinterpret_cast<float2 *>(act + i * 2) = make_float2(a0, a1);       // `action += ...` mutates the caller's array: the rollout queues the NOISY action
         float r = 0.0f, rew = 0.0f;
         bool noisy = true;
         for (int k = 0; k < repeat; ++k) {                                    // :126-133
@@ -412,7 +413,7 @@ int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d
     return DDRL_OK;
 }
 
-int ddrl_env_step_wrapped(ddrl_env_t *h, const float *act_d, float act_noise, float obs_noise, float reward_scale, int32_t action_repeat,
+int ddrl_env_step_wrapped(ddrl_env_t *h, float *act_d, float act_noise, float obs_noise, float reward_scale, int32_t action_repeat,
                           int32_t limit_steps, float *obs2_d, float *rew_d, float *done_d, float *next_obs_d, uint8_t *ended_d,
                           void *stream) {
     DDRL_REQUIRE(h != nullptr && act_d != nullptr, "NULL pointer");

@@ -39,13 +39,12 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, Sto
     const bool v4 = (width & 3) == 0;
     const int wv = v4 ? width >> 2 : width;  // row width in vector elements
     const long long total = (n - skip) * wv;
-    const long long base_row = ptr + skip;   // ring row of source row `skip` before wrapping (< 2 * cap)
+    const long long base_row = (ptr + skip) % cap;  // ring row of source row `skip` (skip = n - cap is unbounded: reduce it once per thread)
     if (total < 0x7fffffffll) {
         const unsigned tot = (unsigned)total, uw = (unsigned)wv, ustride = (unsigned)stride;
         for (unsigned e = (unsigned)t0; e < tot; e += ustride) {
             const unsigned ri = e / uw, c = e - ri * uw;
-            long long row = base_row + ri;
-            if (row >= cap) row -= cap;
+            long long row = base_row + ri;  // base_row < cap and ri < cap: one conditional subtraction is the modulo
             if (row >= cap) row -= cap;
             const long long so = (long long)(skip + ri) * wv + c, dof = row * wv + c;
             if (v4) reinterpret_cast<float4 *>(dst)[dof] = reinterpret_cast<const float4 *>(src)[so];

@@ -28,10 +28,19 @@ class _ActorMethod:
         return fut
 
 
+def _current_device():
+    try:
+        import torch
+        return torch.cuda.current_device() if torch.cuda.is_available() else None
+    except Exception:  # noqa
+        return None
+
+
 class ActorHandle:
     def __init__(self, cls, args, kwargs):
         self._mailbox = queue.Queue()
         self._obj = None
+        self._device = _current_device()   # torch's current device is thread-local and starts at 0 in a new thread
         ready = Future()
         self._thread = threading.Thread(target=self._run, args=(cls, args, kwargs, ready), daemon=True)
         self._thread.start()
@@ -39,6 +48,9 @@ class ActorHandle:
 
     def _run(self, cls, args, kwargs, ready):
         try:
+            if self._device is not None:
+                import torch
+                torch.cuda.set_device(self._device)   # the actor allocates on its creator's GPU, not on cuda:0
             self._obj = cls(*args, **kwargs)
             ready.set_result(True)
         except BaseException as e:  # noqa
@@ -82,11 +94,15 @@ class _RemoteFunction:
 
     def remote(self, *args, **kwargs):
         fut = Future()
+        device = _current_device()
 
         def run():
             if not fut.set_running_or_notify_cancel():
                 return
             try:
+                if device is not None:
+                    import torch
+                    torch.cuda.set_device(device)
                 fut.set_result(self._fn(*args, **kwargs))
             except BaseException as e:  # noqa
                 fut.set_exception(e)

@@ -264,7 +264,7 @@ class RolloutDevice:
         self.ps, self.rb, self.opt = ps, replay_buffer, opt
         self.env = VecLunarLander(opt.num_envs, seed=int(opt.seed) + 1000003 * int(worker_index),
                                   max_ep_len=opt.max_ep_len)
-        self.actor = Actor(opt, job="worker", max_rows=opt.num_envs)
+        self.actor = Actor(opt, job="worker", max_rows=opt.num_envs, index=worker_index)
         self.span = ps.span(self.actor.keys) if ps is not None else None
         self.version = -1
         self.t = 0
@@ -353,7 +353,7 @@ class RolloutDeviceNStep:
         n = int(opt.num_envs)
         self.env = VecLunarLander(n, seed=int(opt.seed) + 1000003 * int(worker_index), max_ep_len=1 << 23)
         self.limit_steps = -(-int(opt.max_ep_len) // int(opt.action_repeat))   # ep_len * action_repeat >= max_ep_len (sac_ray.py:252)
-        self.actor = Actor(opt, job="worker", max_rows=n) if ps is not None else None
+        self.actor = Actor(opt, job="worker", max_rows=n, index=worker_index) if ps is not None else None
         self.span = ps.span(self.actor.keys) if ps is not None else None
         self.version = -1
         self.filling_steps = 0
@@ -394,7 +394,7 @@ class TrainDevice:
         from . import _lib
         from .agent import Learner
         self.ps, self.rb, self.opt = ps, replay_buffer, opt
-        self.agent = Learner(opt, job="learner")
+        self.agent = Learner(opt, job="learner", index=learner_index)
         self.on_push = on_push  # multi-GPU: comm.ParamBroadcast.sync
         if ps is not None:
             span = ps.span(self.agent.keys)

@@ -331,8 +331,10 @@ int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d
  * rewards summed — dropped to 0.0 when the episode ends inside the repeat —, uniform observation
  * noise, reward scale; action_repeat == 1 returns the bare step) followed by the n-step rollout's
  * bookkeeping (algos/sac1/sac_ray.py:212-258): an episode ends on d or after `limit_steps` wrapped
- * steps (= ceil(max_ep_len / opt.action_repeat)), done_d is the raw d.  Same outputs as ddrl_env_step. */
-int ddrl_env_step_wrapped(ddrl_env_t *h, const float *act_d, float act_noise, float obs_noise, float reward_scale,
+ * steps (= ceil(max_ep_len / opt.action_repeat)), done_d is the raw d.  Same outputs as ddrl_env_step.
+ * act_d is updated IN PLACE with the action noise, as the reference's `action += ...` mutates the caller's
+ * array (hyperparams.py:124): what the rollout appends to its a_r_d_queue afterwards is the noisy action. */
+int ddrl_env_step_wrapped(ddrl_env_t *h, float *act_d, float act_noise, float obs_noise, float reward_scale,
                           int32_t action_repeat, int32_t limit_steps, float *obs2_d, float *rew_d, float *done_d,
                           float *next_obs_d, uint8_t *ended_d, void *stream);
 /* Episode statistics accumulated on device since the last call: number of finished episodes,

@@ -266,6 +266,7 @@ class LanderOracle:
         a = np.empty_like(act)
         a[:, 0] = act[:, 0] + F(act_noise) * (F(-2.0) * self._rng(st0, 2) + F(1.0))
         a[:, 1] = act[:, 1] + F(act_noise) * (F(-2.0) * self._rng(st0, 3) + F(1.0))
+        act[...] = a   # hyperparams.py:124 `action += ...` mutates the caller's array (a float32 ndarray is updated in place)
         r = np.zeros(self.n, F)
         rew = np.zeros(self.n, F)
         obs = np.zeros((self.n, 8), F)

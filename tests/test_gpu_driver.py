@@ -81,7 +81,8 @@ def test_device_style_workers_learn_something():
     assert trainer.agent.opt_steps() == (20, 20)
     assert roll.version > v_start                                    # the actor pulled pushed weights
     a = roll.actor.get_weights_flat()
-    assert torch.equal(a, trainer.agent.get_weights_flat()[: a.numel()]) is False or True
+    assert torch.equal(a, ps.pull_flat(0, a.numel()))                              # the actor runs what the server holds: the push after update 16
+    assert not torch.equal(a, trainer.agent.get_weights_flat()[: a.numel()])      # ... which the learner has moved on from (updates 17-20)
     eps, ret, ln = roll.env.stats()
     assert ln >= 0 and np.isfinite(ret)
     losses, _ = trainer.agent.train(rb.sample_batch_device(256), return_outputs=True)
@@ -118,8 +119,8 @@ def test_nstep_rollout_equals_per_env_reference_loop():
     for t in range(steps):
         ro.step()
         act = no.uniform_fill(n * 2, -1.0, 1.0, opt.seed ^ 0x5EED5EED, counter=t * n * 2).reshape(n, 2)  # env.action_space.sample()
-        np.testing.assert_array_equal(ro.act.cpu().numpy(), act)
         o2, r, dd, nxt, ended = env.step_wrapped(act, opt.act_noise, opt.obs_noise, opt.reward_scale, 3, limit)
+        np.testing.assert_array_equal(ro.act.cpu().numpy(), act)   # both now hold the noisy action (`action +=` in Wrapper.step)
         for e in range(n):
             aq[e].append((act[e].copy(), r[e], dd[e]))
             oq[e].append((o2[e].copy(),))

@@ -120,9 +120,11 @@ def test_empty_buffer_raises_like_reference(ddrl):
     assert str(e.value) == "high <= 0"
 
 
-@pytest.mark.parametrize("cap,chunks", [(1000, [1, 7, 992, 5, 1000, 999, 2500, 3]), (4096, [4096, 4096, 100])])
+@pytest.mark.parametrize("cap,chunks", [(1000, [1, 7, 992, 5, 1000, 999, 2500, 3]), (4096, [4096, 4096, 100]),
+                                        (1000, [4, 5003, 1, 12007]), (7, [3, 100, 2])])
 def test_store_batch_equals_sequential_store(ddrl, cap, chunks):
-    """store_batch(n) == n sequential store() calls, incl. wrap inside a batch and n > capacity."""
+    """store_batch(n) == n sequential store() calls, incl. wrap inside a batch and n > capacity — also n many times the
+    capacity with the cursor off zero (n = 5 cap + 3 at ptr = 4: the rows skipped at the front are unbounded)."""
     from oracle.replay_oracle import ReplayBufferOracle
     rs = np.random.RandomState(3)
     buf = ddrl.ReplayBufferSAC1(8, 2, cap)
