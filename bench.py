@@ -221,7 +221,7 @@ def stage_measurements(args, opt, rb, roll, d):
     import torch
     out = {}
     n_env = int(opt.num_envs)
-    t = timed(roll.step, 200)
+    t = timed(lambda: roll.step(20), 20) / 20.0   # 20 vector steps per call: two launches per step, no host work in between
     pf = policy_flops(opt.obs_dim, opt.act_dim, opt.hidden_sizes[0], opt.hidden_sizes[1])
     out["rollout_only"] = {"env_steps_per_s": n_env / t, "us_per_vector_step": t * 1e6, "num_envs": n_env,
                            "flop_per_env_step": pf, "achieved_TFLOPs": n_env * pf / t / 1e12,

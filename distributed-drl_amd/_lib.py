@@ -108,6 +108,8 @@ SIGNATURES = {
     "ddrl_env_destroy": (c_int, [_P]),
     "ddrl_env_reset": (c_int, [_P, _P, _P, _P]),
     "ddrl_env_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "ddrl_rollout_begin": (c_int, [_P, _P, _P]),
+    "ddrl_rollout_step": (c_int, [_P, _P, _P, c_int32, c_uint32, c_uint64, c_int, _P, _P, _P]),
     "ddrl_env_step_wrapped": (c_int, [_P, _P, c_float, c_float, c_float, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "ddrl_env_stats": (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), _P]),
     "ddrl_env_get_state": (c_int, [_P, _P, _P]),

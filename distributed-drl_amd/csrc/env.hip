@@ -9,6 +9,8 @@
 // contraction (-ffp-contract=off), correctly rounded sqrt/divide, polynomial sin/cos shared with
 // the oracle, counter-hash RNG.  Every arithmetic statement below mirrors one line of the oracle.
 #include "ddrl_common.h"
+#include "policy_row.h"
+#include "replay_device.h"
 
 namespace {
 
@@ -352,6 +354,161 @@ __global__ void __launch_bounds__(256) k_env_step_wrapped(float *S, long long n,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fused rollout step (RolloutDevice.step = num_envs iterations of example/dsac.py:96-130 in the policy phase):
+//   a = agent.get_action(o)      the policy-head partials of the forward launch in front of this kernel are summed in
+//                                n-tile order, tanh-squashed with the counter-hash noise (ddrl_pol::policy_row)
+//   o2, r, d, _ = env.step(a)    the physics above
+//   replay_buffer.store(o, a, r, o2, d)   straight into ring row (ptr + i) % capacity — the n stores in env order,
+//                                like ddrl_replay_store; the last block to finish advances the cursor
+//   o = o2 (or env.reset())      written into the actor's observation buffer for the next forward launch
+// One thread per env: no exchange between threads except the cursor ticket.
+// ------------------------------------------------------------------------------------------
+struct RolloutArgs {
+    float *S;
+    long long n;
+    uint32_t seed;
+    float max_ep_len;
+    EnvStats *stats;
+    // policy
+    float *obs;            // [n][obs_dim] in / out (actor's buffer)
+    const float *hp;       // [8][n][16]
+    const float *bmu, *bls;
+    int act, nt2;
+    float scale;
+    int deterministic;
+    uint32_t noise_seed;
+    unsigned long long noise_ctr;
+    // replay ring
+    ddrl_replay_dev::RingState *rs;
+    ddrl_replay_dev::RingPtrs ring;
+    // optional mirrors for the host-side objects
+    float *act_out, *next_obs_out;
+};
+template <int NH>  // head partial rows fetched per env: 4 (act_dim <= 2) or 8
+__global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
+    __shared__ long long s_ptr;
+    if (threadIdx.x == 0) s_ptr = a.rs->ptr;
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = a.n;
+    long long n_end = 0, len_end = 0;
+    double ret_end = 0.0;
+    if (i < n) {
+        // ---- loads first: head partials (mu heads 0..act-1, log_std heads act..2act-1), the acted-on observation, the env state
+        const int nq = (a.nt2 + 3) >> 2;  // float4 groups of a partial row that hold tiles
+        float4 hv[NH][4];
+#pragma unroll
+        for (int c = 0; c < NH; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cc = c < 2 * a.act ? c : 0, qq = q < nq ? q : 0;
+                hv[c][q] = *reinterpret_cast<const float4 *>(a.hp + ((long long)cc * n + i) * 16 + 4 * qq);
+            }
+        float o1[8];
+        {
+            const float4 *p = reinterpret_cast<const float4 *>(a.obs + i * 8);
+            const float4 u = p[0], v = p[1];
+            o1[0] = u.x; o1[1] = u.y; o1[2] = u.z; o1[3] = u.w; o1[4] = v.x; o1[5] = v.y; o1[6] = v.z; o1[7] = v.w;
+        }
+        Env e;
+        e.seed = a.seed; e.id = (uint32_t)i;
+        e.load(a.S, n, i);
+        float mu[4], ls[4], ev[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float sm = 0.f, sl = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {  // n-tile order; slots beyond nt2 hold 0
+                    const float4 m4 = hv[c < NH ? c : 0][q], l4 = hv[(c + a.act) & (NH - 1)][q];
+                    sm += m4.x; sm += m4.y; sm += m4.z; sm += m4.w;
+                    sl += l4.x; sl += l4.y; sl += l4.z; sl += l4.w;
+                }
+            }
+            const int cc = c < a.act ? c : 0;
+            mu[c] = sm + a.bmu[cc];
+            ls[c] = sl + a.bls[cc];
+            ev[c] = (a.deterministic || c >= a.act) ? 0.f : ddrl_pol::normal_at(a.noise_seed, a.noise_ctr + (unsigned long long)(i * a.act + c));
+        }
+        const ddrl_pol::PolRow pr = ddrl_pol::policy_row(mu, ls, ev, a.act, a.scale);
+        const float a0 = a.deterministic ? tanhf(mu[0]) * a.scale : pr.act[0];
+        const float a1 = a.act > 1 ? (a.deterministic ? tanhf(mu[1]) * a.scale : pr.act[1]) : 0.f;
+        // ---- env.step + the worker's bookkeeping (as k_env_step)
+        float o[8];
+        bool done_env;
+        const float rew = e.physics(a0, a1, done_env, o);
+        e.eplen = e.eplen + 1.0f;                       // example/dsac.py:104
+        e.epret = e.epret + rew;                        // :103
+        const bool limit = e.eplen >= a.max_ep_len;
+        const float done_store = limit ? 0.0f : (done_env ? 1.0f : 0.0f);  // :109
+        const bool ended = done_env || limit;                              // :118
+        // ---- replay_buffer.store(o, a, r, o2, d): ring arrays {obs1, obs2, acts, rews, done}
+        const long long cap = a.ring.capacity;
+        if (i >= n - cap) {  // rows that a later store of the same batch would overwrite are skipped (n > capacity)
+            const long long row = (s_ptr + i) % cap;
+            float4 *p1 = reinterpret_cast<float4 *>(a.ring.a[0] + row * 8), *p2 = reinterpret_cast<float4 *>(a.ring.a[1] + row * 8);
+            p1[0] = make_float4(o1[0], o1[1], o1[2], o1[3]); p1[1] = make_float4(o1[4], o1[5], o1[6], o1[7]);
+            p2[0] = make_float4(o[0], o[1], o[2], o[3]); p2[1] = make_float4(o[4], o[5], o[6], o[7]);
+            *reinterpret_cast<float2 *>(a.ring.a[2] + row * 2) = make_float2(a0, a1);
+            a.ring.a[3][row] = rew;
+            a.ring.a[4][row] = done_store;
+        }
+        if (a.act_out) *reinterpret_cast<float2 *>(a.act_out + i * 2) = make_float2(a0, a1);
+        if (ended) {
+            n_end = 1; len_end = (long long)e.eplen; ret_end = (double)e.epret;
+            e.epi = e.epi + 1.0f;
+            e.reset(o);                                 // :127
+        }
+        {
+            float4 *p = reinterpret_cast<float4 *>(a.obs + i * 8);
+            p[0] = make_float4(o[0], o[1], o[2], o[3]);
+            p[1] = make_float4(o[4], o[5], o[6], o[7]);
+            if (a.next_obs_out) {
+                float4 *q = reinterpret_cast<float4 *>(a.next_obs_out + i * 8);
+                q[0] = p[0]; q[1] = p[1];
+            }
+        }
+        e.store(a.S, n, i);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_end += __shfl_xor(n_end, off);
+        len_end += __shfl_xor(len_end, off);
+        ret_end += __shfl_xor(ret_end, off);
+    }
+    if ((threadIdx.x & 63) == 0 && n_end > 0) {
+        atomicAdd((unsigned long long *)&a.stats->episodes, (unsigned long long)n_end);
+        atomicAdd((unsigned long long *)&a.stats->len_sum, (unsigned long long)len_end);
+        atomicAdd(&a.stats->ret_sum, ret_end);
+    }
+    // the last block to finish advances the ring cursor (every block has read rs->ptr before its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = atomicAdd(&a.rs->done_counter, 1u);
+        if (ticket == gridDim.x - 1) {
+            const long long cap = a.ring.capacity;
+            a.rs->ptr = (s_ptr + n) % cap;
+            const long long sz = a.rs->size + n;
+            a.rs->size = sz > cap ? cap : sz;
+            a.rs->steps += n * a.ring.steps_inc;
+            a.rs->done_counter = 0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_env_obs(float *S, long long n, uint32_t seed, float *obs_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Env e;
+    e.seed = seed; e.id = (uint32_t)i;
+    e.load(S, n, i);
+    float o[8];
+    e.obs(o);
+    float4 *p = reinterpret_cast<float4 *>(obs_out + i * 8);
+    p[0] = make_float4(o[0], o[1], o[2], o[3]);
+    p[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
 }  // namespace
 
 struct ddrl_env {
@@ -423,6 +580,47 @@ int ddrl_env_step_wrapped(ddrl_env_t *h, float *act_d, float act_noise, float ob
         h->S, h->n, h->seed, (float)limit_steps, act_d, act_noise, obs_noise, reward_scale, action_repeat, obs2_d, rew_d, done_d, next_obs_d,
         ended_d, h->stats);
     DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_rollout_begin(ddrl_env_t *h, ddrl_actor_t *actor, void *stream) {
+    DDRL_REQUIRE(h != nullptr && actor != nullptr, "NULL handle");
+    const ddrl_actor_rollout_view v = ddrl_actor_internal_view(actor);
+    DDRL_REQUIRE(v.ok, "actor has no direct-operand policy (shape outside the envelope): use ddrl_actor_act + ddrl_env_step + ddrl_replay_store");
+    DDRL_REQUIRE(v.obs_dim == 8 && h->n <= v.max_rows && v.device == h->device, "actor / env mismatch (obs_dim 8, max_rows >= n_envs, same device)");
+    ddrl::DeviceGuard g(h->device);
+    k_env_obs<<<(unsigned)((h->n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->S, h->n, h->seed, v.obs);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay, int32_t n_steps, uint32_t noise_seed, uint64_t noise_ctr,
+                      int deterministic, float *act_out_d, float *next_obs_out_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && actor != nullptr && replay != nullptr, "NULL handle");
+    const ddrl_actor_rollout_view v = ddrl_actor_internal_view(actor);
+    DDRL_REQUIRE(v.ok, "actor has no direct-operand policy (shape outside the envelope): use ddrl_actor_act + ddrl_env_step + ddrl_replay_store");
+    DDRL_REQUIRE(v.obs_dim == 8 && v.act <= 2 && h->n <= v.max_rows && h->n % 32 == 0 && v.device == h->device,
+                 "actor / env mismatch (obs_dim 8, act_dim <= 2, n_envs a multiple of 32 within max_rows, same device)");
+    const ddrl_replay_dev::SamplerView rv = ddrl_replay_sampler_view(replay);
+    DDRL_REQUIRE(rv.ring.n_arr == 5 && rv.ring.w[0] == 8 && rv.ring.w[1] == 8 && rv.ring.w[2] == 2 && rv.ring.w[3] == 1 && rv.ring.w[4] == 1,
+                 "replay row shape must be (obs1[8], obs2[8], acts[2], rews, done)");
+    DDRL_REQUIRE(n_steps >= 1, "n_steps must be >= 1");
+    ddrl::DeviceGuard g(h->device);
+    RolloutArgs a{};
+    a.S = h->S; a.n = h->n; a.seed = h->seed; a.max_ep_len = (float)h->max_ep_len; a.stats = h->stats;
+    a.obs = v.obs; a.hp = v.hp; a.bmu = v.bmu; a.bls = v.bls; a.act = v.act; a.nt2 = v.nt2; a.scale = v.scale;
+    a.deterministic = deterministic; a.noise_seed = noise_seed;
+    a.rs = rv.state; a.ring = rv.ring; a.act_out = act_out_d; a.next_obs_out = next_obs_out_d;
+    for (int k = 0; k < n_steps; ++k) {  // the loop body of worker_rollout, n_steps times with the weights the actor holds
+        const int rc = ddrl_actor_internal_forward(actor, h->n, stream);
+        if (rc != DDRL_OK) return rc;
+        a.noise_ctr = noise_ctr + (uint64_t)k * (uint64_t)h->n * (uint64_t)v.act;
+        // one wave per workgroup: 4096 envs spread over 64 CUs instead of 16 (the kernel is a chain of dependent latencies)
+        if (v.act <= 2) k_env_step_pi<4><<<(unsigned)((h->n + 63) / 64), 64, 0, ddrl::as_stream(stream)>>>(a);
+        else k_env_step_pi<8><<<(unsigned)((h->n + 63) / 64), 64, 0, ddrl::as_stream(stream)>>>(a);
+        DDRL_LAUNCH_CHECK();
+        ddrl_replay_note_store(replay, h->n);
+    }
     return DDRL_OK;
 }
 

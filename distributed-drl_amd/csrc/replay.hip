@@ -226,6 +226,11 @@ bool ddrl_replay_can_fuse(ddrl_replay_t *h, int64_t batch) {
     return batch <= MAX_FUSED_BATCH && bytes <= MAX_FUSED_BYTES && h->h_size > 0;
 }
 void ddrl_replay_note_sample(ddrl_replay_t *h) { h->h_samples += h->ring.samples_inc; }
+void ddrl_replay_note_store(ddrl_replay_t *h, long long n) {  // host mirror bookkeeping for n stores issued by another kernel (ddrl_rollout_step)
+    h->h_ptr = (h->h_ptr + n) % h->ring.capacity;
+    h->h_size = (h->h_size + n > h->ring.capacity) ? h->ring.capacity : h->h_size + n;
+    h->h_steps += n * h->ring.steps_inc;
+}
 
 extern "C" {
 

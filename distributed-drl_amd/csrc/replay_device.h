@@ -187,3 +187,4 @@ struct SamplerView {
 ddrl_replay_dev::SamplerView ddrl_replay_sampler_view(ddrl_replay_t *h);
 bool ddrl_replay_can_fuse(ddrl_replay_t *h, int64_t batch);
 void ddrl_replay_note_sample(ddrl_replay_t *h);  // host mirror bookkeeping for a sample issued by another kernel
+void ddrl_replay_note_store(ddrl_replay_t *h, long long n);  // ... for n stores issued by another kernel

@@ -17,6 +17,7 @@
 // catastrophic cancellation that makes the literal float32 form noisy at the 1e-5 level
 // (DESIGN.md §numerics).
 #include "gemm_core.h"
+#include "policy_row.h"
 
 namespace {
 struct L1Job {  // H1 = relu([in0 | in1] * W1 + b1); optionally also writes the concatenated input rows
@@ -44,13 +45,9 @@ struct L1Jobs {
 // ------------------------------------------------------------------------------------------
 constexpr int L1_ROWS = 16;
 constexpr int L1_MAXD = 40;
-__device__ __forceinline__ float normal_at(uint32_t seed, unsigned long long c) {  // == ddrl_normal_fill element c
-    const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
-    const uint32_t h1 = ddrl::hash3(seed, lo, 2u * hi), h2 = ddrl::hash3(seed, lo, 2u * hi + 1u);
-    const float u1 = (float)((h1 >> 8) + 1u) * (1.0f / 16777216.0f);
-    const float u2 = ddrl::u01(h2);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-}
+using ddrl_pol::normal_at;
+using ddrl_pol::PolRow;
+using ddrl_pol::policy_row;
 __global__ void __launch_bounds__(256) k_l1(L1Jobs jobs) {
     const L1Job &jb = jobs.job[blockIdx.z];
     __shared__ float s_in[L1_ROWS][L1_MAXD];
@@ -1586,6 +1583,12 @@ struct ddrl_actor {
     Seg *segs_d;
     long long max_rows;
     int ldh1, ldh2;
+    // fused rollout step (ddrl_rollout_step): the policy in the direct-operand layout + the observation rows it acts on +
+    // the head partials of the forward launch, in ONE slab (k_dfwd addresses everything as base + 32-bit offset)
+    bool direct;
+    Layout Ld;
+    float *dslab, *pi_d, *obs_d, *hp_d;
+    Seg *segs_dd;
 };
 
 extern "C" {
@@ -1612,6 +1615,26 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
         return DDRL_ERR_NOMEM;
     }
     DDRL_HIP_CHECK(hipMemcpy(h->segs_d, h->L.segs.data(), h->L.segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    {
+        ddrl_sac1_config_t c2 = *cfg;
+        c2.batch = 32;
+        h->direct = direct_ok(c2) && max_rows % 32 == 0 && max_rows <= 32 * 4095 && cfg->obs_dim + 1 <= 13;
+        h->dslab = nullptr; h->segs_dd = nullptr;
+    }
+    if (h->direct) {
+        h->Ld = make_layout(*cfg, true, true);
+        const size_t np = ((size_t)h->Ld.total_int + 2048 + 63) & ~(size_t)63, no = ((size_t)max_rows * cfg->obs_dim + 63) & ~(size_t)63;
+        const size_t nh = (size_t)DFH * max_rows * DNT;
+        e = dev_alloc(&h->dslab, np + no + nh + 2048);
+        if (e == hipSuccess) e = dev_alloc(&h->segs_dd, h->Ld.segs.size());
+        if (e != hipSuccess) {
+            ddrl::set_error("hipMalloc failed in ddrl_actor_create: %s", hipGetErrorString(e));
+            ddrl_actor_destroy(h);
+            return DDRL_ERR_NOMEM;
+        }
+        h->pi_d = h->dslab; h->obs_d = h->dslab + np; h->hp_d = h->obs_d + no;
+        DDRL_HIP_CHECK(hipMemcpy(h->segs_dd, h->Ld.segs.data(), h->Ld.segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    }
     *out = h;
     return DDRL_OK;
 }
@@ -1619,6 +1642,7 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
 int ddrl_actor_destroy(ddrl_actor_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
+    (void)hipFree(h->dslab); (void)hipFree(h->segs_dd);
     (void)hipFree(h->pi_p); (void)hipFree(h->H1); (void)hipFree(h->H2); (void)hipFree(h->segs_d);
     delete h;
     return DDRL_OK;
@@ -1628,6 +1652,7 @@ int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream
     DDRL_REQUIRE(h != nullptr && flat_pi_d != nullptr, "NULL pointer");
     ddrl::DeviceGuard g(h->device);
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_pi_d, h->pi_p, nullptr, 1);
+    if (h->direct) k_pack<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_dd, flat_pi_d, h->pi_d, nullptr, 1);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
@@ -1663,3 +1688,49 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
 }
 
 }  // extern "C"
+
+// ---- internal (env.hip: ddrl_rollout_step) ------------------------------------------------------------------------
+// The policy forward of the fused rollout step: layer 1 + layer 2 + head partials of `n` observation rows that sit in
+// the actor's own observation buffer, as one k_dfwd launch (n / 32 x ceil(h2 / 32) tiles).  The env-step kernel behind it
+// turns the partials into actions (ddrl_pol::policy_row), steps the physics and appends the transitions to the ring.
+int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
+    DDRL_REQUIRE(h != nullptr && h->direct, "actor has no direct-operand policy (shape outside the envelope)");
+    DDRL_REQUIRE(n > 0 && n % 32 == 0 && n <= h->max_rows, "n must be a positive multiple of 32 within max_rows");
+    ddrl::DeviceGuard g(h->device);
+    const ddrl_sac1_config_t &c = h->cfg;
+    const Layout &L = h->Ld;
+    const int nt2 = (c.hidden2 + 31) / 32;
+    DFHead d{};
+    d.base = h->dslab; d.tiles_m = (int)(n / 32); d.tpj = d.tiles_m * nt2; d.K = c.hidden1; d.Np = L.Np2; d.B = (int)n; d.d0 = c.obs_dim;
+    d.dw2_pi = (int)(L.pi_W2 - L.pi_W1); d.dw2_q = d.dw2_pi;
+    d.x_off = d.x2_off = d.a_off = (int)(h->obs_d - h->dslab);
+    for (int i = 0; i < 5; ++i) d.w1o[i] = (int)L.pi_W1;
+    const int D1 = c.obs_dim + 1;
+    d.pack = (D1 <= 8 ? 4 : 4 + (D1 - 8 + 1) / 2) - 4;
+    DDRL_REQUIRE(d.tpj < 65536 && n < 65536, "too many rows for the packed tile arguments");
+    DFArgs F{};
+    F.njobs = 1; F.tiles_n = nt2; F.act = c.act_dim; F.Lp1 = rup32(c.hidden1 + 1); F.Lp2 = rup32(c.hidden2 + 1); F.h2 = c.hidden2;
+    F.scale = (float)c.act_scale;
+    DFJob j{};
+    j.b2 = h->pi_d + L.pi_b2; j.wh0 = h->pi_d + L.pi_Wmu; j.wh1 = h->pi_d + L.pi_Wls; j.nh = 2 * c.act_dim; j.hsplit = c.act_dim; j.hstride = c.act_dim;
+    j.hp = h->hp_d;
+    F.job[0] = j;
+    // row tiles per workgroup: ~1.7 workgroups per CU (two resident per CU fill each other's issue bubbles), each keeping its
+    // W2 / W1 registers for `mi` row tiles instead of re-fetching them per tile
+    const int total = d.tiles_m * nt2;
+    int mi = (total + 439) / 440;
+    if (mi < 1) mi = 1;
+    if (mi > 255) mi = 255;
+    launch_dfwd<0>(d, F, ddrl::as_stream(stream), mi);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+ddrl_actor_rollout_view ddrl_actor_internal_view(ddrl_actor *h) {
+    ddrl_actor_rollout_view v{};
+    if (!h || !h->direct) return v;
+    v.ok = 1; v.obs = h->obs_d; v.hp = h->hp_d; v.bmu = h->pi_d + h->Ld.pi_bmu; v.bls = h->pi_d + h->Ld.pi_bls;
+    v.obs_dim = h->cfg.obs_dim; v.act = h->cfg.act_dim; v.nt2 = (h->cfg.hidden2 + 31) / 32; v.max_rows = h->max_rows;
+    v.scale = (float)h->cfg.act_scale; v.device = h->device;
+    return v;
+}

@@ -62,38 +62,6 @@ __device__ __forceinline__ int kline(const void *rec) {
 }
 __device__ __forceinline__ void ktouch(int v) { asm volatile("" ::"s"(v)); }
 
-// One row of one policy evaluation, all action dims in one lane.  Same formulae and operation order
-// as policy_head() (core.py:49-87, 104-106); mu / log_std pre-activations arrive as sums of partials.
-struct PolRow {
-    float act[4], a[4], std[4], t[4];
-    float logp;
-};
-__device__ __forceinline__ PolRow policy_row(const float (&mu)[4], const float (&lsr)[4], const float (&eps)[4], int act, float scale) {
-    PolRow o;
-    float sp = 0.f, sc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        o.act[c] = 0.f; o.a[c] = 0.f; o.std[c] = 0.f; o.t[c] = 0.f;
-        if (c < act) {
-            const float t = tanhf(lsr[c]);
-            const float log_std = -20.0f + 11.0f * (t + 1.0f);
-            const float std = expf(log_std);
-            const float e = eps[c];
-            const float u = mu[c] + e * std;
-            const float z = (e * std) / (std + STD_EPS);
-            const float pre = -0.5f * ((z * z + 2.0f * log_std) + LOG2PI);
-            const float a = tanhf(u);
-            const float om = 1.0f - a * a;
-            const float cl = fminf(fmaxf(om, 0.f), 1.f);
-            const float corr = logf(cl + 1e-6f);
-            sp += pre; sc += corr;
-            o.act[c] = a * scale; o.a[c] = a; o.std[c] = std; o.t[c] = t;
-        }
-    }
-    o.logp = sp - sc;
-    return o;
-}
-
 // ==========================================================================================
 // forward stages
 // ==========================================================================================
@@ -218,33 +186,35 @@ __device__ __forceinline__ void dkloop(const DOps &o, int K, int b0, int nb, int
 // MT = 2 (phase 0: 400 tiles of 32 rows would put two workgroups on most CUs, each fetching its own copy of a W2 tile —
 // the fetch phase, not the MFMAs, is what a stage waits for): one workgroup = 64 rows x 32 columns, the wave's W2 / W1
 // registers serve both row tiles.
-template <int PH, int MT>
+template <int PH, int MT, bool LOOP>
 __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int w1o0, int w1o1, int w1o2, int w1o3, int w1o4, int dw2_pi,
                                               int dw2_q, int x_off, int x2_off, int a_off, int pack, DFArgs a) {
     static_assert(PH == 0 || MT == 1, "phase 1 computes one policy row per lane");
+    static_assert(!LOOP || (PH == 0 && MT == 1), "row-chunk loop: the actor's forward only");
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ __attribute__((aligned(16))) float tr[4][32 * 36];
     __shared__ float s_wh[DFH][32];
-    const int tpj = tpj_tm & 0xffff, tiles_m = tpj_tm >> 16;
+    const int tpj = tpj_tm & 0xffff, tiles_m = (tpj_tm >> 16) & 0xfff, njobs = (unsigned)tpj_tm >> 28;
+    const int K = K_Np & 0xfff, Np = (K_Np >> 12) & 0xfff, MI = LOOP ? (int)((unsigned)K_Np >> 24) : 1, B = B_d0 & 0xffff, d0 = (B_d0 >> 16) & 0xff, act = B_d0 >> 24;
     DRT(PH, 14); DST(PH, 0);
-    if (PH == 1 && (int)blockIdx.x == 3 * tpj) {  // only launched when a.do_sample
+    if (PH == 1 && (int)blockIdx.x == njobs * tpj) {  // only launched when a.do_sample
         ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
         return;
     }
     int t;
     {   // XCD-aware, panel-major tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s); give each XCD a
         // contiguous run of tiles so that a W2 panel is fetched by one or two L2s instead of all eight (speed only)
-        const int nwg = (PH == 0 ? 5 : 3) * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        const int nwg = njobs * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     const int ji = (t >= tpj) + (t >= 2 * tpj) + (t >= 3 * tpj) + (t >= 4 * tpj);
     t -= ji * tpj;
-    const int nt = (t * (65536 / tiles_m + 1)) >> 16;  // t / tiles_m (t < 8192, tiles_m <= 2047)
-    const int m0 = (t - nt * tiles_m) * (32 * MT), n0 = nt * 32;
+    const int nt = t / tiles_m;
+    const int mchunk = t - nt * tiles_m, n0 = nt * 32;  // tiles_m counts workgroup-level row chunks of MI * MT row tiles
+    int m0 = mchunk * MI * (32 * MT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int K = K_Np & 0xffff, Np = K_Np >> 16, B = B_d0 & 0xffff, d0 = (B_d0 >> 16) & 0xff, act = B_d0 >> 24;
     const int jp = (pack >> (6 * ji)) & 63;
     const int ns = 4 + (jp & 3);
     const bool is_q = (jp & 16) != 0;
@@ -289,169 +259,173 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
             }
         }
     }
-    // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
-    float xin[MT][7];
-    {
-        const float *in0 = base + ((jp & 4) ? x2_off : x_off), *in1 = base + a_off;
-#pragma unroll
-        for (int tt = 0; tt < MT; ++tt) {
-            const long long row = m0 + 32 * tt + l31;
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                const int d = d_slot(s, h);
-                const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
-                const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
-                const float v = *p;
-                xin[tt][s] = (f0 || f1) ? v : (d == D ? 1.0f : 0.f);  // column D: the bias row
-            }
-        }
-    }
     DOps ops;
     dops_load(ops, W1, W2p, K, Np, b0, nb, n0, lane);
-    DST(PH, 1);
-    const DFJob &jb = a.job[ji];
-    ktouch(kline<sizeof(DFJob)>(&jb) | kline<offsetof(DFArgs, do_sample)>(&a));
-    // ---- epilogue operands
-    const float4 b4 = *reinterpret_cast<const float4 *>(jb.b2 + n0 + 4 * (tid >> 5));
-    float whv = 0.f;
-    {
-        const int c = tid >> 5, col = n0 + (tid & 31);
-        const bool ok = c < jb.nh && col < a.h2;
-        const float *p = c < jb.hsplit ? jb.wh0 : jb.wh1;
-        const int cc = c < jb.hsplit ? c : c - jb.hsplit;
-        whv = ok ? p[(long long)col * jb.hstride + cc] : 0.f;
-    }
-    if (PH == 1) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
-        float hs[2][4];
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {  // n-tile order; unused slots are 0
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < DNT / 4; ++q) { s += hv[e][c][q].x; s += hv[e][c][q].y; s += hv[e][c][q].z; s += hv[e][c][q].w; }
-                hs[e][c] = s;
-            }
-        float mu[4], ls[4], ev[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float o = __shfl_xor(hs[0][c], 32);
-            const int cc = c < d1 ? c : 0;
-            mu[c] = (h ? o : hs[0][c]) + jb.pbmu[cc];
-            ls[c] = (h ? hs[0][c] : o) + jb.pbls[cc];
-            ev[c] = jb.peps[(long long)(m0 + l31) * d1 + cc];
-        }
-        const PolRow o = policy_row(mu, ls, ev, d1, a.scale);
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            const int d = d_slot(s, h), c = d - d0;
-            if (d >= d0 && d < D) xin[0][s] = c == 0 ? o.act[0] : (c == 1 ? o.act[1] : (c == 2 ? o.act[2] : o.act[3]));
-        }
-        if (first_n && w == 0 && lane < 32) {
-            const int row = m0 + l31;
-            if (jb.side == 1) {
-                a.logp0[row] = o.logp;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < d1) {
-                        a.act0[row * d1 + c] = o.act[c];
-                        *reinterpret_cast<float4 *>(a.save0 + ((long long)row * d1 + c) * 4) = make_float4(o.a[c], o.std[c], o.t[c], ev[c]);
-                    }
-            } else if (jb.side == 2) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < d1) a.act2[row * d1 + c] = o.act[c];
-            }
-        }
-        if (two && w == 1) {  // wave-uniform
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float o2 = __shfl_xor(hs[1][c], 32);
-                const int cc = c < d1 ? c : 0;
-                mu[c] = (h ? o2 : hs[1][c]) + a.pbmu1[cc];
-                ls[c] = (h ? hs[1][c] : o2) + a.pbls1[cc];
-                ev[c] = a.peps1[(long long)(m0 + l31) * d1 + cc];
-            }
-            const PolRow o1 = policy_row(mu, ls, ev, d1, a.scale);
-            if (lane < 32) a.logp1[m0 + l31] = o1.logp;
-        }
-    }
-    // ---- K loop
-    DST(PH, 2);
-    floatx16 acc[MT];
-#pragma unroll
-    for (int tt = 0; tt < MT; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-    float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
-    if (nb > 0) {
-        if (ns == 4) dkloop<4, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-        else if (ns == 5) dkloop<5, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-        else if (ns == 6) dkloop<6, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-        else dkloop<7, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-    }
-
-    DST(PH, 3);
-    // ---- side outputs of the n-tile-0 workgroups (off the critical path: nothing in this launch reads them)
-    s_wh[tid >> 5][tid & 31] = whv;
-    if (first_n && (jb.aug || jb.xr4)) {  // augmented input rows of the layer-1 wgrads (their ones column is set once at create)
-        for (int idx = tid; idx < 32 * MT * D; idx += 256) {
-            const int r = idx / D, d = idx - r * D;
-            const long long row = m0 + r;
-            const float v = d < d0 ? (base + ((jp & 4) ? x2_off : x_off))[row * d0 + d] : (base + a_off)[row * d1 + (d - d0)];
-            if (jb.aug) jb.aug[row * jb.aug_ld + d] = v;
-            if (jb.xr4) jb.xr4[((row >> 2) * 32 + d) * 4 + (row & 3)] = v;
-        }
-    }
-    if (PH == 0 && a.noise_on && ji == 0 && first_n) {
-        // eps_x, eps_x2, eps_t of this tile's rows; element index as in one flat [3][B*act] fill
-        const unsigned long long nbase = a.opt->noise_ctr;
-        const int per_row = 3 * act;
-        for (int e = tid; e < 32 * MT * per_row; e += 256) {
-            const int rr = e / per_row, q = e - rr * per_row;
-            const int wch = q / act, c = q - wch * act;
-            const int k = (m0 + rr) * act + c;
-            (wch == 0 ? a.e0 : (wch == 1 ? a.e1 : a.e2))[k] = normal_at(a.noise_seed, nbase + (unsigned long long)wch * a.n_each + k);
-        }
-    }
-
-    // ---- split-K combine, bias + relu, H2 in the layouts its consumers read, head partials
-    const int r = tid & 31, cg = tid >> 5;
-#pragma unroll
-    for (int tt = 0; tt < MT; ++tt) {
-        const int mb = m0 + 32 * tt;
-        if (tt > 0) __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) red[w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[tt][q];
-        __syncthreads();
-        if (tt == 0) DST(PH, 4);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * cg + e;
-            const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
-            v[e] = fmaxf(s + (e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w))), 0.f);
-        }
-        if (jb.H2c4) *reinterpret_cast<float4 *>(jb.H2c4 + ((long long)(n0 / 4 + cg) * B + mb + r) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[0][r][4 * cg + e] = v[e];
-        __syncthreads();
-        if (jb.H2r4) {  // (column hidden2 of the image is the ones column: never written here)
-            const int c = tid & 31, rg = tid >> 5;
-            if (n0 + c < a.h2)
-                *reinterpret_cast<float4 *>(jb.H2r4 + ((long long)(mb / 4 + rg) * a.Lp2 + n0 + c) * 4) =
-                    make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
-        }
+    // Row chunks: MI > 1 (the actor's forward over thousands of rows) keeps the wave's W2 / W1 registers for MI row tiles in turn
+    for (int mi = 0; mi < MI && m0 < B; ++mi, m0 += 32 * MT) {
+        // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
+        float xin[MT][7];
         {
-            const int c = tid >> 5;
-            if (c < jb.nh) {
-                float s = 0.f;
-#pragma unroll
-                for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
-                jb.hp[((long long)c * B + mb + r) * DNT + nt] = s;
+            const float *in0 = base + ((jp & 4) ? x2_off : x_off), *in1 = base + a_off;
+    #pragma unroll
+            for (int tt = 0; tt < MT; ++tt) {
+                const long long row = m0 + 32 * tt + l31;
+    #pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    const int d = d_slot(s, h);
+                    const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
+                    const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
+                    const float v = *p;
+                    xin[tt][s] = (f0 || f1) ? v : (d == D ? 1.0f : 0.f);  // column D: the bias row
+                }
             }
         }
+        DST(PH, 1);
+        const DFJob &jb = a.job[ji];
+        ktouch(kline<sizeof(DFJob)>(&jb) | kline<offsetof(DFArgs, do_sample)>(&a));
+        // ---- epilogue operands
+        const float4 b4 = *reinterpret_cast<const float4 *>(jb.b2 + n0 + 4 * (tid >> 5));
+        float whv = 0.f;
+        {
+            const int c = tid >> 5, col = n0 + (tid & 31);
+            const bool ok = c < jb.nh && col < a.h2;
+            const float *p = c < jb.hsplit ? jb.wh0 : jb.wh1;
+            const int cc = c < jb.hsplit ? c : c - jb.hsplit;
+            whv = ok ? p[(long long)col * jb.hstride + cc] : 0.f;
+        }
+        if (PH == 1) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
+            float hs[2][4];
+    #pragma unroll
+            for (int e = 0; e < 2; ++e)
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {  // n-tile order; unused slots are 0
+                    float s = 0.f;
+    #pragma unroll
+                    for (int q = 0; q < DNT / 4; ++q) { s += hv[e][c][q].x; s += hv[e][c][q].y; s += hv[e][c][q].z; s += hv[e][c][q].w; }
+                    hs[e][c] = s;
+                }
+            float mu[4], ls[4], ev[4];
+    #pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float o = __shfl_xor(hs[0][c], 32);
+                const int cc = c < d1 ? c : 0;
+                mu[c] = (h ? o : hs[0][c]) + jb.pbmu[cc];
+                ls[c] = (h ? hs[0][c] : o) + jb.pbls[cc];
+                ev[c] = jb.peps[(long long)(m0 + l31) * d1 + cc];
+            }
+            const PolRow o = policy_row(mu, ls, ev, d1, a.scale);
+    #pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const int d = d_slot(s, h), c = d - d0;
+                if (d >= d0 && d < D) xin[0][s] = c == 0 ? o.act[0] : (c == 1 ? o.act[1] : (c == 2 ? o.act[2] : o.act[3]));
+            }
+            if (first_n && w == 0 && lane < 32) {
+                const int row = m0 + l31;
+                if (jb.side == 1) {
+                    a.logp0[row] = o.logp;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < d1) {
+                            a.act0[row * d1 + c] = o.act[c];
+                            *reinterpret_cast<float4 *>(a.save0 + ((long long)row * d1 + c) * 4) = make_float4(o.a[c], o.std[c], o.t[c], ev[c]);
+                        }
+                } else if (jb.side == 2) {
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < d1) a.act2[row * d1 + c] = o.act[c];
+                }
+            }
+            if (two && w == 1) {  // wave-uniform
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float o2 = __shfl_xor(hs[1][c], 32);
+                    const int cc = c < d1 ? c : 0;
+                    mu[c] = (h ? o2 : hs[1][c]) + a.pbmu1[cc];
+                    ls[c] = (h ? hs[1][c] : o2) + a.pbls1[cc];
+                    ev[c] = a.peps1[(long long)(m0 + l31) * d1 + cc];
+                }
+                const PolRow o1 = policy_row(mu, ls, ev, d1, a.scale);
+                if (lane < 32) a.logp1[m0 + l31] = o1.logp;
+            }
+        }
+        // ---- K loop
+        DST(PH, 2);
+        floatx16 acc[MT];
+    #pragma unroll
+        for (int tt = 0; tt < MT; ++tt)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+        float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
+        if (nb > 0) {
+            if (ns == 4) dkloop<4, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+            else if (ns == 5) dkloop<5, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+            else if (ns == 6) dkloop<6, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+            else dkloop<7, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+        }
+
+        DST(PH, 3);
+        // ---- side outputs of the n-tile-0 workgroups (off the critical path: nothing in this launch reads them)
+        s_wh[tid >> 5][tid & 31] = whv;
+        if (first_n && (jb.aug || jb.xr4)) {  // augmented input rows of the layer-1 wgrads (their ones column is set once at create)
+            for (int idx = tid; idx < 32 * MT * D; idx += 256) {
+                const int r = idx / D, d = idx - r * D;
+                const long long row = m0 + r;
+                const float v = d < d0 ? (base + ((jp & 4) ? x2_off : x_off))[row * d0 + d] : (base + a_off)[row * d1 + (d - d0)];
+                if (jb.aug) jb.aug[row * jb.aug_ld + d] = v;
+                if (jb.xr4) jb.xr4[((row >> 2) * 32 + d) * 4 + (row & 3)] = v;
+            }
+        }
+        if (PH == 0 && a.noise_on && ji == 0 && first_n) {
+            // eps_x, eps_x2, eps_t of this tile's rows; element index as in one flat [3][B*act] fill
+            const unsigned long long nbase = a.opt->noise_ctr;
+            const int per_row = 3 * act;
+            for (int e = tid; e < 32 * MT * per_row; e += 256) {
+                const int rr = e / per_row, q = e - rr * per_row;
+                const int wch = q / act, c = q - wch * act;
+                const int k = (m0 + rr) * act + c;
+                (wch == 0 ? a.e0 : (wch == 1 ? a.e1 : a.e2))[k] = normal_at(a.noise_seed, nbase + (unsigned long long)wch * a.n_each + k);
+            }
+        }
+
+        // ---- split-K combine, bias + relu, H2 in the layouts its consumers read, head partials
+        const int r = tid & 31, cg = tid >> 5;
+    #pragma unroll
+        for (int tt = 0; tt < MT; ++tt) {
+            const int mb = m0 + 32 * tt;
+            if (tt > 0) __syncthreads();
+    #pragma unroll
+            for (int q = 0; q < 16; ++q) red[w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[tt][q];
+            __syncthreads();
+            if (tt == 0) DST(PH, 4);
+            float v[4];
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * cg + e;
+                const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+                v[e] = fmaxf(s + (e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w))), 0.f);
+            }
+            if (jb.H2c4) *reinterpret_cast<float4 *>(jb.H2c4 + ((long long)(n0 / 4 + cg) * B + mb + r) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            __syncthreads();
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) red[0][r][4 * cg + e] = v[e];
+            __syncthreads();
+            if (jb.H2r4) {  // (column hidden2 of the image is the ones column: never written here)
+                const int c = tid & 31, rg = tid >> 5;
+                if (n0 + c < a.h2)
+                    *reinterpret_cast<float4 *>(jb.H2r4 + ((long long)(mb / 4 + rg) * a.Lp2 + n0 + c) * 4) =
+                        make_float4(red[0][4 * rg][c], red[0][4 * rg + 1][c], red[0][4 * rg + 2][c], red[0][4 * rg + 3][c]);
+            }
+            {
+                const int c = tid >> 5;
+                if (c < jb.nh) {
+                    float s = 0.f;
+    #pragma unroll
+                    for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wh[c][col], s);
+                    jb.hp[((long long)c * B + mb + r) * DNT + nt] = s;
+                }
+            }
+        }
+        if (mi + 1 < MI) __syncthreads();  // the next row tile reuses red / s_wh
     }
     DST(PH, 5); DRT(PH, 15);
 }
@@ -465,15 +439,17 @@ static int dfwd_mt(int B, int tiles_n) {
 }
 
 template <int PH>
-static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s) {
-    const int mt = PH == 0 ? dfwd_mt(d.B, F.tiles_n) : 1;
-    const int tiles_m = d.B / (32 * mt), tpj = tiles_m * F.tiles_n;
+static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s, int mi = 1) {
+    const int mt = (PH == 0 && mi == 1) ? dfwd_mt(d.B, F.tiles_n) : 1;
+    const int tiles_m = (d.B / (32 * mt) + mi - 1) / mi, tpj = tiles_m * F.tiles_n;
     const int grid = F.njobs * tpj + ((PH == 1 && F.do_sample) ? 1 : 0);
-    const int a1 = tpj | (tiles_m << 16), a2 = d.K | (d.Np << 16), a3 = d.B | (d.d0 << 16) | (F.act << 24);
-    if (PH == 0 && mt == 2)
-        k_dfwd<0, 2><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+    const int a1 = tpj | (tiles_m << 16) | (F.njobs << 28), a2 = d.K | (d.Np << 12) | (mi << 24), a3 = d.B | (d.d0 << 16) | (F.act << 24);
+    if (PH == 0 && mi > 1)
+        k_dfwd<0, 1, true><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+    else if (PH == 0 && mt == 2)
+        k_dfwd<0, 2, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
     else
-        k_dfwd<PH, 1><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+        k_dfwd<PH, 1, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
 }
 
 // ==========================================================================================

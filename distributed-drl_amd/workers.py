@@ -270,6 +270,8 @@ class RolloutDevice:
         self.t = 0
         self.o = torch.empty_like(self.env.obs)
         self.act = torch.empty(opt.num_envs, 2, dtype=torch.float32, device=self.env.device)
+        self._fused = None if getattr(opt, "fused_rollout", True) else False
+        self._fused_live = False
         self.pull()
 
     def pull(self):
@@ -283,9 +285,41 @@ class RolloutDevice:
             self.actor.set_weights(self.actor.keys, self.ps.pull_device(self.actor.keys))
         return True
 
-    def step(self):
-        """One vector step = num_envs reference iterations (dsac.py:96-130)."""
+    def _fused_ready(self):
+        """Can this worker take the fused launch pair (ddrl_rollout_step)?  Decided once: the actor's shape must be inside
+        the direct-operand envelope and the ring must be the plain five-array SAC layout."""
+        if self._fused is None:
+            from . import _lib
+            from .replay import ReplayBuffer
+            ok = isinstance(self.rb, ReplayBuffer) and not getattr(self.rb, "_acts_1d", False) and self.env.n % 32 == 0
+            if ok:
+                ok = self.actor._lib.ddrl_rollout_begin(self.env._h, self.actor._h, _lib.stream_ptr()) == 0
+            self._fused, self._fused_live = ok, ok
+        return self._fused
+
+    def step(self, n_steps=1):
+        """One vector step = num_envs reference iterations (dsac.py:96-130); n_steps > 1 issues that many back to back with the
+        weights the actor holds (the reference pulls at episode ends only).  Policy phase: ONE policy-forward launch + ONE
+        launch that finishes get_action, steps the physics and appends the transitions to the ring (ddrl_rollout_step);
+        random-action phase (t <= start_steps) and shapes outside the envelope: get_action / env.step / store launches."""
+        from . import _lib
         env = self.env
+        if self.t > self.opt.start_steps and self._fused_ready():
+            if not self._fused_live:   # the unfused path has stepped the envs since: refresh the actor's observation rows
+                _lib.check(self.actor._lib.ddrl_rollout_begin(env._h, self.actor._h, _lib.stream_ptr()))
+                self._fused_live = True
+            a = self.actor
+            _lib.check(a._lib.ddrl_rollout_step(env._h, a._h, self.rb._h, int(n_steps), a._noise_seed, a._noise_ctr, 0, _lib.dptr(self.act),
+                                                _lib.dptr(env.obs), _lib.stream_ptr()))
+            a._noise_ctr += int(n_steps) * env.n * a.cfg.act_dim
+            self.t += int(n_steps)
+            self.pull()
+            return
+        if n_steps > 1:
+            for _ in range(int(n_steps)):
+                self.step()
+            return
+        self._fused_live = False
         self.o.copy_(env.obs)
         if self.t > self.opt.start_steps:
             self.actor.get_actions(self.o, out=self.act)

@@ -337,6 +337,21 @@ int ddrl_env_step(ddrl_env_t *h, const float *act_d, float *obs2_d, float *rew_d
 int ddrl_env_step_wrapped(ddrl_env_t *h, float *act_d, float act_noise, float obs_noise, float reward_scale,
                           int32_t action_repeat, int32_t limit_steps, float *obs2_d, float *rew_d, float *done_d,
                           float *next_obs_d, uint8_t *ended_d, void *stream);
+/* RolloutDevice.step fused: ONE vector step of worker_rollout's policy phase (example/dsac.py:96-130; SAC1 flavour
+ * algos/sac1/sac1.py:177-213) for all n envs, as two launches with no host work in between:
+ *   a = agent.get_action(o)  (Actor.get_action, actor_learner.py:195-197; noise element i*act+c of the counter stream
+ *                             (noise_seed, noise_ctr) = what ddrl_normal_fill would produce; tanh(mu) when deterministic)
+ *   o2, r, d, _ = env.step(a);  replay_buffer.store(o, a, r, o2, d)  (n stores in env order, like ddrl_replay_store);
+ *   o = o2, or the reset observation where the episode ended (d or ep_len == max_ep_len; the stored d is 0 at the limit).
+ * The acted-on observations live inside the actor handle: ddrl_rollout_begin copies the envs' current observations there
+ * (call it once, and again after any ddrl_env_step / ddrl_env_reset issued outside this path).  Requires an actor whose
+ * shape the direct-operand policy supports (LunarLander: obs 8, act 2, hidden % 4 == 0, n % 32 == 0) — else
+ * DDRL_ERR_BAD_ARG; the unfused sequence is ddrl_actor_act + ddrl_env_step + ddrl_replay_store.
+ * n_steps >= 1 vector steps are issued back to back (step k draws noise elements noise_ctr + k*n*act ...).
+ * act_out_d[n,2], next_obs_out_d[n,8]: optional mirrors of the LAST step (may be NULL). */
+int ddrl_rollout_begin(ddrl_env_t *h, ddrl_actor_t *actor, void *stream);
+int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay, int32_t n_steps, uint32_t noise_seed,
+                      uint64_t noise_ctr, int deterministic, float *act_out_d, float *next_obs_out_d, void *stream);
 /* Episode statistics accumulated on device since the last call: number of finished episodes,
  * sum of their returns and lengths.  Synchronises `stream`; resets the accumulators. Host outs. */
 int ddrl_env_stats(ddrl_env_t *h, int64_t *episodes_h, double *ret_sum_h, int64_t *len_sum_h,

@@ -251,3 +251,58 @@ def test_worker_test_sac1_saves_best_weights(tmp_path):
     assert best > -1000 and any("weights saved" in l for l in lines) and any(l.startswith("test_reward:") for l in lines)
     w = pickle.load(open(tmp_path / "weights.pickle", "rb"))
     assert set(w.keys()) == set(keys)
+
+
+def test_fused_rollout_step_matches_the_unfused_sequence_and_the_oracles():
+    """ddrl_rollout_step (policy forward launch + one launch for get_action / env.step / store) vs the three-call sequence
+    it replaces, from identical state and the same noise stream: actions within float32 rounding of each other and of the
+    float64 oracle; given the GPU's own actions the env transition and the stored ring rows are BIT-exact vs the NumPy env
+    oracle (the physics and the store are integer / exact-float work); counters, cursor and episode statistics agree."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd.agent import HyperParameters
+    from distributed_drl_amd.workers import RolloutDevice
+    from oracle import sac1_oracle as so
+    from oracle.env_oracle import LanderOracle
+    n = 4096   # BASELINE config 2
+    opt = HyperParameters()
+    opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, 40, 11
+    from distributed_drl_amd.agent import Learner
+    keys, vals = Learner(opt).get_weights()
+    ps = ddrl.ParameterServer(keys, vals)
+    rbs = [ddrl.ReplayBufferSAC1(8, 2, 3 * n + 100, seed=0) for _ in range(2)]
+    opt_u = HyperParameters()
+    opt_u.__dict__.update(opt.__dict__)
+    opt_u.fused_rollout = False
+    fused, plain = RolloutDevice(ps, rbs[0], opt), RolloutDevice(ps, rbs[1], opt_u)
+    assert fused._fused_ready() and not plain._fused_ready()
+    ora = LanderOracle(n, seed=opt.seed, max_ep_len=opt.max_ep_len)
+    cfg = so.Config()
+    params = dict(zip(keys, vals))
+    for t in range(5):   # 5 x 4096 stores into a 12388-row ring: wraps; max_ep_len 40 is not reached, crashes do end episodes
+        obs = fused.env.obs.cpu().numpy().copy()
+        np.testing.assert_array_equal(obs, ora.obs())
+        ctr = fused.actor._noise_ctr
+        fused.step()
+        plain.step()
+        act = fused.act.cpu().numpy()
+        # same policy, same eps stream: the two GPU paths differ only in the order of float32 sums
+        np.testing.assert_allclose(act, plain.act.cpu().numpy(), rtol=0, atol=2e-6)
+        eps = torch.empty(n * 2, device="cuda")
+        from distributed_drl_amd import _lib
+        _lib.check(_lib.load().ddrl_normal_fill(_lib.dptr(eps), n * 2, fused.actor._noise_seed, ctr, _lib.stream_ptr()))
+        want = so.actor_act(cfg, params, obs, eps.view(n, 2).cpu().numpy(), dtype=torch.float64)
+        np.testing.assert_allclose(act, want, rtol=1e-5, atol=2e-6)
+        # the env + store half, bit for bit, given the GPU's own actions
+        o2, r, d, nxt, ended = ora.step(act)
+        np.testing.assert_array_equal(fused.env.obs.cpu().numpy(), nxt)
+        rings = rbs[0].rings()
+        cap = 3 * n + 100
+        rows = (t * n + np.arange(n)) % cap
+        keep = np.ones(n, bool)
+        for k, w in (("obs1_buf", obs), ("obs2_buf", o2), ("acts_buf", act), ("rews_buf", r), ("done_buf", d)):
+            np.testing.assert_array_equal(rings[k].cpu().numpy()[rows][keep], np.asarray(w, np.float32)[keep], err_msg="%s step %d" % (k, t))
+        plain.env.set_state(fused.env.get_state())   # keep the two env sets identical (their actions differ in the last bits)
+        plain.env.obs.copy_(fused.env.obs)
+    assert rbs[0].get_counts() == rbs[1].get_counts() == (0, 5 * n, 3 * n + 100)
+    assert rbs[0].ptr == (5 * n) % (3 * n + 100)
+    assert fused.env.stats()[0] == ora.episodes
