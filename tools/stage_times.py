@@ -29,7 +29,7 @@ td = TrainDevice(None, rb, opt, updates_per_graph=0 if nograph else 32)
 td.run(8 if nograph else 64)
 torch.cuda.synchronize()
 lib = _lib.load()
-names = ["-", "l1a", "gemm_fa", "rows_a", "l1b", "gemm_fb", "rows_b", "gemm_bq", "rows_c", "gemm_bpi", "gemm_last"]
+names = ["-", "-", "k_dfwd<0>", "-", "-", "k_dfwd<1>", "-", "k_dg bq", "k_dg mid", "k_dg pi", "-"]   # direct path: 5 launches per update
 ms = ctypes.c_float()
 tot = 0.0
 for st in range(1, 11):
