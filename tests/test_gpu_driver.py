@@ -306,3 +306,39 @@ def test_fused_rollout_step_matches_the_unfused_sequence_and_the_oracles():
     assert rbs[0].get_counts() == rbs[1].get_counts() == (0, 5 * n, 3 * n + 100)
     assert rbs[0].ptr == (5 * n) % (3 * n + 100)
     assert fused.env.stats()[0] == ora.episodes
+
+
+def test_actor_learner_loop_at_config2_sizes_counters_and_mt_state():
+    """BASELINE config 2 exactly: 4096 envs, 10^6-transition ring, batch 256, a_l_ratio 2 -> every vector step owes 2048
+    updates (graph-captured, 50 per graph, the sampler of update u+1 riding inside update u).  After three vector steps the
+    device counters, the ring cursor and the MT19937 state of the index stream equal the oracle's after the same sequence of
+    store(4096) / 2048 x sample_batch(256) calls — bit for bit (the index stream depends on the ring size at every draw)."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    from distributed_drl_amd.workers import ActorLearnerLoop, RolloutDevice, TrainDevice
+    from oracle.replay_oracle import ReplayBufferOracle
+    opt = HyperParameters()
+    opt.num_envs, opt.batch_size, opt.start_steps, opt.a_l_ratio, opt.push_freq, opt.seed = 4096, 256, 0, 2, 300, 2
+    cap, pre = 10 ** 6, 300000
+    rb = ddrl.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, cap, seed=4)
+    ora = ReplayBufferOracle(opt.obs_dim, opt.act_dim, cap, seed=4)
+    rs = np.random.RandomState(0)
+    o, a, r = rs.randn(pre, 8).astype(np.float32), rs.uniform(-1, 1, (pre, 2)).astype(np.float32), rs.randn(pre).astype(np.float32)
+    d = np.zeros(pre, np.float32)
+    rb.store_batch(*(torch.from_numpy(x).cuda() for x in (o, a, r, o, d)))
+    ora.ptr = ora.size = ora.steps = pre              # (the oracle's per-row Python store loop is not what is under test here)
+    keys, vals = Learner(opt).get_weights()
+    ps = ddrl.ParameterServer(keys, vals)
+    loop = ActorLearnerLoop(RolloutDevice(ps, rb, opt), TrainDevice(ps, rb, opt, updates_per_graph=50), opt)
+    for step in range(3):
+        loop.run(1)
+        ora.ptr, ora.size, ora.steps = ora.ptr + 4096, ora.size + 4096, ora.steps + 4096   # store(4096): contents do not matter for the index stream, sizes do
+        for _ in range(2048):
+            ora.sample_batch(256)
+    torch.cuda.synchronize()
+    assert loop.counts() == ora.get_counts() == (3 * 2048, pre + 3 * 4096, pre + 3 * 4096)
+    assert rb.ptr == ora.ptr
+    key, pos = rb.mt_state()
+    assert pos == ora.rng.pos and (np.asarray(key) == ora.rng.key).all()
+    assert loop.trainer.agent.opt_steps() == (3 * 2048, 3 * 2048)
+    assert ps.version >= 1 + (3 * 2048) // 300

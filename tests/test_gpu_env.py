@@ -27,7 +27,8 @@ def _heuristic(s):
     return np.clip(np.stack([hover_todo * 20 - 1, -angle_todo * 20], 1), -1, 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("n,seed,policy,steps", [(64, 1, "heuristic", 700), (300, 7, "random", 400), (1, 3, "zero", 150)])
+@pytest.mark.parametrize("n,seed,policy,steps", [(64, 1, "heuristic", 700), (300, 7, "random", 400), (1, 3, "zero", 150),
+                                                 (4096, 11, "random", 120)])   # 4096 = the env count of BASELINE config 2
 def test_env_bit_exact_vs_oracle(ddrl, n, seed, policy, steps):
     from distributed_drl_amd.env import VecLunarLander
     from oracle.env_oracle import LanderOracle

@@ -415,3 +415,31 @@ def test_fused_envelope_shapes(ddrl, obs, act, hid, batch):
     for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target")):
         assert np.abs(learner.export(which).cpu().numpy() - o64.flat(name)).max() <= 2 * 2e-2 * cfg.lr
     assert learner.opt_steps() == (2, 2)
+
+
+def test_ddqn_learner_at_the_config5_observation_width(ddrl):
+    """BASELINE config 5's learner input: flat 84x84x4 = 28 224-wide observations (algos/dqn/train.py:43-52) through the
+    Double-DQN learner — layer 1 is a K = 28 224 GEMM (streaming K loop of k_gemm).  One update vs the float64 oracle; the
+    tolerances are wider than at K = 8 because 28 224 float32 products are summed per pre-activation (~sqrt(K) * 6e-8)."""
+    from distributed_drl_amd import _lib, dqn
+    from oracle import dqn_oracle as do
+    obs, acts, hid, batch = 84 * 84 * 4, 4, (400, 300), 32
+
+    class Opt:
+        obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed = obs, acts, list(hid), 0.99, 1e-3, 0.995, batch, 2
+    learner = dqn.Learner(Opt, "learner")
+    cfg = do.Config(obs_dim=obs, n_actions=acts, hidden1=hid[0], hidden2=hid[1], batch=batch)
+    params = do.init_params(cfg, 2)
+    keys, vals = learner.get_weights()
+    for k, v in zip(keys, vals):
+        np.testing.assert_array_equal(v, params[k])
+    o64 = do.DqnOracle(cfg, params, torch.float64)
+    b = do.synthetic_batch(cfg, 10)
+    b["obs1"], b["obs2"] = b["obs1"] / 16.0, b["obs2"] / 16.0        # keep the K = 28 224 pre-activations O(1)
+    w = o64.step(b)
+    loss, q = learner.train(b, 0, return_outputs=True)
+    assert _rel(loss.item(), w["q_loss"]) <= 1e-4, (loss.item(), float(w["q_loss"]))
+    np.testing.assert_allclose(q.cpu().numpy(), w["q"].numpy(), rtol=1e-3, atol=1e-4)
+    g, g64 = learner.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
+    assert np.abs(g - g64).max() <= 1e-3 * np.abs(g64).max()
+    assert np.abs(learner.export(_lib.SAC1_MAIN).cpu().numpy() - o64.flat("main")).max() <= 2e-2 * cfg.lr
