@@ -93,10 +93,19 @@ struct GemmJobs {
 
 struct Seg {  // one tensor: dense external offset <-> internal offset
     long long ext, in, n;
-    // cols > 0: the tensor is a [n / cols][cols] kernel stored k4-interleaved (sac1_direct.h): element (k, j) lives at
-    // in + ((k / 4) * ld + j) * 4 + k % 4;  cols == 0: contiguous
-    int cols, ld;
+    // cols == 0: contiguous.  cols > 0: a [n / cols][cols] kernel (row k, column j) stored
+    //   mode 1  k4-interleaved (layer 2, sac1_direct.h): in + ((k / 4) * ld + j) * 4 + k % 4
+    //   mode 2  as layer-1 MFMA operand blocks: in + w1y_index(d0 + k, j) — d0 = 0 for the kernel, = its row count for the bias
+    int cols, ld, mode, d0;
 };
+// Layer-1 [W1 ; b1] in the order the transposed layer-1 MFMAs read it (sac1_direct.h): per block of 32 hidden units two
+// float4 per lane — input column d sits in MFMA step s of lane half h (d < 8: h = d / 4, s = d % 4; else h = (d - 8) % 2,
+// s = 4 + (d - 8) / 2), steps 0-3 in the first float4 and 4-7 in the second; within a (block, float4, half) the 32 units
+// are contiguous: one fully coalesced 512-byte segment per half-wave load.  16 floats per hidden unit, unused slots zero.
+__host__ __device__ __forceinline__ long long w1y_index(int d, int j) {
+    const int h = d < 8 ? d >> 2 : (d - 8) & 1, s = d < 8 ? d & 3 : 4 + ((d - 8) >> 1);
+    return ((((long long)(j >> 5) * 2 + (s >> 2)) * 2 + h) * 32 + (j & 31)) * 4 + (s & 3);
+}
 
 struct OptState {  // device-resident Adam bookkeeping (running beta powers like TF's beta*_power)
     float b1p_pi, b2p_pi, b1p_q, b2p_q;
@@ -727,7 +736,7 @@ __global__ void __launch_bounds__(256) k_pack(const Seg *__restrict__ segs, cons
         long long ii = i;
         if (s.cols > 0) {
             const long long k = i / s.cols, j = i - k * s.cols;
-            ii = ((k >> 2) * s.ld + j) * 4 + (k & 3);
+            ii = s.mode == 2 ? w1y_index(s.d0 + (int)k, (int)j) : ((k >> 2) * s.ld + j) * 4 + (k & 3);
         }
         if (to_internal) {
             const float v = src[s.ext + i];

@@ -572,6 +572,16 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
     g[i] = sacc;
 }
 
+// the same for the direct path's layer-1 block layout: partial [q][k][j] -> gradient element w1y_index(k, j)
+__global__ void __launch_bounds__(256) k_reduce_parts_w1y(const float *__restrict__ part, float *__restrict__ g, int nk, int N, int nparts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nk * N) return;
+    const int k = i / N, j = i - k * N;
+    float sacc = 0.f;  // tile order, as the last-arriver step of k_dg sums them
+    for (int q = 0; q < nparts; ++q) sacc += part[(long long)q * nk * N + i];
+    g[w1y_index(k, j)] = sacc;
+}
+
 // ------------------------------------------------------------------------------------------
 // K: batched get_action — one wave per observation row (Actor.get_action, actor_learner.py:195-197)
 // ------------------------------------------------------------------------------------------
@@ -632,18 +642,28 @@ static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only, bool direct
         if (!direct) { add(wslot, h1 * h2, false); add(bslot, h2, true); return; }
         in = pad4(in);
         wslot = in;
-        L.segs.push_back(Seg{ext, in, h1 * h2, (int)h2, L.Np2});
+        L.segs.push_back(Seg{ext, in, h1 * h2, (int)h2, L.Np2, 1, 0});
         in += (long long)L.Kp1 * L.Np2; ext += h1 * h2;
         bslot = in;
         L.segs.push_back(Seg{ext, in, h2});
         in += L.Np2; ext += h2;
     };
-    add(L.pi_W1, o * h1, false); add(L.pi_b1, h1, true); add_w2(L.pi_W2, L.pi_b2);
+    auto add_w1 = [&](long long &wslot, long long &bslot, long long D) {  // [W1 ; b1]
+        if (!direct) { add(wslot, D * h1, false); add(bslot, h1, true); return; }
+        in = pad4(in);
+        wslot = bslot = in;   // one block array holds the kernel rows and, as input column D, the bias
+        L.segs.push_back(Seg{ext, in, D * h1, (int)h1, 0, 2, 0});
+        ext += D * h1;
+        L.segs.push_back(Seg{ext, in, h1, (int)h1, 0, 2, (int)D});
+        ext += h1;
+        in += (long long)L.Kp1 * 16;
+    };
+    add_w1(L.pi_W1, L.pi_b1, o); add_w2(L.pi_W2, L.pi_b2);
     add(L.pi_Wmu, h2 * a, false); add(L.pi_bmu, a, true); add(L.pi_Wls, h2 * a, false); add(L.pi_bls, a, true);
     L.n_pi_int = in;
     L.n_pi = ext;
     for (int q = 0; q < 2 && !pi_only; ++q) {
-        add(L.q_W1[q], (o + a) * h1, false); add(L.q_b1[q], h1, true); add_w2(L.q_W2[q], L.q_b2[q]);
+        add_w1(L.q_W1[q], L.q_b1[q], o + a); add_w2(L.q_W2[q], L.q_b2[q]);
         add(L.q_W3[q], h2, false); add(L.q_b3[q], 1, true);
     }
     L.v_W1 = L.v_b1 = L.v_W2 = L.v_b2 = L.v_W3 = L.v_b3 = -1;
@@ -1029,8 +1049,9 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             auto head = [&](DFHead &d) {
                 d = DFHead{};
                 d.base = S; d.tiles_m = B / 32; d.tpj = (B / 32) * nt2; d.K = h1; d.Np = Np2; d.B = B; d.d0 = o;
-                d.dw2_pi = (int)(L.pi_W2 - L.pi_W1); d.dw2_q = (int)(L.q_W2[0] - L.q_W1[0]);
-                d.x_off = (int)(h->in[st][0] - S); d.x2_off = (int)(h->in[st][1] - S); d.a_off = (int)(h->in[st][2] - S);
+                d.x_off = (int)(h->in[st][0] - S);
+                d.main_off = (int)(Pm - S); d.targ_off = (int)(Pt - S); d.npi = (int)L.q_W1[0]; d.perq = (int)(L.q_W1[1] - L.q_W1[0]);
+                d.hp_off = (int)(h->hp - S);
             };
             auto args = [&](DFArgs &F, int njobs) {
                 F = DFArgs{};
@@ -1064,10 +1085,12 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             FA.job[3] = qj(Pm, 0, 3); FA.job[3].H2c4 = h->H2c4 + 1 * H2C; FA.job[3].H2r4 = h->H2r4 + 1 * H2R; FA.job[3].H1r4 = h->H1r4 + 1 * H1I;
             FA.job[3].xr4 = h->xa_r4;
             FA.job[4] = qj(Pm, 1, 4); FA.job[4].H2c4 = h->H2c4 + 2 * H2C; FA.job[4].H2r4 = h->H2r4 + 2 * H2R; FA.job[4].H1r4 = h->H1r4 + 2 * H1I;
-            HA.w1o[0] = (int)(Pm + L.pi_W1 - S); HA.w1o[1] = HA.w1o[0]; HA.w1o[2] = (int)(Pt + L.pi_W1 - S);
-            HA.w1o[3] = (int)(Pm + L.q_W1[0] - S); HA.w1o[4] = (int)(Pm + L.q_W1[1] - S);
-            HA.pack = (ns_pi) | ((ns_pi | 4) << 6) | ((ns_pi | 4) << 12) | ((ns_q | 8 | 16) << 18) | ((ns_q | 8 | 16) << 24);
             head(HB); args(FB, 3);
+            {   // pack field of a job: steps | obs2 << 2 | target << 3 | network << 4
+                auto pk = [](int ns, int x2, int targ, int net) { return ns | (x2 << 2) | (targ << 3) | (net << 4); };
+                HA.pack = pk(ns_pi, 0, 0, 0) | (pk(ns_pi, 1, 0, 0) << 6) | (pk(ns_pi, 1, 1, 0) << 12) | (pk(ns_q, 0, 0, 1) << 18) | (pk(ns_q, 0, 0, 2) << 24);
+                HB.pack = pk(ns_q, 0, 0, 1) | (pk(ns_q, 1, 1, 1) << 6) | (pk(ns_q, 1, 1, 2) << 12);
+            }
             auto from_pi = [&](DFJob &j, int pev, const float *Ppi, const float *eps, int side) {
                 j.php = h->hp + pev * HP; j.pbmu = Ppi + L.pi_bmu; j.pbls = Ppi + L.pi_bls; j.peps = eps; j.side = side;
             };
@@ -1075,9 +1098,6 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             FB.job[0].H2c4 = h->H2c4 + 3 * H2C; FB.job[0].H1r4 = h->H1r4 + 3 * H1I;
             FB.job[1] = qj(Pt, 0, 6); from_pi(FB.job[1], 2, Pt, h->in[st][7], 2);
             FB.job[2] = qj(Pt, 1, 7); from_pi(FB.job[2], 2, Pt, h->in[st][7], 0);
-            HB.w1o[0] = (int)(Pm + L.q_W1[0] - S); HB.w1o[1] = (int)(Pt + L.q_W1[0] - S); HB.w1o[2] = (int)(Pt + L.q_W1[1] - S);
-            HB.w1o[3] = (int)(h->hp - S); HB.w1o[4] = 0;
-            HB.pack = (ns_q | 16) | ((ns_q | 4 | 16) << 6) | ((ns_q | 4 | 16) << 12);
             // ---- backward launch 1: the three Q dgrads (slot 2 first: its dQ/da partials are what the next launch waits for)
             DGJobs &Q = h->dg_bq[st];
             Q = DGJobs{};
@@ -1096,7 +1116,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             };
             {
                 DGJob j = dq_job(2, 3, 0, nullptr);
-                j.wa = Pm + L.q_W1[0] + (long long)o * h1; j.da_part = h->da_part; j.nact = a;
+                j.wa = Pm + L.q_W1[0]; j.wa_d0 = o; j.da_part = h->da_part; j.nact = a;
                 dg_add(Q, j);
             }
             dg_add(Q, dq_job(0, 1, 0, h->dZ1r4));
@@ -1151,7 +1171,11 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));
             dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4, 32, a, L.pi_Wmu));
             dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4 + (long long)a * 4, 32, a, L.pi_Wls));
-            for (int q = 0; q < 2; ++q) dg_add(P, wgrad_rm(h->xa_r4, 32, o + a + 1, h->dZ1r4 + q * H1I, h->Lp1, h1, L.q_W1[q]));
+            for (int q = 0; q < 2; ++q) {
+                DGJob j = wgrad_rm(h->xa_r4, 32, o + a + 1, h->dZ1r4 + q * H1I, h->Lp1, h1, L.q_W1[q]);
+                j.type = DG_WGRAD_W1Y;   // [W1 ; b1] lives in the layer-1 block layout
+                dg_add(P, j);
+            }
         }
     }
 
@@ -1205,7 +1229,11 @@ int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream) {
     if (which == DDRL_SAC1_GRAD && h->fused_l1_wgrad && !h->grad_imported) {
         // the pi layer-1 gradient exists only as row-tile partials until Adam runs: materialise it
         const long long n = (long long)(h->cfg.obs_dim + 1) * h->cfg.hidden1;
-        k_reduce_parts<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->part, h->grad + h->L.pi_W1, n, n, h->ad.nparts);
+        if (h->fused)
+            k_reduce_parts_w1y<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->part, h->grad + h->L.pi_W1, h->cfg.obs_dim + 1,
+                                                                                               h->cfg.hidden1, h->ad.nparts);
+        else
+            k_reduce_parts<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->part, h->grad + h->L.pi_W1, n, n, h->ad.nparts);
     }
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, buf, flat_d, nullptr, 0);
     DDRL_LAUNCH_CHECK();
@@ -1343,7 +1371,14 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 h->ad.adam_blocks = (int)blocks;
                 h->ad.opt = h->opt + h->opt_cur; h->ad.opt_next = h->opt + (h->opt_cur ^ 1);
                 h->opt_cur ^= 1;
+                const int nparts = h->ad.nparts;
+                if (nparts > 0) {  // the policy's layer-1 gradient exists as row-tile partials: sum them into the (block-layout) gradient first
+                    const int nk = h->cfg.obs_dim + 1, N = h->cfg.hidden1;
+                    k_reduce_parts_w1y<<<(unsigned)((nk * N + 255) / 256), 256, 0, s>>>(h->part, h->grad + h->L.pi_W1, nk, N, nparts);
+                }
+                h->ad.nparts = 0;
                 k_adam_polyak<<<(unsigned)(blocks + (h->ad.do_sample ? 1 : 0)), 256, 0, s>>>(h->ad);
+                h->ad.nparts = nparts;
                 refresh_shadows(h, s);
                 break;
             }
@@ -1702,9 +1737,8 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
     const int nt2 = (c.hidden2 + 31) / 32;
     DFHead d{};
     d.base = h->dslab; d.tiles_m = (int)(n / 32); d.tpj = d.tiles_m * nt2; d.K = c.hidden1; d.Np = L.Np2; d.B = (int)n; d.d0 = c.obs_dim;
-    d.dw2_pi = (int)(L.pi_W2 - L.pi_W1); d.dw2_q = d.dw2_pi;
-    d.x_off = d.x2_off = d.a_off = (int)(h->obs_d - h->dslab);
-    for (int i = 0; i < 5; ++i) d.w1o[i] = (int)L.pi_W1;
+    d.x_off = (int)(h->obs_d - h->dslab);
+    d.main_off = d.targ_off = (int)L.pi_W1; d.npi = d.perq = 0; d.hp_off = (int)(h->hp_d - h->dslab);
     const int D1 = c.obs_dim + 1;
     d.pack = (D1 <= 8 ? 4 : 4 + (D1 - 8 + 1) / 2) - 4;
     DDRL_REQUIRE(d.tpj < 65536 && n < 65536, "too many rows for the packed tile arguments");

@@ -101,15 +101,16 @@ struct DFHead {
     int tpj, tiles_m;   // tiles per job, row tiles
     int K, Np;          // hidden1, padded hidden2 (row stride of the k4-interleaved W2)
     int B, d0;          // batch, obs_dim
-    int w1o[5];         // per job: [W1 ; b1] offset.  phase 1: [3] = head-partial buffer
-    int dw2_pi, dw2_q;  // W2 offset - W1 offset of a policy / Q network
-    int x_off, x2_off, a_off;
-    int pack;           // 6 bits per job: [1:0] layer-1 MFMA steps - 4 (input columns + the bias column, in pairs), [2] input is x2, [3] second input from memory, [4] Q network
+    int main_off, targ_off;  // the main / target parameter buffers
+    int npi, perq;           // inside a buffer: the policy, then q1 at npi, q2 at npi + perq
+    int hp_off;              // head-partial buffer (phase 1 reads the policy evaluations' partials)
+    int x_off;               // input set: obs1; obs2 and acts follow as consecutive 256-byte aligned items
+    int pack;                // 6 bits per job: [1:0] layer-1 MFMA steps - 4 (input columns + the bias column, in pairs), [2] input is obs2, [3] target copy, [5:4] network
 };
 
 // One 32-unit block of the K loop: layer 1 (NS MFMA steps) -> relu -> 4 * nrq layer-2 MFMA steps.
 template <int NS>
-__device__ __forceinline__ void dblock(const float (&w1)[7], const float (&xin)[7], const float4 (&bq)[4], int nrq, floatx16 &x1, floatx16 &acc) {
+__device__ __forceinline__ void dblock(const float (&w1)[8], const float (&xin)[7], const float4 (&bq)[4], int nrq, floatx16 &x1, floatx16 &acc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) x1[r] = 0.f;
 #pragma unroll
@@ -128,13 +129,14 @@ __device__ __forceinline__ void dblock(const float (&w1)[7], const float (&xin)[
 }
 
 // The operand streams of one wave for its blocks [b0, b0 + nb) of 32 hidden-1 units: W2 groups and [W1 ; b1] columns.
-// The bias row follows the kernel rows in memory, so it is simply input column D of the layer-1 MFMAs (its input is the
-// constant 1; rows beyond it meet a zero input, whatever finite values they hold) — no bias loads: a per-lane broadcast
-// load costs the fetch path as much as a tile load.  Issued first thing in the kernel from preloaded scalars only;
-// loads beyond nb re-read the last block (no branches in front of a load).
+// The bias is simply input column D of the layer-1 MFMAs (its input is the constant 1) — no bias loads: a per-lane
+// broadcast load costs the fetch path as much as a tile load.  A CU retires about one wave-load per 15 cycles WHATEVER its
+// width, so every load is a 16-byte one: the layer-1 parameters are stored in the order these MFMAs read them (two float4
+// per lane and block instead of seven dwords: 51 -> 30 loads per wave).  Issued first thing in the kernel from preloaded
+// scalars only; loads beyond nb re-read the last block (no branches in front of a load).
 struct DOps {
     float4 bq[4][4];
-    float w1[4][7];
+    float w1[4][8];
 };
 // Issue order = order of need (a wave's loads return in order): the layer-1 columns of a block, then its W2 groups.
 __device__ __forceinline__ void dops_load(DOps &o, const float *__restrict__ W1, const float *__restrict__ W2p, int K, int Np, int b0, int nb,
@@ -144,7 +146,10 @@ __device__ __forceinline__ void dops_load(DOps &o, const float *__restrict__ W1,
     for (int bi = 0; bi < 4; ++bi) {
         const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
 #pragma unroll
-        for (int s = 0; s < 7; ++s) o.w1[bi][s] = W1[(long long)d_slot(s, h) * K + u0 + l31];
+        for (int q = 0; q < 2; ++q) {  // [W1 ; b1] in the layer-1 block layout (gemm_core.h, w1y_index): two float4 per lane and block
+            const float4 v = *reinterpret_cast<const float4 *>(W1 + ((((long long)(u0 >> 5) * 2 + q) * 2 + h) * 32 + l31) * 4);
+            o.w1[bi][4 * q + 0] = v.x; o.w1[bi][4 * q + 1] = v.y; o.w1[bi][4 * q + 2] = v.z; o.w1[bi][4 * q + 3] = v.w;
+        }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) o.bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
     }
@@ -187,8 +192,8 @@ __device__ __forceinline__ void dkloop(const DOps &o, int K, int b0, int nb, int
 // the fetch phase, not the MFMAs, is what a stage waits for): one workgroup = 64 rows x 32 columns, the wave's W2 / W1
 // registers serve both row tiles.
 template <int PH, int MT, bool LOOP>
-__global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int w1o0, int w1o1, int w1o2, int w1o3, int w1o4, int dw2_pi,
-                                              int dw2_q, int x_off, int x2_off, int a_off, int pack, DFArgs a) {
+__global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int pack, int x_off, int main_off, int targ_off, int npi, int perq,
+                                              int hp_off, DFArgs a) {  // 12 dwords: what the hardware preloads into SGPRs at wave launch
     static_assert(PH == 0 || MT == 1, "phase 1 computes one policy row per lane");
     static_assert(!LOOP || (PH == 0 && MT == 1), "row-chunk loop: the actor's forward only");
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
@@ -217,10 +222,13 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     const int l31 = lane & 31, h = lane >> 5;
     const int jp = (pack >> (6 * ji)) & 63;
     const int ns = 4 + (jp & 3);
-    const bool is_q = (jp & 16) != 0;
-    const int d1 = PH == 1 ? act : ((jp & 8) ? act : 0);
-    const int w1o = ji == 0 ? w1o0 : (ji == 1 ? w1o1 : (ji == 2 ? w1o2 : (PH == 0 ? (ji == 3 ? w1o3 : w1o4) : w1o2)));
-    const float *W1 = base + w1o, *W2p = W1 + (is_q ? dw2_q : dw2_pi);
+    // this job's network: bits [5:4] of its pack field = 0 policy / 1 q1 / 2 q2, bit [3] = target copy; the three networks sit
+    // at fixed distances inside a parameter buffer (policy first, then the two Q networks)
+    const int net = (jp >> 4) & 3;
+    const int d1 = PH == 1 ? act : (net > 0 ? act : 0);  // phase 0: a Q network's second input is the stored action
+    const int w1o = ((jp & 8) ? targ_off : main_off) + (net == 0 ? 0 : npi + (net - 1) * perq);
+    const int x2_off = x_off + ((B * d0 + 63) & ~63), a_off = x2_off + ((B * d0 + 63) & ~63);  // the input set's buffers are consecutive 256-B aligned slab items
+    const float *W1 = base + w1o, *W2p = W1 + ((K + 31) & ~31) * 16;  // the k4-interleaved W2 follows the 16-floats-per-unit layer-1 block array
     const bool first_n = nt == 0;
     // this wave's 32-unit blocks: the waves at the END get the extra (possibly partial) block
     const int nblk = (K + 31) >> 5, bs = nblk >> 2, rem = nblk & 3;
@@ -244,7 +252,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (e == 0 || two) {  // block-uniform
-                const float *hp = base + w1o3 + (e == 0 ? (ji == 0 ? 0 : 2) : 1) * HPq;
+                const float *hp = base + hp_off + (e == 0 ? (ji == 0 ? 0 : 2) : 1) * HPq;
                 const float4 *p0 = reinterpret_cast<const float4 *>(hp + ((long long)(h * d1) * B + m0 + l31) * DNT);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -445,18 +453,18 @@ static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s, int mi 
     const int grid = F.njobs * tpj + ((PH == 1 && F.do_sample) ? 1 : 0);
     const int a1 = tpj | (tiles_m << 16) | (F.njobs << 28), a2 = d.K | (d.Np << 12) | (mi << 24), a3 = d.B | (d.d0 << 16) | (F.act << 24);
     if (PH == 0 && mi > 1)
-        k_dfwd<0, 1, true><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+        k_dfwd<0, 1, true><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
     else if (PH == 0 && mt == 2)
-        k_dfwd<0, 2, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+        k_dfwd<0, 2, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
     else
-        k_dfwd<PH, 1, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.w1o[0], d.w1o[1], d.w1o[2], d.w1o[3], d.w1o[4], d.dw2_pi, d.dw2_q, d.x_off, d.x2_off, d.a_off, d.pack, F);
+        k_dfwd<PH, 1, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
 }
 
 // ==========================================================================================
 // k_dg: the backward launches.  One workgroup = one 32x32 output tile of one job; the four waves split the contraction
 // in 8-deep groups; both operands are x4 images read straight into the MFMA lane layout.
 // ==========================================================================================
-enum { DG_DGRAD_Q = 0, DG_DGRAD = 1, DG_WGRAD_J4 = 2, DG_WGRAD_RM = 3, DG_ROWS_C = 4, DG_LOSS = 5 };
+enum { DG_DGRAD_Q = 0, DG_DGRAD = 1, DG_WGRAD_J4 = 2, DG_WGRAD_RM = 3, DG_ROWS_C = 4, DG_LOSS = 5, DG_WGRAD_W1Y = 6 };
 struct DGJob {
     int type;
     int M, N, K;             // output M x N, contraction length K
@@ -474,14 +482,15 @@ struct DGJob {
     int ldmask;
     float *C;                // dgrad: dZ1r4 [M/4][ldc][4] (nullable);  WGRAD_RM: gradient, row-major (row stride ldc)
     int ldc;
-    const float *wa;         // DGRAD_Q slot 2: action rows of the main q1 layer-1 kernel [act][N]
+    const float *wa;         // DGRAD_Q slot 2: the main q1 layer-1 block array (action rows = input columns wa_d0 ..)
+    int wa_d0;
     float *da_part;          // ... dQ/da partials [tiles_n][B][4]
     int nact;
     const float *part_x;     // DGRAD: fused layer-1 wgrad partials (see gemm_core.h)
     float *part;
     int part_nk, part_ldx;
     int *part_cnt;           // ... arrival counters, one per column tile (zero between launches)
-    long long part_adam_off; // ... the layer-1 kernel [part_nk][N] (bias row last) in the flat buffers
+    long long part_adam_off; // ... the layer-1 block array (w1y_index(k, j); the bias is input column part_nk - 1) in the flat buffers
     // wgrad epilogue (optimizer): offsets into the flat parameter-shaped buffers
     long long adam_off;      // J4: the W2 image;  RM: element (0, 0)
     long long bias_off;      // J4: b2
@@ -702,7 +711,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     if (has_da) {
         const int c = tid >> 5, col = n0 + (tid & 31);
         const bool ok = c < jb.nact && col < jb.N;
-        const float v = jb.wa[ok ? (long long)c * jb.N + col : 0];
+        const float v = jb.wa[ok ? w1y_index(jb.wa_d0 + c, col) : 0];
         wa_v = ok ? v : 0.f;
     }
     if (has_part) {
@@ -715,7 +724,8 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             px_v[u] = ok ? v : 0.f;
         }
     }
-    const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || type == DG_WGRAD_RM) && jb.adam_off >= 0;
+    const bool rm_like = type == DG_WGRAD_RM || type == DG_WGRAD_W1Y;  // element-addressed gradient: row-major, or the layer-1 block layout
+    const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || rm_like) && jb.adam_off >= 0;
     float al_pi = 0.f, al_q = 0.f;
     if (jobs.ad.on) {
         const float b1p_pi = jobs.ad.opt->b1p_pi, b2p_pi = jobs.ad.opt->b2p_pi, b1p_q = jobs.ad.opt->b1p_q, b2p_q = jobs.ad.opt->b2p_q;
@@ -742,14 +752,14 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             const long long bc = b_ok ? b_idx : jb.bias_off;
             bm = jobs.ad.m[bc]; bv = jobs.ad.v[bc]; bp = jobs.ad.p[bc]; bt = jobs.ad.t[bc];
         }
-    } else if (type == DG_WGRAD_RM) {
+    } else if (rm_like) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o = tid + 256 * q;
             const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
             okv[q] = gi < jb.M && gj < jb.N;
             if (do_adam) {
-                const long long idx = okv[q] ? jb.adam_off + (long long)gi * jb.ldc + gj : jb.adam_off;
+                const long long idx = !okv[q] ? jb.adam_off : jb.adam_off + (type == DG_WGRAD_W1Y ? w1y_index(gi, gj) : (long long)gi * jb.ldc + gj);
                 am[q] = jobs.ad.m[idx]; av[q] = jobs.ad.v[idx]; ap[q] = jobs.ad.p[idx]; at[q] = jobs.ad.t[idx];
             }
         }
@@ -883,7 +893,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                         for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
                             const int k = idx >> 5, col = idx & 31;
                             if (n0 + col < jb.N) {
-                                const long long e = (long long)k * jb.N + n0 + col, off = jb.part_adam_off + e;
+                                const long long e = (long long)k * jb.N + n0 + col, off = jb.part_adam_off + w1y_index(k, n0 + col);
                                 float am_ = jobs.ad.m[off], av_ = jobs.ad.v[off], ap_ = jobs.ad.p[off], at_ = jobs.ad.t[off];
                                 float g = 0.f;
                                 for (int q0 = 0; q0 < tiles_m; q0 += 8) {  // 8 partials per round trip, summed in tile order (as k_adam_polyak)
@@ -956,7 +966,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         DST(kid, 5); DRT(kid, 15);
         return;
     }
-    // DG_WGRAD_RM: row-major gradient (layer-1 kernels with their bias row, head kernels)
+    // DG_WGRAD_RM / DG_WGRAD_W1Y: element-addressed gradient (head kernels row-major; layer-1 kernels with their bias in the block layout)
     {
         const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
 #pragma unroll
@@ -965,7 +975,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             const int row = o >> 5, col = o & 31;
             const float gv = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
             if (okv[q]) {
-                const long long idx = jb.adam_off + (long long)(m0 + row) * jb.ldc + n0 + col;
+                const long long idx = jb.adam_off + (type == DG_WGRAD_W1Y ? w1y_index(m0 + row, n0 + col) : (long long)(m0 + row) * jb.ldc + n0 + col);
                 jobs.ad.g[idx] = gv;
                 if (do_adam) {
                     const float al = idx < jobs.ad.n_pi ? al_pi : al_q;
