@@ -237,6 +237,13 @@ def stage_measurements(args, opt, rb, roll, d):
     out["sample"] = {"batch": B, "us": t * 1e6, "bytes_per_batch": B * 164, "GBps": B * 164 / t / 1e9,
                      "frac_of_hbm_peak": B * 164 / t / 1e9 / PEAK_HBM_GBPS,
                      "note": "stand-alone launch (latency-bound); inside the learner loop the sampler rides in a forward launch"}
+    K = 1024
+    blk = torch.empty(K * B * 20, dtype=torch.float32, device="cuda")
+    t = timed(lambda: rb.sample_many(B, K, blk), 10)
+    out["sample_block"] = {"batch": B, "batches": K, "ms": t * 1e3, "bytes": K * B * 164, "GBps": K * B * 164 / t / 1e9,
+                           "frac_of_hbm_peak": K * B * 164 / t / 1e9 / PEAK_HBM_GBPS,
+                           "what": "the block of batches a shard owner draws for one step of a remote learner (configs 3/4): "
+                                   "one sequential MT19937 index draw + one gather sweep"}
     if args.cfg5_capacity > 0:
         try:
             obs_dim, B5, cap = 84 * 84 * 4, 512, int(args.cfg5_capacity)
@@ -319,7 +326,7 @@ def main():
             fill_replay(r, shard_cap, 1234 + rank)
             return r
         run = partition.PartitionedRun(opt, roles, make_replay, lambda r_: RolloutDevice(None, r_, opt, worker_index=rank),
-                                       lambda: Learner(opt, job="learner", index=rank), seed=opt.seed)
+                                       lambda: Learner(opt, job="learner", index=rank), seed=opt.seed, updates_per_graph=args.updates_per_graph)
 
         def one_step():
             run.step(updates_per_step)
@@ -377,7 +384,9 @@ def main():
         upd_s = dt / (args.steps * updates_per_step)
         roofline.update({"achieved": gf / upd_s / 1e12, "frac": gf / upd_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "avg_launch_us": upd_s / launches_per_update * 1e6,
-                         "note": "from the timed region (eager per-update stepping on the learner ranks, batch transfer included)"})
+                         "note": "from the timed region of learner rank 0: env step + block transfers + the learner loop (%s)" %
+                                 ("graph-captured, the sampler following the step's feed plan" if len(roles.learners) == 1 else
+                                  "eager: gradients, RCCL all-reduce, Adam per update")})
     traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -401,7 +410,7 @@ def main():
                                "(%d shard(s)), batch=%d, hidden (400,300), %d updates per learner rank per step, push every 300 updates" %
                                (num_envs, args.capacity, len(roles.shard_owner), args.batch, updates_per_step),
                    "num_envs": num_envs, "replay_capacity": args.capacity, "batch": args.batch,
-                   "updates_per_step": updates_per_step, "updates_per_graph": args.updates_per_graph if world == 1 else 0,
+                   "updates_per_step": updates_per_step, "updates_per_graph": args.updates_per_graph if len(roles.learners) == 1 else 0,
                    "env_steps_per_sample": env_steps / max(1, updates), "learner_ranks": roles.learners, "rollout_ranks": roles.rollouts,
                    "backend": (torch.distributed.get_backend() if world > 1 else None), "devices": ndev,
                    "parallelism": roles.describe()},

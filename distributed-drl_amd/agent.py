@@ -256,6 +256,16 @@ class Learner(_Net):
         _lib.check(self._lib.ddrl_sac1_fill_noise(self._h, self._noise_seed, _lib.stream_ptr()))
         return keep, [_lib.dptr(t) for t in keep] + self._in0[5:8] + [None, None, None, None]
 
+    def input_batch(self, which=0):
+        """Views of input set `which` (0/1) of the learner — where the device loop's sampler gathers the batch of every
+        other update (ddrl_sac1_input_buffers): obs1, obs2, acts, rews, done."""
+        from .replay import _view
+        bufs = (ctypes.c_void_p * 8)()
+        _lib.check(self._lib.ddrl_sac1_input_buffers(self._h, int(which), bufs))
+        B, o, a = self.cfg.batch, self.cfg.obs_dim, self.cfg.act_dim
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return {k: _view(bufs[i], s, dev) for i, (k, s) in enumerate((("obs1", (B, o)), ("obs2", (B, o)), ("acts", (B, a)), ("rews", (B,)), ("done", (B,))))}
+
     def train_device(self, batch):
         """train() for a device-resident batch with in-kernel noise (what the graph loop does per update, issued eagerly)."""
         keep, ptrs = self._device_args(batch)

@@ -184,6 +184,23 @@ __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, co
     }
 }
 
+// Gather for many SMALL rows (the block a shard owner draws for a whole step: 2^18 rows of 32 B): one lane per 16-B
+// (or 4-B) element, all rows of an array in one grid-stride sweep — k_gather's workgroup-per-row would be launch-bound.
+__global__ void __launch_bounds__(256) k_gather_small(RingPtrs ring, BatchPtrs out, const long long *__restrict__ idx, int B) {
+    const int j = blockIdx.y, width = ring.w[j];
+    const bool v4 = (width & 3) == 0;
+    const unsigned wv = v4 ? width >> 2 : width, total = (unsigned)B * wv;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned b = e / wv, c = e - b * wv;
+        const long long so = idx[b] * wv + c;
+        if (v4) reinterpret_cast<float4 *>(out.a[j])[e] = reinterpret_cast<const float4 *>(ring.a[j])[so];
+        else out.a[j][e] = ring.a[j][so];
+    }
+}
+
+__global__ void k_set_feed(RingState *st, Feed f) { st->feed = f; }
+__global__ void k_add_samples(RingState *st, long long inc) { st->sample_times += inc; }
+
 __global__ void k_set_counts(RingState *st, long long ptr, long long size, long long steps, long long samples) {
     st->ptr = ptr; st->size = size; st->steps = steps; st->sample_times = samples;
     st->done_counter = 0; st->error = 0;
@@ -204,6 +221,7 @@ struct ddrl_replay {
     int *rank_buf;       // device scratch of the masked store
     long long rank_cap;
     uint32_t flags;
+    bool feed_on;        // a feed plan is attached (ddrl_replay_set_feed): the sampler may be handed remote batches
 };
 
 static int refresh_counts(ddrl_replay *h, hipStream_t s) {
@@ -223,7 +241,7 @@ static long long row_floats(const ddrl_replay *h) {
 }
 bool ddrl_replay_can_fuse(ddrl_replay_t *h, int64_t batch) {
     const long long bytes = batch * row_floats(h) * (long long)sizeof(float);
-    return batch <= MAX_FUSED_BATCH && bytes <= MAX_FUSED_BYTES && h->h_size > 0;
+    return batch <= MAX_FUSED_BATCH && bytes <= MAX_FUSED_BYTES && (h->h_size > 0 || h->feed_on);
 }
 void ddrl_replay_note_sample(ddrl_replay_t *h) { h->h_samples += h->ring.samples_inc; }
 void ddrl_replay_note_store(ddrl_replay_t *h, long long n) {  // host mirror bookkeeping for n stores issued by another kernel (ddrl_rollout_step)
@@ -363,6 +381,15 @@ int ddrl_replay_store(ddrl_replay_t *h, const float *obs_d, const float *act_d, 
 }
 
 static int launch_gather(ddrl_replay *h, const long long *idx, int64_t B, BatchPtrs out, hipStream_t s) {
+    int widest = 1;
+    for (int j = 0; j < h->ring.n_arr; ++j) widest = h->ring.w[j] > widest ? h->ring.w[j] : widest;
+    if (widest <= 64 && B >= 4096) {  // many small rows
+        long long blocks = (B * ((widest & 3) == 0 ? widest / 4 : widest) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        k_gather_small<<<dim3((unsigned)blocks, (unsigned)h->ring.n_arr), 256, 0, s>>>(h->ring, out, idx, (int)B);
+        DDRL_LAUNCH_CHECK();
+        return DDRL_OK;
+    }
     k_gather<<<dim3((unsigned)B, (unsigned)h->ring.n_arr), 256, 0, s>>>(h->ring, out, idx, (int)B);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
@@ -378,7 +405,9 @@ int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, 
     }
     ddrl::DeviceGuard g(h->device);
     hipStream_t s = ddrl::as_stream(stream);
-    if (h->h_size <= 0 || h->h_dirty) {
+    if (h->feed_on) {
+        DDRL_REQUIRE(ddrl_replay_can_fuse(h, batch), "a feed plan is attached: the batch must fit the one-workgroup sampler");
+    } else if (h->h_size <= 0 || h->h_dirty) {
         // the mirror may lag behind graph replays / masked stores: ask the device before reporting empty
         int rc = refresh_counts(h, s);
         if (rc != DDRL_OK) return rc;
@@ -410,6 +439,42 @@ int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *ob
     DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");
     float *out[5] = {obs1_d, obs2_d, acts_d, rews_d, done_d};
     return ddrl_replay_sample_ex(h, batch, out, idx_d, stream);
+}
+
+int ddrl_replay_sample_many(ddrl_replay_t *h, int64_t batch, int64_t count, float *const *out_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr && out_h != nullptr, "NULL pointer");
+    DDRL_REQUIRE(batch > 0 && count > 0 && batch * count <= (1 << 24), "batch, count must be positive with batch * count <= 2^24");
+    DDRL_REQUIRE(!h->feed_on, "a feed plan is attached to this ring");
+    // `count` consecutive sample_batch(batch) calls consume the index stream exactly like one draw of batch * count
+    // (the ring size cannot change in between: nothing else is ordered between them on this stream)
+    const int rc = ddrl_replay_sample_ex(h, batch * count, out_h, nullptr, stream);
+    if (rc != DDRL_OK || count == 1) return rc;
+    ddrl::DeviceGuard g(h->device);
+    k_add_samples<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->state, (count - 1) * h->ring.samples_inc);
+    DDRL_LAUNCH_CHECK();
+    h->h_samples += (count - 1) * h->ring.samples_inc;
+    return DDRL_OK;
+}
+
+int ddrl_replay_set_feed(ddrl_replay_t *h, const int32_t *plan_d, int32_t plan_len, int32_t batch, int32_t n_regions,
+                         const float *const *region_base_h, const int32_t *region_count_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(plan_d == nullptr || (plan_len >= 0 && batch > 0 && n_regions >= 0 && n_regions <= MAX_FEED), "bad plan length / batch / region count");
+    DDRL_REQUIRE(plan_d == nullptr || n_regions == 0 || (region_base_h && region_count_h), "NULL region table");
+    Feed f{};
+    if (plan_d) {
+        f.plan = plan_d; f.pos = 0; f.len = plan_len; f.batch = batch; f.n_regions = n_regions;
+        for (int r = 0; r < n_regions; ++r) {
+            DDRL_REQUIRE(region_count_h[r] >= 0 && region_count_h[r] < (1 << 24) && (region_count_h[r] == 0 || region_base_h[r]), "bad region");
+            f.base[r] = region_base_h[r]; f.count[r] = region_count_h[r];
+        }
+    }
+    ddrl::DeviceGuard g(h->device);
+    k_set_feed<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->state, f);
+    DDRL_LAUNCH_CHECK();
+    h->feed_on = plan_d != nullptr;
+    h->h_dirty = true;  // fed updates do not count as local samples: the mirror re-reads the device counters
+    return DDRL_OK;
 }
 
 int ddrl_replay_gather_ex(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *const *out_h, void *stream) {

@@ -12,6 +12,20 @@ constexpr int SAMPLE_THREADS = 256;
 constexpr int MAX_FUSED_BATCH = 4096;          // idx staged in LDS for the fused sample+gather
 constexpr long long MAX_FUSED_BYTES = 1 << 18;  // fuse the gather when the whole batch is <= 256 KiB
 
+constexpr int MAX_FEED = 8;
+
+// Batches drawn on OTHER ranks' shards (partition.py): the learner's sampler follows a per-update plan held in
+// device memory — entry -1 = draw from the local ring, entry (r << 24 | i) = take batch i of region r, a block of
+// `count[r]` batches [obs1 | obs2 | acts | rews | done] (each array [count*B, w]) that shard owner r drew with its own
+// index stream and sent in one message.  Lives in the ring state so that a captured graph follows a new plan
+// without re-capture.
+struct Feed {
+    const int *plan;
+    int pos, len, batch, n_regions;
+    const float *base[MAX_FEED];
+    int count[MAX_FEED];
+};
+
 struct RingState {
     long long ptr, size, steps, sample_times;
     unsigned int done_counter;  // last-block-done ticket for the store kernel
@@ -19,6 +33,7 @@ struct RingState {
     int mt_pos;
     int pad;
     uint32_t mt_key[MT_N];
+    Feed feed;                  // after the MT state: refresh_counts copies the head of the struct only
 };
 
 constexpr int MAX_ARRAYS = 6;
@@ -103,6 +118,35 @@ __device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring
     __shared__ int s_consumed;
     __shared__ unsigned s_idx[MAX_FUSED_BATCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (fuse_gather && st->feed.plan != nullptr) {
+        const int pos = st->feed.pos;
+        const int p = pos < st->feed.len ? st->feed.plan[pos] : -1;
+        __syncthreads();  // every lane has read the position
+        if (tid == 0) st->feed.pos = pos + 1;
+        if (p >= 0) {     // a batch another rank drew: copy it, consume no local draw
+            const int r = p >> 24, i = p & 0xffffff;
+            if (B != st->feed.batch || r >= st->feed.n_regions || i >= st->feed.count[r]) {
+                if (tid == 0) st->error = DDRL_ERR_BAD_ARG;
+                return;
+            }
+            const float *src = st->feed.base[r];
+            const long long rows = (long long)st->feed.count[r] * B;
+#pragma unroll
+            for (int j = 0; j < MAX_ARRAYS; ++j)
+                if (j < ring.n_arr) {
+                    const int w = ring.w[j], n = B * w;
+                    const float *sj = src + (long long)i * n;
+                    if ((n & 3) == 0 && ((rows * w) & 3) == 0 && ((((unsigned long long)out.a[j]) | ((unsigned long long)src)) & 15ull) == 0) {
+                        for (int e = tid; e < (n >> 2); e += SAMPLE_THREADS)
+                            reinterpret_cast<float4 *>(out.a[j])[e] = reinterpret_cast<const float4 *>(sj)[e];
+                    } else {
+                        for (int e = tid; e < n; e += SAMPLE_THREADS) out.a[j][e] = sj[e];
+                    }
+                    src += rows * w;
+                }
+            return;
+        }
+    }
     const long long size = st->size;
     if (size <= 0) {  // reference: ValueError("high <= 0"); the host wrapper reports it
         if (tid == 0) st->error = DDRL_ERR_EMPTY_BUFFER;

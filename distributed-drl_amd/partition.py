@@ -9,9 +9,12 @@ What the reference does with Ray actors:
 
 Here:
   config 3 (2 ranks)  learner on rank 0; BOTH ranks run envs and own a shard (local store, no collective on
-                      store); per update the learner picks a shard on its seeded stream; a remote owner draws the
-                      batch from its device ring and sends the packed 20 KB to the learner (point-to-point
-                      RCCL send/recv over xGMI, prefetched one update ahead); parameters = one RCCL broadcast.
+                      store); per update the learner picks a shard on its seeded stream; the batches a remote owner
+                      owes for one step are drawn from its device ring in one launch sequence
+                      (ddrl_replay_sample_many) and sent as ONE point-to-point message (RCCL send/recv over xGMI,
+                      20 KB per batch); the learner's sampler follows the step's plan from device memory (local
+                      draw or "batch i of owner r's block", ddrl_replay_set_feed), so the graph-captured learner
+                      loop of config 2 runs unchanged; parameters = one RCCL broadcast.
   config 4 (8 ranks)  ranks 0-1 learners (synchronous data parallel: one all-reduce of the flat gradient per
                       update between them — a documented NEW semantics, the reference's multi-learner is
                       unsynchronised last-writer-wins, example/dsac.py:59-62,233), ranks 2-7 rollout ranks with
@@ -19,8 +22,11 @@ Here:
   other sizes         world // 4 learners (at least one); world 1 = config 2 (everything on the one rank).
 
 Every rank derives the whole schedule (which learner draws from which shard at which update) from seeded
-streams it holds itself, so no request message is needed: an owner simply issues its sends in schedule order and
-a learner its receives — pairwise message order is the match.  Works on any torch.distributed backend; with
+streams it holds itself, so no request message is needed: per step an owner sends each learner one block and a
+learner posts one receive per owner.  The rings do not change between a step's env step and its updates, so
+drawing a step's batches ahead of the updates hands out exactly the batches per-update requests would; a shard
+serving two learners serves learner 0's batches of the step first (the reference's order is whatever order the
+Ray calls arrive in).  Works on any torch.distributed backend; with
 "gloo" (functional checks with several ranks on ONE GPU, DDRL_DIST_BACKEND=gloo) device tensors are staged through
 the host.
 """
@@ -61,7 +67,7 @@ class Roles:
     def describe(self):
         if self.world == 1:
             return "single GPU: envs + replay + learner"
-        return "%d learner rank(s) %s%s, %d rollout rank(s) %s with one replay shard each; batch = owner gather + P2P send, params = RCCL broadcast" % (
+        return "%d learner rank(s) %s%s, %d rollout rank(s) %s with one replay shard each; batches = owner gather, one P2P block per (owner, learner) and step, params = RCCL broadcast" % (
             len(self.learners), self.learners, " (gradient all-reduce)" if len(self.learners) > 1 else "",
             len(self.rollouts), self.rollouts)
 
@@ -132,15 +138,36 @@ class Schedule:
         return [(l, self.roles.shard_owner[p.next()]) for l, p in zip(self.roles.learners, self.pickers)]
 
 
+class _Loop:
+    """ddrl_loop over (learner, ring): n updates of sample -> train per call, graph-captured in chunks."""
+
+    def __init__(self, learner, rb, per_graph):
+        import ctypes
+        from . import _lib
+        self._lib, self._libmod = _lib.load(), _lib
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.ddrl_loop_create(ctypes.byref(h), learner._h, rb._h, int(per_graph), int(learner._noise_seed)))
+        self._h, self._keep = h, (learner, rb)
+
+    def run(self, n):
+        self._libmod.check(self._lib.ddrl_loop_run(self._h, int(n), self._libmod.stream_ptr()))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ddrl_loop_destroy(h)
+
+
 class PartitionedRun:
     """One rank's share of the partitioned actor-learner loop.
 
-    step(n_updates): a rollout rank steps its envs once and stores locally; then, update by update, shard owners
-    draw + send the batches the schedule assigns to them and learner ranks receive (one update ahead), train, and —
-    with several learners — all-reduce the flat gradient; every `push_freq` updates learner 0 broadcasts the flat
-    parameter vector and the rollout ranks adopt it."""
+    step(n_updates): a rollout rank steps its envs once and stores locally; shard owners draw the blocks of batches
+    the schedule assigns to them for this step and send one message per learner; a learner rank receives its
+    blocks, hands the step's plan to its sampler and runs the n updates — the graph-captured loop when it is the
+    only learner, eager compute / all-reduce / apply per update with several; every `push_freq` updates learner 0
+    broadcasts the flat parameter vector and the rollout ranks adopt it."""
 
-    def __init__(self, opt, roles, make_replay, make_rollout, make_learner, seed=0, push_freq=None, device=None):
+    def __init__(self, opt, roles, make_replay, make_rollout, make_learner, seed=0, push_freq=None, device=None, updates_per_graph=16):
         self.opt, self.roles = opt, roles
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.B = int(opt.batch_size)
@@ -158,11 +185,22 @@ class PartitionedRun:
         if len(roles.learners) > 1 and dist.is_initialized():
             self.lgroup = dist.new_group(ranks=roles.learners)   # collective: every rank calls it
         self.cnt = 0                                  # updates done (per learner)
-        self.send_bufs = [torch.empty(self.nf, dtype=torch.float32, device=self.device) for _ in range(4)] if self.rb is not None else []
-        self.recv_bufs = [torch.empty(self.nf, dtype=torch.float32, device=self.device) for _ in range(2)] if self.learner is not None else []
+        self.feed_ring, self.loop, self.batch_buf = None, None, None
+        if self.learner is not None:
+            # the ring whose sampler the learner drives: its own shard, or (dedicated learner rank) an empty one-row ring
+            # that only ever follows the feed plan
+            from .replay import ReplayBufferSAC1
+            self.feed_ring = self.rb if self.rb is not None else ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 1)
+            self.batch_buf = torch.empty(self.nf, dtype=torch.float32, device=self.device)
+            if self.lgroup is None:
+                self.loop = _Loop(self.learner, self.feed_ring, updates_per_graph)
+        self.send_bufs, self.regions = {}, {}
+        self.plan_d, self.plan_h = None, None
         self.sends = []
-        self.stats = {"local_batches": 0, "remote_batches": 0, "sent_batches": 0, "pushes": 0}
-        self.last_batch = None
+        self.stats = {"local_batches": 0, "remote_batches": 0, "sent_batches": 0, "sent_blocks": 0, "pushes": 0}
+        self.last_plan = None
+        import os
+        self.timing = os.environ.get("DDRL_PART_TIMING", "0") == "1"
         if self.bcast is not None:
             self._push()                              # initial weights: every rank starts from learner 0's vector
 
@@ -179,68 +217,106 @@ class PartitionedRun:
             n_pi = self.roll.actor.n_params
             self.roll.actor.set_weights_flat(self.bcast.buf[:n_pi])
 
-    # -- one update's traffic -------------------------------------------------------------------
-    def _serve(self, plan):
-        """Owner side: draw and send the batches this rank owes for one update."""
-        me = self.roles.rank
-        for l, owner in plan:
-            if owner == me and l != me:
-                buf = self.send_bufs[self.stats["sent_batches"] % len(self.send_bufs)]
-                if len(self.sends) >= len(self.send_bufs):
-                    self.sends.pop(0).wait()          # the buffer about to be reused has left
-                sample_packed(self.rb, self.B, buf)
-                self.sends.append(_send(buf, l))
-                self.stats["sent_batches"] += 1
+    # -- one step's traffic ---------------------------------------------------------------------
+    def _buf(self, table, key, batches):
+        t = table.get(key)
+        if t is None or t.numel() < batches * self.nf:
+            t = table[key] = torch.empty(max(batches, 64) * self.nf, dtype=torch.float32, device=self.device)
+        return t
 
-    def _post(self, plan, slot):
-        """Learner side: start receiving (or draw locally) the batch of one update into recv slot `slot`."""
+    def _serve(self, plans):
+        """Owner side: draw and send, learner by learner, the block of batches this rank owes for the step."""
         me = self.roles.rank
-        for l, owner in plan:
-            if l != me:
+        for li, l in enumerate(self.roles.learners):
+            if l == me:
                 continue
-            if owner == me:
-                sample_packed(self.rb, self.B, self.recv_bufs[slot])
-                self.stats["local_batches"] += 1
-                return None
-            self.stats["remote_batches"] += 1
-            return _Recv(self.recv_bufs[slot], owner)
-        return None
+            k = sum(1 for p in plans if p[li][1] == me)
+            if k == 0:
+                continue
+            blk = self.rb.sample_many(self.B, k, self._buf(self.send_bufs, l, k))
+            self.sends.append(_send(blk, l))
+            self.stats["sent_batches"] += k
+            self.stats["sent_blocks"] += 1
 
-    def _train(self, flat):
-        batch = batch_views(flat, self.opt.obs_dim, self.opt.act_dim, self.B)
-        self.last_batch = batch
-        if self.lgroup is None:
-            self.learner.train_device(batch)
-        else:
+    def _receive(self, plans):
+        """Learner side: post one receive per remote owner, lay the step's plan down for the sampler."""
+        me, li = self.roles.rank, self.roles.learners.index(self.roles.rank)
+        owners = [p[li][1] for p in plans]
+        remote = sorted(set(o for o in owners if o != me))
+        count = {o: owners.count(o) for o in remote}
+        recvs, regions = [], []
+        for o in remote:
+            buf = self._buf(self.regions, o, count[o])[: count[o] * self.nf]
+            recvs.append(_Recv(buf, o))
+            regions.append((buf, count[o]))
+        nxt = {o: 0 for o in remote}
+        plan = np.empty(len(owners), dtype=np.int32)
+        for u, o in enumerate(owners):
+            if o == me:
+                plan[u] = -1
+            else:
+                plan[u] = (remote.index(o) << 24) | nxt[o]
+                nxt[o] += 1
+        n = len(owners)
+        if self.plan_d is None or self.plan_d.numel() < n:
+            self.plan_d = torch.empty(max(n, 64), dtype=torch.int32, device=self.device)
+            self.plan_h = torch.empty(max(n, 64), dtype=torch.int32).pin_memory()
+        self.plan_h[:n].copy_(torch.from_numpy(plan))
+        self.plan_d[:n].copy_(self.plan_h[:n], non_blocking=True)
+        self.feed_ring.set_feed(self.plan_d[:n], self.B, regions)
+        for r in recvs:
+            r.wait()
+        self.stats["local_batches"] += owners.count(me)
+        self.stats["remote_batches"] += n - owners.count(me)
+        self.last_plan = plan
+
+    def _train_eager(self, n):
+        """Several learners: per update, the plan's batch -> gradients -> all-reduce (mean) -> Adam + polyak."""
+        for _ in range(n):
+            batch = sample_packed(self.feed_ring, self.B, self.batch_buf)
             g = self.learner.compute_gradients_device(batch)
             comm.allreduce_mean_(g, group=self.lgroup)
             self.learner.apply_gradients(g)
 
+    def _tick(self, key, t0):
+        """DDRL_PART_TIMING=1: wall time per phase (device drained at every phase boundary — diagnosis only)."""
+        if not self.timing:
+            return 0.0
+        import time
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if key is not None:
+            self.stats[key] = self.stats.get(key, 0.0) + (t1 - t0)
+        return t1
+
     def step(self, n_updates):
+        t = self._tick(None, 0.0)
         if self.roll is not None:
             self.roll.step()
+        t = self._tick("s_env", t)
         n = int(n_updates)
-        if self.roles.world == 1:
-            # config 2: everything local — the graph-captured loop is the faster way to run this (workers.TrainDevice)
-            for _ in range(n):
-                sample_packed(self.rb, self.B, self.recv_bufs[0])
-                self._train(self.recv_bufs[0])
-                self.cnt += 1
-            return
         plans = [self.schedule.next() for _ in range(n)]
-        pending = self._post(plans[0], 0) if self.learner is not None else None
-        for u in range(n):
-            if self.rb is not None:
-                self._serve(plans[u])
+        if self.rb is not None:
+            self._serve(plans)
+        t = self._tick("s_serve", t)
+        if self.learner is not None:
+            self._receive(plans)
+        t = self._tick("s_receive", t)
+        left = n
+        while left > 0:
+            seg = min(left, self.push_freq - self.cnt % self.push_freq)   # updates until the next push
             if self.learner is not None:
-                nxt = self._post(plans[u + 1], (u + 1) & 1) if u + 1 < n else None   # one update ahead
-                if pending is not None:
-                    pending.wait()
-                self._train(self.recv_bufs[u & 1])
-                pending = nxt
-            self.cnt += 1
-            if self.cnt % self.push_freq == 0:
+                if self.loop is not None:
+                    self.loop.run(seg)
+                else:
+                    self._train_eager(seg)
+            t = self._tick("s_updates", t)
+            self.cnt += seg
+            left -= seg
+            if self.cnt % self.push_freq == 0 and self.bcast is not None:
                 self._push()
+                t = self._tick("s_push", t)
         for w in self.sends:
             w.wait()
         self.sends = []
+        self._tick("s_drain", t)

@@ -96,6 +96,35 @@ class ReplayBuffer:
                                                 _lib.dptr(out["rews"]), _lib.dptr(out["done"]), _lib.stream_ptr()))
         return out
 
+    def sample_many(self, batch_size, count, flat):
+        """`count` consecutive sample_batch(batch_size) draws gathered into the packed float32 device buffer `flat`
+        as one block [obs1 | obs2 | acts | rews | done], each array [count * B, w] (ddrl_replay_sample_many): what a
+        shard owner sends a remote learner for one step (partition.py)."""
+        B, K = int(batch_size), int(count)
+        ptrs, off = (ctypes.c_void_p * 5)(), 0
+        for j, w in enumerate((self.obs_dim, self.obs_dim, self.act_dim, 1, 1)):
+            ptrs[j] = flat.data_ptr() + 4 * off
+            off += K * B * w
+        assert flat.numel() >= off and flat.dtype == torch.float32 and flat.is_cuda and flat.is_contiguous()
+        _lib.check(self._lib.ddrl_replay_sample_many(self._h, B, K, ptrs, _lib.stream_ptr()))
+        return flat[:off]
+
+    def set_feed(self, plan, batch_size, regions):
+        """Attach a per-update feed plan (int32 device tensor: -1 = local draw, r << 24 | i = batch i of regions[r]) to
+        this ring's sampler; regions = [(packed block tensor, batches in it)].  plan=None detaches."""
+        if plan is None:
+            _lib.check(self._lib.ddrl_replay_set_feed(self._h, None, 0, 0, 0, None, None, _lib.stream_ptr()))
+            self._feed_keep = None
+            return
+        assert plan.dtype == torch.int32 and plan.is_cuda and plan.is_contiguous()
+        n = len(regions)
+        base, cnt = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_int32 * max(n, 1))()
+        for r, (t, k) in enumerate(regions):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+            base[r], cnt[r] = t.data_ptr(), int(k)
+        _lib.check(self._lib.ddrl_replay_set_feed(self._h, _lib.dptr(plan), int(plan.numel()), int(batch_size), n, base, cnt, _lib.stream_ptr()))
+        self._feed_keep = (plan, [t for t, _ in regions])   # the kernels read these until the next set_feed
+
     def get_counts(self):
         """example/dsac.py:47-48: number of store() calls so far."""
         return self._counts()[2]

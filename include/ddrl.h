@@ -109,6 +109,20 @@ int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n,
 int ddrl_replay_store_masked_ex(ddrl_replay_t *h, const float *const *src_h, const uint8_t *mask_d, int64_t n, void *stream);
 int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, int64_t *idx_d, void *stream);
 int ddrl_replay_gather_ex(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *const *out_h, void *stream);
+/* `count` consecutive sample_batch(batch) calls in one launch sequence: out_h[j] is [count*batch, w_j], batch i = rows
+ * [i*batch, (i+1)*batch).  Consumes the index stream exactly like `count` separate calls and advances sample_times
+ * by count * samples_inc.  A shard owner draws the block of batches it owes a remote learner for one step with it
+ * (the reference learner's `replay_buffer[i].sample_batch.remote()`, algos/sac1/sac_ray.py:137-141, batched). */
+int ddrl_replay_sample_many(ddrl_replay_t *h, int64_t batch, int64_t count, float *const *out_h, void *stream);
+/* Attach a feed plan to the ring's sampler (learner side of the sharded replay): the next plan_len calls of the
+ * small-batch sampler (ddrl_replay_sample* with `batch`, alone or inside the learner's launches / a captured loop)
+ * follow plan_d[0..plan_len) (DEVICE int32): -1 = draw from this ring as usual; (r << 24 | i) = copy batch i of
+ * region r instead, consuming no local draw.  Region r is a block that ddrl_replay_sample_many produced on the
+ * owning rank: region_base_h[r] (device) -> [obs1 | obs2 | ...] with each array [region_count_h[r]*batch, w_j].
+ * The plan position restarts at 0 on every call; plan_d and the regions must stay valid while attached.
+ * plan_d == NULL detaches.  n_regions <= 8.  A plan entry out of range sets the ring's sticky error. */
+int ddrl_replay_set_feed(ddrl_replay_t *h, const int32_t *plan_d, int32_t plan_len, int32_t batch, int32_t n_regions,
+                         const float *const *region_base_h, const int32_t *region_count_h, void *stream);
 int ddrl_replay_buffers_ex(ddrl_replay_t *h, float **arrays_h, int32_t *widths_h, int32_t *n_arrays_h);
 
 /* Raw ring pointers (device) for checkpointing / inspection (algos/dqn/train.py:82-90 saves

@@ -270,3 +270,74 @@ def test_nstep_window_buffer_golden(ddrl, golden_dir):
         assert torch.equal(s1[k], s2[k]), k
     assert s1["obs"].shape == (16, 9, 8) and s1["acts"].shape == (16, 8, 2)
     assert b1.get_counts() == (1, 70, 50)
+
+
+def _filled(ddrl, seed, n=3000, cap=4096, obs=8, act=2, data_seed=0):
+    rs = np.random.RandomState(data_seed)
+    rb = ddrl.ReplayBufferSAC1(obs, act, cap, seed=seed)
+    rb.store_batch(*(torch.from_numpy(x).cuda() for x in (
+        rs.randn(n, obs).astype(np.float32), rs.uniform(-1, 1, (n, act)).astype(np.float32), np.arange(n, dtype=np.float32),
+        rs.randn(n, obs).astype(np.float32), (rs.rand(n) < 0.1).astype(np.float32))))
+    return rb
+
+
+def _packed(b):
+    return np.concatenate([b[k].reshape(-1).cpu().numpy() for k in ("obs1", "obs2", "acts", "rews", "done")])
+
+
+@pytest.mark.parametrize("B,K", [(256, 9), (100, 5), (33, 4)])
+def test_sample_many_equals_consecutive_sample_batches(ddrl, B, K):
+    """The block a shard owner sends for one step (ddrl_replay_sample_many) = K consecutive sample_batch(B) calls: same
+    indices (NumPy's stream), same rows, same counters, same sampler state afterwards."""
+    a, b = _filled(ddrl, 42), _filled(ddrl, 42)
+    nf = B * (2 * 8 + 2 + 2)
+    flat = torch.empty(K * nf, dtype=torch.float32, device="cuda")
+    blk = a.sample_many(B, K, flat).cpu().numpy()
+    np.random.seed(42)
+    idx = np.random.randint(0, 3000, B * K)
+    np.testing.assert_array_equal(blk[K * B * 18: K * B * 19].astype(np.int64), idx)   # rews carry the ring row number
+    seq = [_packed(b.sample_batch_device(B, fresh=True)) for _ in range(K)]
+    for cum, w in ((0, 8), (8, 8), (16, 2), (18, 1), (19, 1)):      # array j of the block is [K * B, w]: batch i = rows [i B, (i + 1) B)
+        for i in range(K):
+            np.testing.assert_array_equal(blk[K * B * cum + i * B * w: K * B * cum + (i + 1) * B * w], seq[i][B * cum: B * cum + B * w])
+    assert a.get_counts() == b.get_counts() == (K, 3000, 3000)
+    assert _fp(a) == _fp(b)
+
+
+def test_feed_plan_interleaves_remote_blocks_with_local_draws(ddrl):
+    """The learner side of the sharded replay (ddrl_replay_set_feed): plan entry -1 draws from the local ring exactly as
+    if the remote updates were not there; entry r << 24 | i returns batch i of region r bit for bit and consumes no local
+    draw; the plan restarts with every set_feed; detaching restores the plain sampler."""
+    B = 64
+    nf = B * 20
+    owners = [_filled(ddrl, 7, data_seed=1), _filled(ddrl, 8, data_seed=2)]
+    K = [5, 3]
+    blocks = [o.sample_many(B, k, torch.empty(k * nf, dtype=torch.float32, device="cuda")) for o, k in zip(owners, K)]
+    local, twin = _filled(ddrl, 9), _filled(ddrl, 9)
+    plan = [-1, 0 << 24 | 0, 1 << 24 | 0, -1, -1, 0 << 24 | 1, 1 << 24 | 1, 0 << 24 | 2, -1, 1 << 24 | 2, 0 << 24 | 3, 0 << 24 | 4]
+    plan_d = torch.tensor(plan, dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        local.set_feed(plan_d, B, list(zip(blocks, K)))
+        for p in plan:
+            got = _packed(local.sample_batch_device(B, fresh=True))
+            if p < 0:
+                want = _packed(twin.sample_batch_device(B, fresh=True))
+            else:
+                r, i = p >> 24, p & 0xffffff
+                blk, k = blocks[r].cpu().numpy(), K[r]
+                want = np.concatenate([blk[o * k * B + i * B * w: o * k * B + (i + 1) * B * w] for o, w in ((0, 8), (8, 8), (16, 2), (18, 1), (19, 1))])
+            np.testing.assert_array_equal(got, want, err_msg="rep %d entry %d" % (rep, p))
+        assert _fp(local) == _fp(twin)
+    # beyond the plan's end: local draws
+    np.testing.assert_array_equal(_packed(local.sample_batch_device(B, fresh=True)), _packed(twin.sample_batch_device(B, fresh=True)))
+    # sample_times counts local draws only (the owners counted the fed batches)
+    assert local.get_counts()[0] == twin.get_counts()[0] == 2 * plan.count(-1) + 1
+    local.set_feed(None, B, [])
+    np.testing.assert_array_equal(_packed(local.sample_batch_device(B, fresh=True)), _packed(twin.sample_batch_device(B, fresh=True)))
+    # an empty one-row ring that only follows a plan (a dedicated learner rank): fed batches come through, a local entry
+    # reports the reference's empty-buffer error
+    ghost = ddrl.ReplayBufferSAC1(8, 2, 1)
+    ghost.set_feed(torch.tensor([1 << 24 | 1], dtype=torch.int32, device="cuda"), B, list(zip(blocks, K)))
+    got = _packed(ghost.sample_batch_device(B, fresh=True))
+    blk = blocks[1].cpu().numpy()
+    np.testing.assert_array_equal(got[:B * 8], blk[B * 8: 2 * B * 8])

@@ -61,12 +61,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _gpu_worker(rank, world, port, q):
+def _prefilled_shard(d, opt, r):
+    """Shard r with 500 rows whose reward 1000 r + i shows the ring and row a sampled transition came from."""
+    rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 4096, seed=100 + r)
+    rs = np.random.RandomState(r)
+    n = 500
+    rb.store_batch(*(torch.from_numpy(x).cuda() for x in (
+        rs.randn(n, 8).astype(np.float32), rs.uniform(-1, 1, (n, 2)).astype(np.float32),
+        (1000.0 * r + np.arange(n)).astype(np.float32), rs.randn(n, 8).astype(np.float32), np.zeros(n, np.float32))))
+    return rb
+
+
+def _rows(rb, idx):
+    """The packed batch [obs1 | obs2 | acts | rews | done] the ring hands out for indices idx (host copy)."""
+    g = rb.rings()
+    return np.concatenate([g[k][torch.from_numpy(idx).cuda()].reshape(-1).cpu().numpy() for k in ("obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf")])
+
+
+def _gpu_worker(rank, world, port, q, num_learners):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           DDRL_DIST_BACKEND="gloo")
         import distributed_drl_amd as d
+        import torch.distributed as dist
         from distributed_drl_amd import _lib, comm, partition
         from distributed_drl_amd.agent import HyperParameters, Learner
         from distributed_drl_amd.workers import RolloutDevice
@@ -75,61 +93,60 @@ def _gpu_worker(rank, world, port, q):
         _lib.require_gpu()
         opt = HyperParameters()
         opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = 64, 32, 5, -1, 50, 6
-        roles = partition.Roles(w, r)
-
-        def make_replay():   # every row of shard s carries reward 1000 s + i: a batch shows which ring it came from
-            rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 4096, seed=100 + r)
-            rs = np.random.RandomState(r)
-            n = 500
-            rb.store_batch(*(torch.from_numpy(x).cuda() for x in (
-                rs.randn(n, 8).astype(np.float32), rs.uniform(-1, 1, (n, 2)).astype(np.float32),
-                (1000.0 * r + np.arange(n)).astype(np.float32), rs.randn(n, 8).astype(np.float32), np.zeros(n, np.float32))))
-            return rb
-        run = partition.PartitionedRun(opt, roles, make_replay, lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
-                                       lambda: Learner(opt, job="learner", index=r), seed=9)
-        # the learner's initial weights reached the other rank's actor
-        pi0 = run.bcast.buf[: run.roll.actor.n_params].clone()
-        assert torch.equal(run.roll.actor.get_weights_flat(), pi0)
+        B = opt.batch_size
+        roles = partition.Roles(w, r, num_learners=num_learners)
+        run = partition.PartitionedRun(opt, roles, lambda: _prefilled_shard(d, opt, r), lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
+                                       lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=0)
+        pi0 = run.bcast.buf[: 8 * 400 + 400 + 400 * 300 + 300 + 2 * (300 * 2 + 2)].clone()
+        if run.roll is not None:   # the learner's initial weights reached every rollout rank's actor
+            assert torch.equal(run.roll.actor.get_weights_flat(), pi0)
         sched = partition.Schedule(roles, seed=9)
         n_upd = 14
-        owners = [sched.next()[0][1] for _ in range(n_upd)]
-        # record what every ring hands out (in order) and what the learner trains on (in order)
-        drawn, trained = [], []
-        orig = partition.sample_packed
-
-        def recording(rb, B, flat):
-            v = orig(rb, B, flat)
-            drawn.append(flat.detach().cpu().numpy().copy())
-            return v
-        partition.sample_packed = recording
+        plans = [sched.next() for _ in range(n_upd)]
+        # What every ring must hand out, from NumPy's own legacy stream: the ring's sampler is np.random.seed(100 + r);
+        # at step u it holds 500 + 64 (u + 1) rows (the env step of the step is stored before its updates) and serves
+        # learner 0's batch before learner 1's.
+        rs = np.random.RandomState(100 + r)
+        handed, trained = [], []
         for u in range(n_upd):   # one update per step() call so that the batch of every update can be inspected
             run.step(1)
-            if roles.is_learner:
-                trained.append(torch.cat([run.last_batch[k].reshape(-1) for k in ("obs1", "obs2", "acts", "rews", "done")]).cpu().numpy().copy())
-        torch.cuda.synchronize()
-        import torch.distributed as dist
-        all_drawn = [None, None]
-        dist.all_gather_object(all_drawn, drawn)
+            torch.cuda.synchronize()
+            if run.rb is not None:
+                for l, owner in plans[u]:
+                    if owner == r:
+                        handed.append((u, l, _rows(run.rb, rs.randint(0, 500 + opt.num_envs * (u + 1), B))))
+            if run.loop is not None:   # single learner: the device loop gathered update u's batch into input set u & 1
+                v = run.learner.input_batch(u & 1)
+                trained.append(torch.cat([v[k].reshape(-1) for k in ("obs1", "obs2", "acts", "rews", "done")]).cpu().numpy().copy())
+            elif run.learner is not None:
+                trained.append(run.batch_buf.cpu().numpy().copy())
+        everything = [None] * w
+        dist.all_gather_object(everything, handed)
         if roles.is_learner:
-            # update u trained on exactly the next batch drawn from the ring of the scheduled owner (bit for bit; never a mix)
-            nxt = [0, 0]
-            for u, own in enumerate(owners):
-                np.testing.assert_array_equal(trained[u], all_drawn[own][nxt[own]], err_msg="update %d from shard %d" % (u, own))
-                nxt[own] += 1
-            assert nxt == [len(all_drawn[0]), len(all_drawn[1])]
+            # update u trained on exactly the batch the scheduled owner's ring handed out for it (bit for bit; never a mix)
+            want = {(u, l): rows for per_rank in everything for (u, l, rows) in per_rank}
+            for u in range(n_upd):
+                np.testing.assert_array_equal(trained[u], want[(u, r)], err_msg="update %d of learner %d" % (u, r))
             assert run.learner.opt_steps() == (n_upd, n_upd)
-            assert run.stats["local_batches"] == owners.count(0) and run.stats["remote_batches"] == owners.count(1)
-        else:
-            assert run.stats["sent_batches"] == owners.count(1) == len(drawn)
-        # owner-side sampler streams advanced exactly once per batch they served; both rings took their local stores
-        samples, steps, size = run.rb.get_counts()
-        assert samples == owners.count(r) and steps == 500 + n_upd * opt.num_envs
-        # two pushes (updates 6 and 12) + the initial one: the remote actor runs the learner's pushed policy
+            mine = [dict(p)[r] for p in plans]
+            assert run.stats["local_batches"] == mine.count(r) and run.stats["remote_batches"] == n_upd - mine.count(r)
+        if run.rb is not None:
+            # the shard's sampler advanced once per batch it served, the ring took its local stores
+            served = sum(1 for p in plans for _, owner in p if owner == r)
+            samples, steps, size = run.rb.get_counts()
+            assert samples == served and steps == 500 + n_upd * opt.num_envs == size
+            assert run.stats["sent_batches"] == sum(1 for p in plans for l, owner in p if owner == r and l != r)
+        # two pushes (updates 6 and 12) + the initial one: the rollout ranks run the learner's pushed policy
         assert run.stats["pushes"] == 3
         flat = run.bcast.buf.clone()
         if roles.is_learner:
             assert not torch.equal(flat[: pi0.numel()], pi0)
-        assert torch.equal(run.roll.actor.get_weights_flat(), flat[: pi0.numel()])
+        if run.roll is not None:
+            assert torch.equal(run.roll.actor.get_weights_flat(), flat[: pi0.numel()])
+        if num_learners == 2:   # synchronous data parallel: both learners hold the same parameters after every update
+            ws = [None] * w
+            dist.all_gather_object(ws, run.learner.get_weights_flat().cpu().numpy() if roles.is_learner else None)
+            np.testing.assert_array_equal(ws[0], ws[1])
         comm.barrier()
         q.put((rank, "ok"))
     except Exception:  # noqa
@@ -137,17 +154,28 @@ def _gpu_worker(rank, world, port, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.gpu
-def test_config3_two_ranks_on_one_gpu_hip_ring_and_learner():
-    """Config 3 end to end with the real HIP ring / sampler / learner on both ranks (gloo transport, both on cuda:0): the
-    learner's batches come from the scheduled owner's ring, counters and pushes line up on both ranks."""
+def _spawn(world, num_learners):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, num_learners)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+@pytest.mark.gpu
+def test_config3_two_ranks_on_one_gpu_hip_ring_and_learner():
+    """Config 3 end to end with the real HIP ring / sampler / learner loop on both ranks (gloo transport, both on cuda:0):
+    every update trains on the batch the scheduled owner's ring hands out, counters and pushes line up on both ranks."""
+    _spawn(2, None)
+
+
+@pytest.mark.gpu
+def test_config4_roles_three_ranks_on_one_gpu_two_learners_one_shard():
+    """Config 4's roles at the smallest size (2 data-parallel learner ranks + 1 rollout rank with the shard): the owner
+    serves both learners' blocks, the learners all-reduce their gradients and stay bit-identical."""
+    _spawn(3, 2)
