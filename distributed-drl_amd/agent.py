@@ -188,8 +188,8 @@ class Learner(_Net):
         # set_weights + target_init (actor_learner.py:125-127)
         _lib.check(self._lib.ddrl_sac1_set_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
 
-    def export(self, which):
-        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+    def export(self, which, out=None):
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device) if out is None else out
         _lib.check(self._lib.ddrl_sac1_export(self._h, which, _lib.dptr(flat), _lib.stream_ptr()))
         return flat
 
@@ -271,10 +271,10 @@ class Learner(_Net):
         keep, ptrs = self._device_args(batch)
         _lib.check(self._lib.ddrl_sac1_step(self._h, *ptrs, _lib.stream_ptr()))
 
-    def compute_gradients_device(self, batch):
+    def compute_gradients_device(self, batch, out=None):
         keep, ptrs = self._device_args(batch)
         _lib.check(self._lib.ddrl_sac1_compute_grads(self._h, *ptrs, _lib.stream_ptr()))
-        return self.export(_lib.SAC1_GRAD)
+        return self.export(_lib.SAC1_GRAD, out)
 
     def compute_gradients(self, batch, eps=None):
         """Forward + backward only (the stubbed compute_gradients of actor_learner.py:144-145)."""

@@ -57,6 +57,9 @@ def allreduce_mean_(flat, group=None):
     """In-place mean over the group's ranks (learner gradient all-reduce)."""
     if not dist.is_initialized():
         return flat
+    if dist.get_backend(group) == "nccl":      # RCCL averages inside the reduction kernel
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     n = dist.get_world_size(group)
     if n > 1:

@@ -139,31 +139,57 @@ struct DOps {
     float w1[4][8];
 };
 // Issue order = order of need (a wave's loads return in order): the layer-1 columns of a block, then its W2 groups.
-__device__ __forceinline__ void dops_load(DOps &o, const float *__restrict__ W1, const float *__restrict__ W2p, int K, int Np, int b0, int nb,
-                                          int n0, int lane) {
+// Only the first DPRE blocks are requested before the K loop; block bi + DPRE is requested when block bi's MFMAs are
+// issued, so the fetch path (one wave-load per ~15 cycles and CU: ~3.6k cycles for the 8 waves of two workgroups) works
+// beside the matrix pipe instead of in front of it.
+#ifndef DDRL_DPRE
+#define DDRL_DPRE 1
+#endif
+#ifndef DDRL_DGP
+#define DDRL_DGP 2
+#endif
+#ifndef DDRL_DGMID
+#define DDRL_DGMID 4
+#endif
+#ifndef DDRL_XIN_FIRST
+#define DDRL_XIN_FIRST 1
+#endif
+#ifndef DDRL_XIN_MASK
+#define DDRL_XIN_MASK 0
+#endif
+#ifndef DDRL_MID
+#define DDRL_MID 1
+#endif
+constexpr int DPRE = DDRL_DPRE;
+struct DSrc {
+    const float *W1, *W2p;
+    int Np, b0, nb, n0;
+};
+__device__ __forceinline__ void dops_load_block(DOps &o, const DSrc &s, int bi, int lane) {
     const int l31 = lane & 31, h = lane >> 5;
+    const int u0 = (s.b0 + (bi < s.nb ? bi : (s.nb > 0 ? s.nb - 1 : 0))) * 32;
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi) {
-        const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {  // [W1 ; b1] in the layer-1 block layout (gemm_core.h, w1y_index): two float4 per lane and block
-            const float4 v = *reinterpret_cast<const float4 *>(W1 + ((((long long)(u0 >> 5) * 2 + q) * 2 + h) * 32 + l31) * 4);
-            o.w1[bi][4 * q + 0] = v.x; o.w1[bi][4 * q + 1] = v.y; o.w1[bi][4 * q + 2] = v.z; o.w1[bi][4 * q + 3] = v.w;
-        }
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) o.bq[bi][rq] = *reinterpret_cast<const float4 *>(W2p + ((long long)(u0 / 4 + 2 * rq + h) * Np + n0 + l31) * 4);
+    for (int q = 0; q < 2; ++q) {  // [W1 ; b1] in the layer-1 block layout (gemm_core.h, w1y_index): two float4 per lane and block
+        const float4 v = *reinterpret_cast<const float4 *>(s.W1 + ((((long long)(u0 >> 5) * 2 + q) * 2 + h) * 32 + l31) * 4);
+        o.w1[bi][4 * q + 0] = v.x; o.w1[bi][4 * q + 1] = v.y; o.w1[bi][4 * q + 2] = v.z; o.w1[bi][4 * q + 3] = v.w;
     }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) o.bq[bi][rq] = *reinterpret_cast<const float4 *>(s.W2p + ((long long)(u0 / 4 + 2 * rq + h) * s.Np + s.n0 + l31) * 4);
 }
 
 // K loop of one wave over MT row tiles that share the wave's W2 / W1 registers.  h1r4 != nullptr (n-tile-0 workgroups of
 // a differentiated evaluation): X1 also goes to memory as [row/4][unit][4] through a wave-private LDS tile (registers hold
 // row-in-lane / unit-in-register; the image wants 4 rows per float4).
-template <int NS, int MT>
-__device__ __forceinline__ void dkloop(const DOps &o, int K, int b0, int nb, int lane, const float (&xin)[MT][7], floatx16 (&acc)[MT],
-                                       float *__restrict__ h1r4, int Lp1, int m0, float *__restrict__ tr) {
-    const int l31 = lane & 31, h = lane >> 5;
+template <int NS, int MT, class Mid>
+__device__ __forceinline__ void dkloop(DOps &o, const DSrc &src, bool fetch, int K, int lane, const float (&xin)[MT][7], floatx16 (&acc)[MT],
+                                       float *__restrict__ h1r4, int Lp1, int m0, float *__restrict__ tr, Mid &&mid) {
+    const int l31 = lane & 31, h = lane >> 5, b0 = src.b0, nb = src.nb;
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
+        if (bi + DPRE < 4) {
+            if (fetch) dops_load_block(o, src, bi + DPRE, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (bi < nb) {
             const int u0 = (b0 + bi) * 32;
             const int nrq = (K - u0 >= 32) ? 4 : ((K - u0 + 7) >> 3);
@@ -185,6 +211,12 @@ __device__ __forceinline__ void dkloop(const DOps &o, int K, int b0, int nb, int
                 }
             }
         }
+#if DDRL_MID
+        if (bi == 0) {  // whatever the epilogue needs and nothing in the K loop does: requested behind block 0's MFMAs
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
     }
 }
 
@@ -268,7 +300,11 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         }
     }
     DOps ops;
-    dops_load(ops, W1, W2p, K, Np, b0, nb, n0, lane);
+    const DSrc src{W1, W2p, Np, b0, nb, n0};
+#if !DDRL_XIN_FIRST
+#pragma unroll
+    for (int bi = 0; bi < DPRE; ++bi) dops_load_block(ops, src, bi, lane);
+#endif
     // Row chunks: MI > 1 (the actor's forward over thousands of rows) keeps the wave's W2 / W1 registers for MI row tiles in turn
     for (int mi = 0; mi < MI && m0 < B; ++mi, m0 += 32 * MT) {
         // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
@@ -283,24 +319,35 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
                     const int d = d_slot(s, h);
                     const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
                     const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
+                    // (no select on the loaded value: the compiler would sink the load into a branch.)  Column D: the bias row
+#if DDRL_XIN_MASK
+                    xin[tt][s] = *p * ((f0 || f1) ? 1.0f : 0.f) + ((!f0 && !f1 && d == D) ? 1.0f : 0.f);
+#else
                     const float v = *p;
-                    xin[tt][s] = (f0 || f1) ? v : (d == D ? 1.0f : 0.f);  // column D: the bias row
+                    xin[tt][s] = (f0 || f1) ? v : (d == D ? 1.0f : 0.f);
+#endif
                 }
             }
         }
+#if DDRL_XIN_FIRST
+        if (mi == 0) {  // behind the input rows: a wave's loads return in order and the first MFMA needs those first
+#pragma unroll
+            for (int bi = 0; bi < DPRE; ++bi) dops_load_block(ops, src, bi, lane);
+        }
+#endif
         DST(PH, 1);
         const DFJob &jb = a.job[ji];
         ktouch(kline<sizeof(DFJob)>(&jb) | kline<offsetof(DFArgs, do_sample)>(&a));
-        // ---- epilogue operands
-        const float4 b4 = *reinterpret_cast<const float4 *>(jb.b2 + n0 + 4 * (tid >> 5));
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float whv = 0.f;
-        {
+        auto epilogue_operands = [&]() {
+            b4 = *reinterpret_cast<const float4 *>(jb.b2 + n0 + 4 * (tid >> 5));
             const int c = tid >> 5, col = n0 + (tid & 31);
             const bool ok = c < jb.nh && col < a.h2;
             const float *p = c < jb.hsplit ? jb.wh0 : jb.wh1;
             const int cc = c < jb.hsplit ? c : c - jb.hsplit;
-            whv = ok ? p[(long long)col * jb.hstride + cc] : 0.f;
-        }
+            whv = p[ok ? (long long)col * jb.hstride + cc : 0] * (ok ? 1.0f : 0.f);
+        };
         if (PH == 1) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
             float hs[2][4];
     #pragma unroll
@@ -364,11 +411,14 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
         float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
-        if (nb > 0) {
-            if (ns == 4) dkloop<4, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-            else if (ns == 5) dkloop<5, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-            else if (ns == 6) dkloop<6, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
-            else dkloop<7, MT>(ops, K, b0, nb, lane, xin, acc, h1r4, a.Lp1, m0, tr[w]);
+#if !DDRL_MID
+        epilogue_operands();
+#endif
+        {
+            if (ns == 4) dkloop<4, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            else if (ns == 5) dkloop<5, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            else if (ns == 6) dkloop<6, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            else dkloop<7, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
         }
 
         DST(PH, 3);
@@ -689,49 +739,30 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     // both operand streams of this wave: unconditional loads, groups beyond ng re-read the last one (a branch or a
     // select in front of a load makes the compiler wait for the previous load before issuing the next)
     float4 a4[GMAX], b4[GMAX];
-    {
-        const float *Ap = Aop + (long long)(m0 + l31) * 4, *Bp = Bop + (long long)(n0 + l31) * 4;
-        const int glast = ng > 0 ? g0 + ng - 1 : (G > 0 ? G - 1 : 0);
+    const float *Ap = Aop + (long long)(m0 + l31) * 4, *Bp = Bop + (long long)(n0 + l31) * 4;
+    const int glast = ng > 0 ? g0 + ng - 1 : (G > 0 ? G - 1 : 0);
+    auto fetch_group = [&](int g) {
+        const int gg = g0 + g < glast ? g0 + g : glast;
+        const long long kg = 2 * gg + h;
+        a4[g] = *reinterpret_cast<const float4 *>(Ap + kg * lda * 4);
+        b4[g] = *reinterpret_cast<const float4 *>(Bp + kg * ldb * 4);
+    };
+    // only the first DGP groups are requested up front; group g + DGP is requested when group g's MFMAs are issued (the
+    // fetch path then works beside the matrix pipe, and the first MFMA does not queue behind the whole stream)
+    constexpr int DGP = DDRL_DGP < GMAX ? DDRL_DGP : GMAX;
 #pragma unroll
-        for (int g = 0; g < GMAX; ++g) {
-            const int gg = g0 + g < glast ? g0 + g : glast;
-            const long long kg = 2 * gg + h;
-            a4[g] = *reinterpret_cast<const float4 *>(Ap + kg * lda * 4);
-            b4[g] = *reinterpret_cast<const float4 *>(Bp + kg * ldb * 4);
-        }
-    }
+    for (int g = 0; g < DGP; ++g) fetch_group(g);
     ktouch(kl);
     DST(kid, 1);
-    // ---- epilogue operands, fetched behind the operand streams
+    // ---- epilogue operands: requested from inside the K loop (behind the MFMAs of the first groups), so that the first
+    // MFMA does not queue behind up to 16 more wave-loads per wave
     const bool is_dgrad = type == DG_DGRAD_Q || type == DG_DGRAD;
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (is_dgrad) mk = *reinterpret_cast<const float4 *>(jb.mask + ((long long)(m0 / 4 + cg) * jb.ldmask + n0 + r) * 4);  // mapping C: (col r, row group cg)
-    float wa_v = 0.f, px_v[2] = {0.f, 0.f};  // staged into LDS after the K loop (an LDS store here would wait for every load above)
+    float wa_v = 0.f, px_v[2] = {0.f, 0.f};  // staged into LDS after the K loop
     const bool has_da = is_dgrad && jb.da_part, has_part = type == DG_DGRAD && jb.part;  // block-uniform
-    if (has_da) {
-        const int c = tid >> 5, col = n0 + (tid & 31);
-        const bool ok = c < jb.nact && col < jb.N;
-        const float v = jb.wa[ok ? w1y_index(jb.wa_d0 + c, col) : 0];
-        wa_v = ok ? v : 0.f;
-    }
-    if (has_part) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + 256 * u;  // 32 * 12 = 384 slots
-            const int rr = idx / 12, k = idx - rr * 12;
-            const bool ok = idx < 32 * 12 && k < jb.part_nk;
-            const float v = jb.part_x[ok ? (long long)(m0 + rr) * jb.part_ldx + k : 0];
-            px_v[u] = ok ? v : 0.f;
-        }
-    }
     const bool rm_like = type == DG_WGRAD_RM || type == DG_WGRAD_W1Y;  // element-addressed gradient: row-major, or the layer-1 block layout
     const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || rm_like) && jb.adam_off >= 0;
     float al_pi = 0.f, al_q = 0.f;
-    if (jobs.ad.on) {
-        const float b1p_pi = jobs.ad.opt->b1p_pi, b2p_pi = jobs.ad.opt->b2p_pi, b1p_q = jobs.ad.opt->b1p_q, b2p_q = jobs.ad.opt->b2p_q;
-        al_pi = jobs.ad.lr * sqrtf(1.0f - b2p_pi) / (1.0f - b1p_pi);
-        al_q = jobs.ad.lr * sqrtf(1.0f - b2p_q) / (1.0f - b1p_q);
-    }
     // optimizer state of this tile: J4 — thread (col r, row group cg) owns rows 4cg..4cg+3 of column r as one float4;
     // RM — thread owns elements (o >> 5, o & 31), o = tid + 256 q
     float4 j_m, j_v, j_p, j_t;
@@ -740,30 +771,57 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     bool okv[4];
     long long j_idx = 0, b_idx = 0;
     bool j_ok = false, b_ok = false;
-    if (type == DG_WGRAD_J4) {
-        j_ok = m0 + 4 * cg < jb.bias_row && n0 + r < jb.N;
-        j_idx = jb.adam_off + ((long long)(m0 / 4 + cg) * jb.ldc + n0 + r) * 4;
-        b_ok = m0 + 4 * cg == jb.bias_row && n0 + r < jb.N;  // (hidden1 % 4 == 0: the bias row opens a group)
-        b_idx = jb.bias_off + n0 + r;
-        if (do_adam) {
-            const long long ic = j_ok ? j_idx : jb.adam_off;
-            j_m = *reinterpret_cast<const float4 *>(jobs.ad.m + ic); j_v = *reinterpret_cast<const float4 *>(jobs.ad.v + ic);
-            j_p = *reinterpret_cast<const float4 *>(jobs.ad.p + ic); j_t = *reinterpret_cast<const float4 *>(jobs.ad.t + ic);
-            const long long bc = b_ok ? b_idx : jb.bias_off;
-            bm = jobs.ad.m[bc]; bv = jobs.ad.v[bc]; bp = jobs.ad.p[bc]; bt = jobs.ad.t[bc];
+    auto epilogue_operands = [&]() {
+        if (is_dgrad) mk = *reinterpret_cast<const float4 *>(jb.mask + ((long long)(m0 / 4 + cg) * jb.ldmask + n0 + r) * 4);  // mapping C: (col r, row group cg)
+        if (has_da) {
+            const int c = tid >> 5, col = n0 + (tid & 31);
+            const bool ok = c < jb.nact && col < jb.N;
+            const float v = jb.wa[ok ? w1y_index(jb.wa_d0 + c, col) : 0];
+            wa_v = ok ? v : 0.f;
         }
-    } else if (rm_like) {
+        if (has_part) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = tid + 256 * q;
-            const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
-            okv[q] = gi < jb.M && gj < jb.N;
-            if (do_adam) {
-                const long long idx = !okv[q] ? jb.adam_off : jb.adam_off + (type == DG_WGRAD_W1Y ? w1y_index(gi, gj) : (long long)gi * jb.ldc + gj);
-                am[q] = jobs.ad.m[idx]; av[q] = jobs.ad.v[idx]; ap[q] = jobs.ad.p[idx]; at[q] = jobs.ad.t[idx];
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 256 * u;  // 32 * 12 = 384 slots
+                const int rr = idx / 12, k = idx - rr * 12;
+                const bool ok = idx < 32 * 12 && k < jb.part_nk;
+                const float v = jb.part_x[ok ? (long long)(m0 + rr) * jb.part_ldx + k : 0];
+                px_v[u] = ok ? v : 0.f;
             }
         }
-    }
+        if (jobs.ad.on) {
+            const float b1p_pi = jobs.ad.opt->b1p_pi, b2p_pi = jobs.ad.opt->b2p_pi, b1p_q = jobs.ad.opt->b1p_q, b2p_q = jobs.ad.opt->b2p_q;
+            al_pi = jobs.ad.lr * sqrtf(1.0f - b2p_pi) / (1.0f - b1p_pi);
+            al_q = jobs.ad.lr * sqrtf(1.0f - b2p_q) / (1.0f - b1p_q);
+        }
+        if (type == DG_WGRAD_J4) {
+            j_ok = m0 + 4 * cg < jb.bias_row && n0 + r < jb.N;
+            j_idx = jb.adam_off + ((long long)(m0 / 4 + cg) * jb.ldc + n0 + r) * 4;
+            b_ok = m0 + 4 * cg == jb.bias_row && n0 + r < jb.N;  // (hidden1 % 4 == 0: the bias row opens a group)
+            b_idx = jb.bias_off + n0 + r;
+            if (do_adam) {
+                const long long ic = j_ok ? j_idx : jb.adam_off;
+                j_m = *reinterpret_cast<const float4 *>(jobs.ad.m + ic); j_v = *reinterpret_cast<const float4 *>(jobs.ad.v + ic);
+                j_p = *reinterpret_cast<const float4 *>(jobs.ad.p + ic); j_t = *reinterpret_cast<const float4 *>(jobs.ad.t + ic);
+                const long long bc = b_ok ? b_idx : jb.bias_off;
+                bm = jobs.ad.m[bc]; bv = jobs.ad.v[bc]; bp = jobs.ad.p[bc]; bt = jobs.ad.t[bc];
+            }
+        } else if (rm_like) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = tid + 256 * q;
+                const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+                okv[q] = gi < jb.M && gj < jb.N;
+                if (do_adam) {
+                    const long long idx = !okv[q] ? jb.adam_off : jb.adam_off + (type == DG_WGRAD_W1Y ? w1y_index(gi, gj) : (long long)gi * jb.ldc + gj);
+                    am[q] = jobs.ad.m[idx]; av[q] = jobs.ad.v[idx]; ap[q] = jobs.ad.p[idx]; at[q] = jobs.ad.t[idx];
+                }
+            }
+        }
+    };
+#if !DDRL_DGMID
+    epilogue_operands();
+#endif
     // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
     float dqr = jb.gconst;
     if (has_gen) { s_gw[tid] = gv0; s_gw[tid + 256] = gv1; }
@@ -811,6 +869,16 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
+        if (g + DGP < GMAX) {
+            fetch_group(g + DGP);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if DDRL_DGMID
+        if (g == DDRL_DGMID) {
+            epilogue_operands();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         if (g < ng) {
             float4 av4 = a4[g], bv4 = b4[g];
             if (type == DG_DGRAD_Q) {

@@ -194,6 +194,8 @@ class PartitionedRun:
             self.batch_buf = torch.empty(self.nf, dtype=torch.float32, device=self.device)
             if self.lgroup is None:
                 self.loop = _Loop(self.learner, self.feed_ring, updates_per_graph)
+            else:
+                self.grad_buf = torch.empty(self.learner.n_params, dtype=torch.float32, device=self.device)
         self.send_bufs, self.regions = {}, {}
         self.plan_d, self.plan_h = None, None
         self.sends = []
@@ -274,7 +276,7 @@ class PartitionedRun:
         """Several learners: per update, the plan's batch -> gradients -> all-reduce (mean) -> Adam + polyak."""
         for _ in range(n):
             batch = sample_packed(self.feed_ring, self.B, self.batch_buf)
-            g = self.learner.compute_gradients_device(batch)
+            g = self.learner.compute_gradients_device(batch, out=self.grad_buf)
             comm.allreduce_mean_(g, group=self.lgroup)
             self.learner.apply_gradients(g)
 
