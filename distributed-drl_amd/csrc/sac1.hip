@@ -1728,6 +1728,9 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
 // The policy forward of the fused rollout step: layer 1 + layer 2 + head partials of `n` observation rows that sit in
 // the actor's own observation buffer, as one k_dfwd launch (n / 32 x ceil(h2 / 32) tiles).  The env-step kernel behind it
 // turns the partials into actions (ddrl_pol::policy_row), steps the physics and appends the transitions to the ring.
+#ifdef DDRL_STAMPS
+unsigned long long *g_actor_st = nullptr;
+#endif
 int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
     DDRL_REQUIRE(h != nullptr && h->direct, "actor has no direct-operand policy (shape outside the envelope)");
     DDRL_REQUIRE(n > 0 && n % 32 == 0 && n <= h->max_rows, "n must be a positive multiple of 32 within max_rows");
@@ -1735,27 +1738,21 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
     const ddrl_sac1_config_t &c = h->cfg;
     const Layout &L = h->Ld;
     const int nt2 = (c.hidden2 + 31) / 32;
-    DFHead d{};
-    d.base = h->dslab; d.tiles_m = (int)(n / 32); d.tpj = d.tiles_m * nt2; d.K = c.hidden1; d.Np = L.Np2; d.B = (int)n; d.d0 = c.obs_dim;
-    d.x_off = (int)(h->obs_d - h->dslab);
-    d.main_off = d.targ_off = (int)L.pi_W1; d.npi = d.perq = 0; d.hp_off = (int)(h->hp_d - h->dslab);
-    const int D1 = c.obs_dim + 1;
-    d.pack = (D1 <= 8 ? 4 : 4 + (D1 - 8 + 1) / 2) - 4;
-    DDRL_REQUIRE(d.tpj < 65536 && n < 65536, "too many rows for the packed tile arguments");
-    DFArgs F{};
-    F.njobs = 1; F.tiles_n = nt2; F.act = c.act_dim; F.Lp1 = rup32(c.hidden1 + 1); F.Lp2 = rup32(c.hidden2 + 1); F.h2 = c.hidden2;
-    F.scale = (float)c.act_scale;
-    DFJob j{};
-    j.b2 = h->pi_d + L.pi_b2; j.wh0 = h->pi_d + L.pi_Wmu; j.wh1 = h->pi_d + L.pi_Wls; j.nh = 2 * c.act_dim; j.hsplit = c.act_dim; j.hstride = c.act_dim;
-    j.hp = h->hp_d;
-    F.job[0] = j;
-    // row tiles per workgroup: ~1.7 workgroups per CU (two resident per CU fill each other's issue bubbles), each keeping its
-    // W2 / W1 registers for `mi` row tiles instead of re-fetching them per tile
-    const int total = d.tiles_m * nt2;
-    int mi = (total + 439) / 440;
-    if (mi < 1) mi = 1;
-    if (mi > 255) mi = 255;
-    launch_dfwd<0>(d, F, ddrl::as_stream(stream), mi);
+    ActFwdArgs A{};
+    A.W1 = h->pi_d + L.pi_W1; A.W2p = A.W1 + ((c.hidden1 + 31) & ~31) * 16;   // the k4-interleaved W2 follows the layer-1 block array
+    A.b2 = h->pi_d + L.pi_b2; A.wmu = h->pi_d + L.pi_Wmu; A.wls = h->pi_d + L.pi_Wls; A.obs = h->obs_d; A.hp = h->hp_d;
+    A.rows = (int)n; A.K = c.hidden1; A.Np = L.Np2; A.h2 = c.hidden2; A.d0 = c.obs_dim; A.act = c.act_dim; A.tiles_n = nt2;
+    A.ngroups = (nt2 + ANT - 1) / ANT;   // 10 column tiles -> 2 workgroups of 5 per row tile
+#ifdef DDRL_STAMPS
+    A.st = g_actor_st;
+#endif
+    const int D1 = c.obs_dim + 1, ns = D1 <= 8 ? 4 : 4 + (D1 - 8 + 1) / 2;
+    const unsigned grid = (unsigned)(n / 32) * A.ngroups;
+    hipStream_t s = ddrl::as_stream(stream);
+    if (ns == 4) k_actor_fwd<4><<<grid, 256, 0, s>>>(A);
+    else if (ns == 5) k_actor_fwd<5><<<grid, 256, 0, s>>>(A);
+    else if (ns == 6) k_actor_fwd<6><<<grid, 256, 0, s>>>(A);
+    else k_actor_fwd<7><<<grid, 256, 0, s>>>(A);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }

@@ -40,6 +40,7 @@ constexpr int DFH = 8;    // head slots per evaluation (2 * act_dim <= 8)
 constexpr int DNT = 16;   // n-tile slots of a head-partial row (hidden2 <= 512)
 constexpr int DGMAX = 16; // 8-deep contraction groups per wave (contraction <= 512)
 
+__device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 __device__ __forceinline__ int d_slot(int s, int h) { return s < 4 ? 4 * h + s : 8 + 2 * (s - 4) + h; }
 __device__ __forceinline__ float relu1(float x) {
     float y;
@@ -180,14 +181,14 @@ __device__ __forceinline__ void dops_load_block(DOps &o, const DSrc &s, int bi, 
 // K loop of one wave over MT row tiles that share the wave's W2 / W1 registers.  h1r4 != nullptr (n-tile-0 workgroups of
 // a differentiated evaluation): X1 also goes to memory as [row/4][unit][4] through a wave-private LDS tile (registers hold
 // row-in-lane / unit-in-register; the image wants 4 rows per float4).
-template <int NS, int MT, class Mid>
-__device__ __forceinline__ void dkloop(DOps &o, const DSrc &src, bool fetch, int K, int lane, const float (&xin)[MT][7], floatx16 (&acc)[MT],
+template <int NS, int MT, int PRE, class Mid>
+__device__ __forceinline__ void dkloop(DOps &o, const DSrc &src, int K, int lane, const float (&xin)[MT][7], floatx16 (&acc)[MT],
                                        float *__restrict__ h1r4, int Lp1, int m0, float *__restrict__ tr, Mid &&mid) {
     const int l31 = lane & 31, h = lane >> 5, b0 = src.b0, nb = src.nb;
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
-        if (bi + DPRE < 4) {
-            if (fetch) dops_load_block(o, src, bi + DPRE, lane);
+        if (bi + PRE < 4) {
+            dops_load_block(o, src, bi + PRE, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (bi < nb) {
@@ -223,16 +224,15 @@ __device__ __forceinline__ void dkloop(DOps &o, const DSrc &src, bool fetch, int
 // MT = 2 (phase 0: 400 tiles of 32 rows would put two workgroups on most CUs, each fetching its own copy of a W2 tile —
 // the fetch phase, not the MFMAs, is what a stage waits for): one workgroup = 64 rows x 32 columns, the wave's W2 / W1
 // registers serve both row tiles.
-template <int PH, int MT, bool LOOP>
+template <int PH, int MT>
 __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int pack, int x_off, int main_off, int targ_off, int npi, int perq,
                                               int hp_off, DFArgs a) {  // 12 dwords: what the hardware preloads into SGPRs at wave launch
     static_assert(PH == 0 || MT == 1, "phase 1 computes one policy row per lane");
-    static_assert(!LOOP || (PH == 0 && MT == 1), "row-chunk loop: the actor's forward only");
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ __attribute__((aligned(16))) float tr[4][32 * 36];
     __shared__ float s_wh[DFH][32];
     const int tpj = tpj_tm & 0xffff, tiles_m = (tpj_tm >> 16) & 0xfff, njobs = (unsigned)tpj_tm >> 28;
-    const int K = K_Np & 0xfff, Np = (K_Np >> 12) & 0xfff, MI = LOOP ? (int)((unsigned)K_Np >> 24) : 1, B = B_d0 & 0xffff, d0 = (B_d0 >> 16) & 0xff, act = B_d0 >> 24;
+    const int K = K_Np & 0xfff, Np = (K_Np >> 12) & 0xfff, B = B_d0 & 0xffff, d0 = (B_d0 >> 16) & 0xff, act = B_d0 >> 24;
     DRT(PH, 14); DST(PH, 0);
     if (PH == 1 && (int)blockIdx.x == njobs * tpj) {  // only launched when a.do_sample
         ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
@@ -247,8 +247,8 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     const int ji = (t >= tpj) + (t >= 2 * tpj) + (t >= 3 * tpj) + (t >= 4 * tpj);
     t -= ji * tpj;
     const int nt = t / tiles_m;
-    const int mchunk = t - nt * tiles_m, n0 = nt * 32;  // tiles_m counts workgroup-level row chunks of MI * MT row tiles
-    int m0 = mchunk * MI * (32 * MT);
+    const int mchunk = t - nt * tiles_m, n0 = nt * 32;  // tiles_m counts workgroup-level row chunks of MT row tiles
+    const int m0 = mchunk * (32 * MT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -301,12 +301,12 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     }
     DOps ops;
     const DSrc src{W1, W2p, Np, b0, nb, n0};
-#if !DDRL_XIN_FIRST
+    constexpr int PRE = DPRE;
+    if (!DDRL_XIN_FIRST) {
 #pragma unroll
-    for (int bi = 0; bi < DPRE; ++bi) dops_load_block(ops, src, bi, lane);
-#endif
-    // Row chunks: MI > 1 (the actor's forward over thousands of rows) keeps the wave's W2 / W1 registers for MI row tiles in turn
-    for (int mi = 0; mi < MI && m0 < B; ++mi, m0 += 32 * MT) {
+        for (int bi = 0; bi < PRE; ++bi) dops_load_block(ops, src, bi, lane);
+    }
+    {
         // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
         float xin[MT][7];
         {
@@ -329,12 +329,10 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
                 }
             }
         }
-#if DDRL_XIN_FIRST
-        if (mi == 0) {  // behind the input rows: a wave's loads return in order and the first MFMA needs those first
+        if (DDRL_XIN_FIRST) {  // behind the input rows: a wave's loads return in order and the first MFMA needs those first
 #pragma unroll
-            for (int bi = 0; bi < DPRE; ++bi) dops_load_block(ops, src, bi, lane);
+            for (int bi = 0; bi < PRE; ++bi) dops_load_block(ops, src, bi, lane);
         }
-#endif
         DST(PH, 1);
         const DFJob &jb = a.job[ji];
         ktouch(kline<sizeof(DFJob)>(&jb) | kline<offsetof(DFArgs, do_sample)>(&a));
@@ -415,10 +413,10 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         epilogue_operands();
 #endif
         {
-            if (ns == 4) dkloop<4, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
-            else if (ns == 5) dkloop<5, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
-            else if (ns == 6) dkloop<6, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
-            else dkloop<7, MT>(ops, src, mi == 0, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            if (ns == 4) dkloop<4, MT, PRE>(ops, src, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            else if (ns == 5) dkloop<5, MT, PRE>(ops, src, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            else if (ns == 6) dkloop<6, MT, PRE>(ops, src, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
+            else dkloop<7, MT, PRE>(ops, src, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
         }
 
         DST(PH, 3);
@@ -483,7 +481,6 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
                 }
             }
         }
-        if (mi + 1 < MI) __syncthreads();  // the next row tile reuses red / s_wh
     }
     DST(PH, 5); DRT(PH, 15);
 }
@@ -497,17 +494,204 @@ static int dfwd_mt(int B, int tiles_n) {
 }
 
 template <int PH>
-static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s, int mi = 1) {
-    const int mt = (PH == 0 && mi == 1) ? dfwd_mt(d.B, F.tiles_n) : 1;
-    const int tiles_m = (d.B / (32 * mt) + mi - 1) / mi, tpj = tiles_m * F.tiles_n;
+static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s) {
+    const int mt = PH == 0 ? dfwd_mt(d.B, F.tiles_n) : 1;
+    const int tiles_m = d.B / (32 * mt), tpj = tiles_m * F.tiles_n;
     const int grid = F.njobs * tpj + ((PH == 1 && F.do_sample) ? 1 : 0);
-    const int a1 = tpj | (tiles_m << 16) | (F.njobs << 28), a2 = d.K | (d.Np << 12) | (mi << 24), a3 = d.B | (d.d0 << 16) | (F.act << 24);
-    if (PH == 0 && mi > 1)
-        k_dfwd<0, 1, true><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
-    else if (PH == 0 && mt == 2)
-        k_dfwd<0, 2, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
+    const int a1 = tpj | (tiles_m << 16) | (F.njobs << 28), a2 = d.K | (d.Np << 12), a3 = d.B | (d.d0 << 16) | (F.act << 24);
+    if (PH == 0 && mt == 2)
+        k_dfwd<0, 2><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
     else
-        k_dfwd<PH, 1, false><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
+        k_dfwd<PH, 1><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, F);
+}
+
+// ==========================================================================================
+// k_actor_fwd: the policy forward of the rollout (thousands of rows, one network, heads only).
+// One workgroup = one 32-row tile x up to ANT consecutive column tiles of layer 2.  Each wave computes layer 1 for ITS
+// quarter of the hidden-1 units ONCE and keeps it in registers (k_dfwd regenerates it per column tile), then walks the
+// column tiles: every W2 group of tile t + 1 is requested between the MFMAs of the same group of tile t, so the only
+// latency a wave ever waits for is that of its first loads.  4096 rows x 10 column tiles = 128 x 2 workgroups of 5 tiles:
+// one per CU, 16.2 us per launch.  (Measured alternatives: 4 workgroups of 3, 3, 2, 2 tiles per row tile, two per CU, so that
+// a wave busy issuing loads — ~60 cycles per 16-byte-per-lane load — leaves the matrix pipe to the other workgroup's wave:
+// 17.9 us, layer 1 is generated 4x instead of 2x and the register budget halves; skewing the four waves by one MFMA each
+// after every barrier: no change — the issue cost is per wave, not a queue at the CU's fetch path.)
+// Same summation orders as k_dfwd (block order inside a wave, waves 0..3 in the combine, columns 0..31 in the head dot).
+// ==========================================================================================
+constexpr int ANT = 5;
+struct ActFwdArgs {
+    const float *W1, *W2p, *b2, *wmu, *wls, *obs;
+    float *hp;
+    int rows, K, Np, h2, d0, act, tiles_n, ngroups;
+#ifdef DDRL_STAMPS
+    unsigned long long *st;  // dev harness (tools/actor_bench.hip): [workgroup][wave][32] cycle stamps
+#endif
+};
+#ifdef DDRL_STAMPS
+#define AST(i) do { if (a.st && lane == 0) a.st[((long long)blockIdx.x * 4 + w) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AST(i) do { } while (0)
+#endif
+template <int NS>
+__global__ void __launch_bounds__(256) k_actor_fwd(ActFwdArgs a) {
+    // rows of 36 floats: 16-byte aligned (b128 LDS reads) and conflict-free for 16 lanes reading 4 words each
+    __shared__ __attribute__((aligned(16))) float red[2][4][32][36];
+    __shared__ __attribute__((aligned(16))) float red2[2][32][36];
+    __shared__ __attribute__((aligned(16))) float s_wh[ANT][DFH][32];
+    __shared__ __attribute__((aligned(16))) float s_b2[ANT][32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    // column tiles are dealt to `ngroups` workgroups per row tile as evenly as they go
+    const int rt = blockIdx.x / a.ngroups, grp = blockIdx.x - rt * a.ngroups;
+    const int gbase = a.tiles_n / a.ngroups, gextra = a.tiles_n % a.ngroups;
+    const int ntiles = gbase + (grp < gextra ? 1 : 0);
+    const int m0 = rt * 32, nt0 = grp * gbase + (grp < gextra ? grp : gextra);
+    const int K = a.K, Np = a.Np, d0 = a.d0;
+    const int nblk = (K + 31) >> 5, bs = nblk >> 2, rem = nblk & 3;
+    const int nb = bs + (w >= 4 - rem ? 1 : 0);
+    const int b0 = w * bs + (w > 4 - rem ? w - (4 - rem) : 0);
+    AST(0);
+    // ---- loads in the order of need: the input rows, the layer-1 columns of this wave's blocks, the W2 groups of tile 0
+    float xin[7];
+    {
+        const long long row = m0 + l31 < a.rows ? m0 + l31 : a.rows - 1;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int d = d_slot(s, h);
+            const float v = a.obs[row * d0 + (d < d0 ? d : 0)];
+            xin[s] = d < d0 ? v : (d == d0 ? 1.0f : 0.f);  // column d0: the bias row
+        }
+    }
+    float w1[4][8];
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+        const int blk = b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.W1 + ((((long long)blk * 2 + q) * 2 + h) * 32 + l31) * 4);
+            w1[bi][4 * q + 0] = v.x; w1[bi][4 * q + 1] = v.y; w1[bi][4 * q + 2] = v.z; w1[bi][4 * q + 3] = v.w;
+        }
+    }
+    float4 bq[2][4][4];
+    const int lane_off = (h * Np + l31) * 4;
+    auto fetch_group = [&](int buf, int t, int bi, int rq) {  // one W2 group (8 hidden-1 units x 32 columns) of column tile t
+        // wave-uniform base (scalar registers) + one per-lane offset shared by every group: no vector address arithmetic per load
+        const int nt = nt0 + t < a.tiles_n ? nt0 + t : a.tiles_n - 1;
+        const int u0 = (b0 + (bi < nb ? bi : (nb > 0 ? nb - 1 : 0))) * 32;
+        const float *gp = a.W2p + ((long long)(u0 / 4 + 2 * rq) * Np + nt * 32) * 4;
+        bq[buf][bi][rq] = *reinterpret_cast<const float4 *>(gp + lane_off);
+    };
+    // head kernels and biases of this workgroup's column tiles: requested now, staged into LDS behind tile 0's MFMAs
+    float whv[(ANT * DFH * 32 + 255) / 256], b2v = 0.f;
+#pragma unroll
+    for (int i = 0; i < (ANT * DFH * 32 + 255) / 256; ++i) {
+        const int e = tid + 256 * i;
+        const int t = e / (DFH * 32), c = (e / 32) % DFH, col = (nt0 + t) * 32 + (e & 31);
+        const bool ok = e < ANT * DFH * 32 && c < 2 * a.act && col < a.h2 && t < ntiles;
+        const float *p = c < a.act ? a.wmu : a.wls;
+        const float v = p[ok ? (long long)col * a.act + (c < a.act ? c : c - a.act) : 0];
+        whv[i] = ok ? v : 0.f;
+    }
+    {
+        const int t = tid >> 5, col = (nt0 + t) * 32 + (tid & 31);
+        const bool ok = tid < ANT * 32 && col < Np && t < ntiles;
+        const float v = a.b2[ok ? col : 0];  // (pads of b2 are zero)
+        b2v = ok ? v : 0.f;
+    }
+    AST(1);
+    // ---- layer 1 of this wave's blocks, once
+    floatx16 x1[4];
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x1[bi][r] = 0.f;
+        if (bi < nb) {  // wave-uniform
+#pragma unroll
+            for (int s = 0; s < NS; ++s) x1[bi] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[bi][s], xin[s], x1[bi], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x1[bi][r] = relu1(x1[bi][r]);
+        }
+    }
+    // tile 0's W2 groups: requested behind the layer-1 MFMAs (which wait for the input rows and layer-1 columns only)
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) fetch_group(0, 0, bi, rq);
+    AST(2);
+    auto stage_heads = [&]() {
+#pragma unroll
+        for (int i = 0; i < (ANT * DFH * 32 + 255) / 256; ++i) {
+            const int e = tid + 256 * i;
+            if (e < ANT * DFH * 32) (&s_wh[0][0][0])[e] = whv[i];
+        }
+        if (tid < ANT * 32) (&s_b2[0][0])[tid] = b2v;
+    };
+    // ---- the column tiles
+    const int r = tid & 31, cg = tid >> 5;
+#pragma unroll
+    for (int t = 0; t < ANT; ++t) {
+        if (t < ntiles) {  // block-uniform
+            floatx16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+                if (bi < nb) {
+                    const int u0 = (b0 + bi) * 32;
+                    const int nrq = (K - u0 >= 32) ? 4 : ((K - u0 + 7) >> 3);
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        if (rq < nrq) {
+                            const float4 b = bq[t & 1][bi][rq];
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 0], b.x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 1], b.y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 2], b.z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 3], b.w, acc, 0, 0, 0);
+                        }
+                        if (t + 1 < ANT) {  // the same group of the next column tile, requested between this group's MFMAs and the next's
+                            __builtin_amdgcn_sched_barrier(0);
+                            fetch_group((t + 1) & 1, t + 1, bi, rq);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else if (t + 1 < ANT) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) fetch_group((t + 1) & 1, t + 1, bi, rq);
+                }
+            }
+            AST(3 + 5 * t);
+            if (t == 0) stage_heads();  // requested behind tile 0's MFMAs, stored before the first barrier
+            // split-K combine, bias + relu, head partials (LDS tiles double-buffered by tile parity: two barriers per tile)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[t & 1][w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[q];
+            AST(4 + 5 * t);
+            __syncthreads();
+            AST(5 + 5 * t);
+            {
+                const float4 p0 = *reinterpret_cast<const float4 *>(&red[t & 1][0][r][4 * cg]), p1 = *reinterpret_cast<const float4 *>(&red[t & 1][1][r][4 * cg]);
+                const float4 p2 = *reinterpret_cast<const float4 *>(&red[t & 1][2][r][4 * cg]), p3 = *reinterpret_cast<const float4 *>(&red[t & 1][3][r][4 * cg]);
+                const float4 bb = *reinterpret_cast<const float4 *>(&s_b2[t][4 * cg]);
+                float4 v;
+                v.x = fmaxf((((p0.x + p1.x) + p2.x) + p3.x) + bb.x, 0.f);
+                v.y = fmaxf((((p0.y + p1.y) + p2.y) + p3.y) + bb.y, 0.f);
+                v.z = fmaxf((((p0.z + p1.z) + p2.z) + p3.z) + bb.z, 0.f);
+                v.w = fmaxf((((p0.w + p1.w) + p2.w) + p3.w) + bb.w, 0.f);
+                *reinterpret_cast<float4 *>(&red2[t & 1][r][4 * cg]) = v;
+            }
+            AST(6 + 5 * t);
+            __syncthreads();
+            if (cg < 2 * a.act) {
+                float sum = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(&red2[t & 1][r][4 * c4]), y = *reinterpret_cast<const float4 *>(&s_wh[t][cg][4 * c4]);
+                    sum = fmaf(x.x, y.x, sum); sum = fmaf(x.y, y.y, sum); sum = fmaf(x.z, y.z, sum); sum = fmaf(x.w, y.w, sum);
+                }
+                if (m0 + r < a.rows) a.hp[((long long)cg * a.rows + m0 + r) * DNT + nt0 + t] = sum;
+            }
+            AST(7 + 5 * t);
+        }
+    }
 }
 
 // ==========================================================================================
@@ -575,7 +759,6 @@ struct DGJobs {
     DGJob job[MAX_DG_JOBS];
 };
 
-__device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 template <int GMAX>
 __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, int ts3, int ts4, int ts5, int ts6, int ts7, int kid, DGJobs jobs) {
