@@ -244,6 +244,32 @@ def stage_measurements(args, opt, rb, roll, d):
                            "frac_of_hbm_peak": K * B * 164 / t / 1e9 / PEAK_HBM_GBPS,
                            "what": "the block of batches a shard owner draws for one step of a remote learner (configs 3/4): "
                                    "one sequential MT19937 index draw + one gather sweep"}
+    try:   # example/dsac.py's own algorithm (SAC-v: policy + twin Q + V + target V, batch 100, hidden 300 x 2, lr 1e-3)
+        from distributed_drl_amd.agent import Model
+
+        class A:
+            pass
+        A.obs_dim, A.act_dim, A.ac_kwargs, A.gamma, A.polyak, A.lr, A.alpha, A.batch_size, A.seed, A.max_ep_len = \
+            8, 2, dict(hidden_sizes=[300, 300]), 0.99, 0.995, 1e-3, 0.2, 100, 0, 1000
+        m = Model(A)
+        bv = {k: torch.randn(100, w, device="cuda").squeeze(-1) if w > 1 else torch.randn(100, device="cuda")
+              for k, w in (("obs1", 8), ("obs2", 8), ("acts", 2), ("rews", 1), ("done", 1))}
+        bv["done"] = (torch.rand(100, device="cuda") < 0.01).float()
+        t = timed(lambda: m.train_device(bv), 300)
+        out["sac_v_update"] = {"batch": 100, "hidden": [300, 300], "us": t * 1e6, "updates_per_s": 1.0 / t,
+                               "what": "one Model.train step of example/model.py's SAC-v on a device batch, eager launches "
+                                       "(the generic multi-launch path: the direct-operand path covers the SAC1 variant only)"}
+        from distributed_drl_amd.partition import _Loop
+        rbv = d.ReplayBufferSAC1(8, 2, 100000, seed=3)
+        fill_replay(rbv, 100000, 77)
+        lp = _Loop(m, rbv, 16)
+        lp.run(64)
+        t = timed(lambda: lp.run(320), 5, warm=1) / 320
+        out["sac_v_update"].update({"loop_us": t * 1e6, "loop_updates_per_s": 1.0 / t,
+                                    "loop_what": "sample_batch(100) + train inside the graph-captured device loop (16 updates per graph)"})
+        del lp, m, rbv
+    except Exception as e:  # noqa
+        out["sac_v_update"] = {"error": repr(e)[:200]}
     if args.cfg5_capacity > 0:
         try:
             obs_dim, B5, cap = 84 * 84 * 4, 512, int(args.cfg5_capacity)
