@@ -709,7 +709,7 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
 // Envelope of the direct-operand path (sac1_direct.h); everything else takes the generic kernels.
 static bool direct_ok(const ddrl_sac1_config_t &c) {
     return c.variant == DDRL_SAC1 && c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * DNT &&
-           c.obs_dim + c.act_dim <= 12 && 2 * c.act_dim <= DFH && c.act_dim <= 4 && c.batch % 32 == 0 && c.batch <= 32768 &&
+           c.obs_dim + c.act_dim <= 12 && 2 * c.act_dim <= DFH && c.act_dim <= 4 && c.batch <= 32768 &&
            getenv("DDRL_SAC1_GENERIC") == nullptr;
 }
 
@@ -891,7 +891,10 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     h->fused = direct_ok(*cfg);
     h->L = make_layout(*cfg, false, h->fused);
     const Layout &L = h->L;
-    const int B = cfg->batch, o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
+    // direct-operand path: every row-indexed buffer holds a whole number of 32-row tiles; rows past the batch are padding
+    // (zero inputs, no loss terms, zero upstream gradients) and means run over the Bv valid rows
+    const int Bv = cfg->batch, B = h->fused ? (int)rup32(Bv) : Bv;
+    const int o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
     const size_t NT = (size_t)L.total_int;
     const int Kp1 = L.Kp1, Np2 = L.Np2;
     h->Lp1 = rup32(h1 + 1); h->Lp2 = rup32(h2 + 1);  // activation images keep room for the ones column
@@ -1059,7 +1062,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 F.scale = (float)cfg->act_scale;
                 F.act0 = h->act0; F.act2 = h->act2; F.logp0 = h->logp0; F.logp1 = h->logp1; F.save0 = h->save0;
                 F.php1 = h->hp + 1 * HP; F.pbmu1 = Pm + L.pi_bmu; F.pbls1 = Pm + L.pi_bls; F.peps1 = h->in[st][6];
-                F.noise_on = 0; F.n_each = B * a; F.noise_seed = 0;
+                F.noise_on = 0; F.n_each = Bv * a; F.Bv = Bv; F.noise_seed = 0;
                 F.e0 = h->in[st][5]; F.e1 = h->in[st][6]; F.e2 = h->in[st][7]; F.opt = h->opt;
             };
             auto pij = [&](const float *P, int ev) {
@@ -1101,7 +1104,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             // ---- backward launch 1: the three Q dgrads (slot 2 first: its dQ/da partials are what the next launch waits for)
             DGJobs &Q = h->dg_bq[st];
             Q = DGJobs{};
-            Q.hp = h->hp; Q.B = B;
+            Q.hp = h->hp; Q.B = B; Q.Bv = Bv;
             Q.b3q1 = Pm + L.q_b3[0]; Q.b3q2 = Pm + L.q_b3[1]; Q.b3q1t = Pt + L.q_b3[0]; Q.b3q2t = Pt + L.q_b3[1];
             Q.rew = h->in[st][3]; Q.done = h->in[st][4]; Q.logp0 = h->logp0; Q.logp1 = h->logp1;
             Q.q1o = h->q1o; Q.q2o = h->q2o; Q.dq = h->dq; Q.loss_part = h->loss_part;
@@ -1110,7 +1113,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 DGJob j{};
                 j.type = DG_DGRAD_Q; j.M = B; j.N = h1; j.K = h2; j.slot = slot;
                 j.A = h->H2c4 + img * H2C; j.lda = B; j.B = h->c4_q[q]; j.ldb = Kp1;
-                j.gw = Pm + L.q_W3[q]; j.gdq = nullptr; j.gconst = -1.0f / (float)B;
+                j.gw = Pm + L.q_W3[q]; j.gdq = nullptr; j.gconst = -1.0f / (float)Bv;
                 j.mask = h->H1r4 + img * H1I; j.ldmask = h->Lp1; j.C = C; j.ldc = h->Lp1; j.adam_off = -1;
                 return j;
             };
@@ -1141,7 +1144,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         {   // ---- backward launch 2: policy-head backward tiles, loss means, Q layer-2 + head wgrads (optimizer in the epilogue)
             DGJobs &M = h->dg_mid;
             M = DGJobs{};
-            M.B = B; M.ad = ctx;
+            M.B = B; M.Bv = Bv; M.ad = ctx;
             DGJob rc{};
             rc.type = DG_ROWS_C; rc.M = B; rc.N = h2; rc.K = 0; rc.nact = a; rc.adam_off = -1;
             rc.h2c4 = h->H2c4; rc.dap = h->da_part; rc.nparts = (h1 + 31) / 32; rc.save0 = h->save0;
@@ -1161,7 +1164,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         {   // ---- backward launch 3: policy dgrad (+ layer-1 wgrad partials), policy wgrads, Q layer-1 wgrads
             DGJobs &P = h->dg_pi;
             P = DGJobs{};
-            P.B = B; P.ad = ctx;
+            P.B = B; P.Bv = Bv; P.ad = ctx;
             DGJob d{};
             d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->dzpi_c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
             d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = nullptr; d.ldc = h->Lp1; d.adam_off = -1;

@@ -86,7 +86,8 @@ struct DFArgs {
     float scale;
     float *act0, *act2, *logp0, *logp1, *save0;
     const float *php1, *pbmu1, *pbls1, *peps1;  // pi_main @ x2: only its log-prob is needed (actor_learner.py:62)
-    int noise_on, n_each;
+    int noise_on, n_each;    // n_each = valid rows * act (element index of a flat [3][rows * act] fill)
+    int Bv;                  // valid rows: the batch; rows up to the next multiple of 32 are padding (zero inputs, no loss terms)
     uint32_t noise_seed;
     float *e0, *e1, *e2;
     const OptState *opt;
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
                 const int rr = e / per_row, q = e - rr * per_row;
                 const int wch = q / act, c = q - wch * act;
                 const int k = (m0 + rr) * act + c;
-                (wch == 0 ? a.e0 : (wch == 1 ? a.e1 : a.e2))[k] = normal_at(a.noise_seed, nbase + (unsigned long long)wch * a.n_each + k);
+                if (m0 + rr < a.Bv) (wch == 0 ? a.e0 : (wch == 1 ? a.e1 : a.e2))[k] = normal_at(a.noise_seed, nbase + (unsigned long long)wch * a.n_each + k);
             }
         }
 
@@ -755,7 +756,7 @@ struct DGJobs {
     const float *rew, *done, *logp0, *logp1;
     float *q1o, *q2o, *dq, *loss_part;
     float alpha, gamma;
-    int B;
+    int B, Bv;         // rows of every image (a multiple of 32), valid rows (the batch: means and loss terms run over these)
     DGJob job[MAX_DG_JOBS];
 };
 
@@ -784,15 +785,15 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int type = jb.type;
-    const int Bn = jobs.B;
+    const int Bn = jobs.B, Bv = jobs.Bv;
 
     if (type == DG_LOSS) {
         // reduce_mean over the batch: per-row terms summed in a fixed order (lane-strided partial sums, then the xor tree)
         if (w != 0) return;
         float s3[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int b0 = 0; b0 < Bn; b0 += 64) {
+        for (int b0 = 0; b0 < Bv; b0 += 64) {
             const int b = b0 + lane;
-            const bool ok = b < Bn;
+            const bool ok = b < Bv;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float v = jb.loss_part[(ok ? b : 0) * jb.nl + (c < jb.nl ? c : 0)];
@@ -802,7 +803,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float tot = wave_sum(s3[c]);
-            const float mean = tot / (float)Bn;
+            const float mean = tot / (float)Bv;
             if (lane == 0 && c < jb.nl) jb.losses[c] = c == 0 ? mean : 0.5f * mean;
         }
         return;
@@ -845,7 +846,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float av = sv[c].x, std = sv[c].y, tt = sv[c].z, e = sv[c].w;
-            const float glp = jb.alpha / (float)Bn;  // d pi_loss / d logp_pi
+            const float glp = row < Bv ? jb.alpha / (float)Bv : 0.f;  // d pi_loss / d logp_pi (padding rows carry no loss)
             const float om = 1.0f - av * av;
             const float cl = fminf(fmaxf(om, 0.f), 1.f);
             const float du = (ga[c] * jb.scale) * om + glp * ((2.0f * av * om) / (cl + 1e-6f));
@@ -1006,7 +1007,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     epilogue_operands();
 #endif
     // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
-    float dqr = jb.gconst;
+    float dqr = m0 + l31 < Bv ? jb.gconst : 0.f;
     if (has_gen) { s_gw[tid] = gv0; s_gw[tid + 256] = gv1; }
     if (has_gen && !need_q) __syncthreads();
     if (type == DG_DGRAD_Q) {
@@ -1027,7 +1028,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                 const float vb = minq - jobs.alpha * lp1;                       // :62
                 const float backup = rew + (jobs.gamma * (1.0f - done)) * vb;   // :63
                 const float e1 = backup - q1v, e2 = backup - q2v;
-                const float inv_b = 1.0f / (float)Bn;
+                const float inv_b = row < Bv ? 1.0f / (float)Bv : 0.f;  // padding rows: no loss terms, zero upstream gradients
                 const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b;
                 if (lane < 32) {
                     s_g[l31] = jb.slot == 0 ? dq1 : dq2;

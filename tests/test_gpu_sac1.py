@@ -383,10 +383,11 @@ def test_sqn_learner_matches_oracle(ddrl, obs, acts, hid, batch):
 
 
 @pytest.mark.parametrize("obs,act,hid,batch", [(6, 1, (64, 96), 64), (9, 3, (128, 100), 96), (8, 4, (512, 512), 32), (3, 2, (36, 8), 32),
-                                               (8, 2, (400, 300), 128)])
+                                               (8, 2, (400, 300), 128), (8, 2, (400, 300), 100), (8, 2, (300, 300), 37), (5, 3, (64, 40), 1)])
 def test_fused_envelope_shapes(ddrl, obs, act, hid, batch):
     """Shapes inside the fused path's envelope other than the headline one (1-4 action dims, K ranges that are not
-    multiples of the 32-unit layer-1 blocks, 1 to 16 column tiles, one sub-chunk per wave): first update vs the
+    multiples of the 32-unit layer-1 blocks, 1 to 16 column tiles, one sub-chunk per wave, batches that are not a
+    whole number of 32-row tiles — the padding rows must carry no loss and no gradient): first update vs the
     float64 oracle — losses 1e-5 relative, gradients, parameters — and the per-row outputs."""
     from distributed_drl_amd import _lib
     import os
