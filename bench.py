@@ -258,7 +258,7 @@ def stage_measurements(args, opt, rb, roll, d):
         t = timed(lambda: m.train_device(bv), 300)
         out["sac_v_update"] = {"batch": 100, "hidden": [300, 300], "us": t * 1e6, "updates_per_s": 1.0 / t,
                                "what": "one Model.train step of example/model.py's SAC-v on a device batch, eager launches "
-                                       "(the generic multi-launch path: the direct-operand path covers the SAC1 variant only)"}
+                                       "(direct-operand kernels, five launches; the 100 rows are padded to four 32-row tiles)"}
         from distributed_drl_amd.partition import _Loop
         rbv = d.ReplayBufferSAC1(8, 2, 100000, seed=3)
         fill_replay(rbv, 100000, 77)

@@ -668,7 +668,7 @@ static Layout make_layout(const ddrl_sac1_config_t &c, bool pi_only, bool direct
     }
     L.v_W1 = L.v_b1 = L.v_W2 = L.v_b2 = L.v_W3 = L.v_b3 = -1;
     if (!pi_only && c.variant == DDRL_SAC_V) {  // vf_mlp(x): obs -> h1 -> h2 -> 1 (example/core.py:112-113)
-        add(L.v_W1, o * h1, false); add(L.v_b1, h1, true); add(L.v_W2, h1 * h2, false); add(L.v_b2, h2, true);
+        add_w1(L.v_W1, L.v_b1, o); add_w2(L.v_W2, L.v_b2);
         add(L.v_W3, h2, false); add(L.v_b3, 1, true);
     }
     L.total_int = in;
@@ -708,7 +708,7 @@ static int check_cfg(const ddrl_sac1_config_t *c) {
 
 // Envelope of the direct-operand path (sac1_direct.h); everything else takes the generic kernels.
 static bool direct_ok(const ddrl_sac1_config_t &c) {
-    return c.variant == DDRL_SAC1 && c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * DNT &&
+    return c.hidden1 % 4 == 0 && c.hidden2 % 4 == 0 && c.hidden1 <= 512 && c.hidden2 <= 32 * DNT &&
            c.obs_dim + c.act_dim <= 12 && 2 * c.act_dim <= DFH && c.act_dim <= 4 && c.batch <= 32768 &&
            getenv("DDRL_SAC1_GENERIC") == nullptr;
 }
@@ -748,7 +748,8 @@ struct ddrl_sac1 {
     // direct-path activations (x4 images, see sac1_direct.h) and the dgrad images of the main layer-2 kernels
     int Lp1, Lp2;
     float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq;
-    float *c4_pi[2], *c4_q[2];
+    float *c4_pi[2], *c4_q[3];   // c4_q[2]: V (SAC-v)
+    float *xv_r4;                // SAC-v: the [x | 1] image of V's layer-1 wgrad
     int *part_cnt;       // arrival counters of the policy layer-1 partials (one per column tile)
     int sh_cur;          // which copy of the policy dgrad image is current (the optimizer epilogue writes the other one)
     bool fuse_apply;     // this launch_grads also applies the optimizer (Adam in the wgrad epilogues)
@@ -868,6 +869,169 @@ static int build_sacv(ddrl_sac1 *h) {
     return DDRL_OK;
 }
 
+// Job tables of the SAC-v update on the direct-operand kernels (sac1_direct.h).  B = rows of every image (whole 32-row
+// tiles), Bv = the batch.  Evaluations (head-partial slots): 0 pi(x) 1 q1(x,a) 2 q2(x,a) 3 v(x) 4 v_targ(x2) |
+// phase 1: 5 q1(x,pi) 6 q2(x,pi).  Image slots — H1r4 / H2c4: 0 pi 1 q1(x,a) 2 q2(x,a) 3 q1(x,pi) 4 v;  H2r4: 0 pi 1 q1 2 q2 3 v;
+// dZ1r4: 0 q1 1 q2 2 v.  Network ids of the forward pack field: 0 policy, 1 q1, 2 q2, 3 v (the value networks follow the
+// policy at equal distances in a parameter buffer).
+static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
+    const ddrl_sac1_config_t *cfg = &h->cfg;
+    const Layout &L = h->L;
+    const int o = cfg->obs_dim, a = cfg->act_dim, h1 = cfg->hidden1, h2 = cfg->hidden2;
+    const int Kp1 = L.Kp1, Np2 = L.Np2, nt2 = (h2 + 31) / 32;
+    const float *Pm = h->main_p, *Pt = h->target_p, *S = h->slab;
+    DDRL_REQUIRE(L.v_W1 - L.q_W1[1] == L.q_W1[1] - L.q_W1[0], "internal: the value networks must sit at equal distances");
+    h->fused_l1_wgrad = true;
+    h->sh_cur = 0;
+    const long long HP = (long long)DFH * B * DNT;
+    const long long H1I = (long long)B * h->Lp1, H2C = (long long)Np2 * B, H2R = (long long)B * h->Lp2;
+    auto steps = [](int D) { return D + 1 <= 8 ? 4 : 4 + (D + 1 - 8 + 1) / 2; };
+    const long long vW1[3] = {L.q_W1[0], L.q_W1[1], L.v_W1}, vW2[3] = {L.q_W2[0], L.q_W2[1], L.v_W2}, vb2[3] = {L.q_b2[0], L.q_b2[1], L.v_b2};
+    const long long vW3[3] = {L.q_W3[0], L.q_W3[1], L.v_W3};
+    for (int st = 0; st < 2; ++st) {
+        auto head = [&](DFHead &d) {
+            d = DFHead{};
+            d.base = S; d.tiles_m = B / 32; d.tpj = (B / 32) * nt2; d.K = h1; d.Np = Np2; d.B = B; d.d0 = o;
+            d.x_off = (int)(h->in[st][0] - S);
+            d.main_off = (int)(Pm - S); d.targ_off = (int)(Pt - S); d.npi = (int)L.q_W1[0]; d.perq = (int)(L.q_W1[1] - L.q_W1[0]);
+            d.hp_off = (int)(h->hp - S);
+        };
+        auto args = [&](DFArgs &F, int njobs) {
+            F = DFArgs{};
+            F.njobs = njobs; F.tiles_n = nt2; F.act = a; F.Lp1 = h->Lp1; F.Lp2 = h->Lp2; F.h2 = h2;
+            F.scale = (float)cfg->act_scale;
+            F.act0 = h->act0; F.act2 = h->act2; F.logp0 = h->logp0; F.logp1 = h->logp1; F.save0 = h->save0;
+            F.php1 = nullptr; F.pbmu1 = Pm + L.pi_bmu; F.pbls1 = Pm + L.pi_bls; F.peps1 = h->in[st][6];
+            F.pev_pack = 0;   // both phase-1 jobs take the action sampled by pi(x)
+            F.noise_on = 0; F.n_each = Bv * a; F.Bv = Bv; F.noise_seed = 0;
+            F.e0 = h->in[st][5]; F.e1 = h->in[st][6]; F.e2 = h->in[st][7]; F.opt = h->opt;
+        };
+        auto vj = [&](const float *P, int q, int ev) {   // a value network (q = 0, 1: Q; 2: V)
+            DFJob j{};
+            j.b2 = P + vb2[q]; j.wh0 = P + vW3[q]; j.wh1 = j.wh0; j.nh = 1; j.hsplit = 1; j.hstride = 1;
+            j.hp = h->hp + ev * HP;
+            return j;
+        };
+        const int ns_pi = steps(o) - 4, ns_q = steps(o + a) - 4;
+        DFHead &HA = h->fh_a[st], &HB = h->fh_b[st];
+        DFArgs &FA = h->f_a[st], &FB = h->f_b[st];
+        head(HA); args(FA, 5);
+        {
+            DFJob j{};
+            j.b2 = Pm + L.pi_b2; j.wh0 = Pm + L.pi_Wmu; j.wh1 = Pm + L.pi_Wls; j.nh = 2 * a; j.hsplit = a; j.hstride = a; j.hp = h->hp;
+            j.H2c4 = h->H2c4; j.H2r4 = h->H2r4; j.H1r4 = h->H1r4; j.aug = h->xp; j.aug_ld = h->ldxp;
+            FA.job[0] = j;
+        }
+        FA.job[1] = vj(Pm, 0, 1); FA.job[1].H2c4 = h->H2c4 + 1 * H2C; FA.job[1].H2r4 = h->H2r4 + 1 * H2R; FA.job[1].H1r4 = h->H1r4 + 1 * H1I;
+        FA.job[1].xr4 = h->xa_r4;
+        FA.job[2] = vj(Pm, 1, 2); FA.job[2].H2c4 = h->H2c4 + 2 * H2C; FA.job[2].H2r4 = h->H2r4 + 2 * H2R; FA.job[2].H1r4 = h->H1r4 + 2 * H1I;
+        FA.job[3] = vj(Pm, 2, 3); FA.job[3].H2c4 = h->H2c4 + 4 * H2C; FA.job[3].H2r4 = h->H2r4 + 3 * H2R; FA.job[3].H1r4 = h->H1r4 + 4 * H1I;
+        FA.job[3].xr4 = h->xv_r4;
+        FA.job[4] = vj(Pt, 2, 4);
+        head(HB); args(FB, 2);
+        {
+            auto pk = [](int ns, int x2, int targ, int net) { return ns | (x2 << 2) | (targ << 3) | (net << 4); };
+            HA.pack = pk(ns_pi, 0, 0, 0) | (pk(ns_q, 0, 0, 1) << 6) | (pk(ns_q, 0, 0, 2) << 12) | (pk(ns_pi, 0, 0, 3) << 18) | (pk(ns_pi, 1, 1, 3) << 24);
+            HB.pack = pk(ns_q, 0, 0, 1) | (pk(ns_q, 0, 0, 2) << 6);
+        }
+        auto from_pi = [&](DFJob &j, int side) {
+            j.php = h->hp; j.pbmu = Pm + L.pi_bmu; j.pbls = Pm + L.pi_bls; j.peps = h->in[st][5]; j.side = side;
+        };
+        FB.job[0] = vj(Pm, 0, 5); from_pi(FB.job[0], 1);
+        FB.job[0].H2c4 = h->H2c4 + 3 * H2C; FB.job[0].H1r4 = h->H1r4 + 3 * H1I;
+        FB.job[1] = vj(Pm, 1, 6); from_pi(FB.job[1], 0);
+        // ---- backward launch 1: the four value dgrads (slot 2 first: its dQ/da partials are what the next launch waits for)
+        DGJobs &Q = h->dg_bq[st];
+        Q = DGJobs{};
+        Q.hp = h->hp; Q.B = B; Q.Bv = Bv; Q.sacv = 1; Q.q_ev0 = 1; Q.q_nev = 6;
+        Q.b3q1 = Pm + L.q_b3[0]; Q.b3q2 = Pm + L.q_b3[1]; Q.b3q1t = Pm + L.v_b3; Q.b3q2t = Pt + L.v_b3;
+        Q.rew = h->in[st][3]; Q.done = h->in[st][4]; Q.logp0 = h->logp0; Q.logp1 = h->logp1;
+        Q.q1o = h->q1o; Q.q2o = h->q2o; Q.vo = h->vo; Q.vto = h->vto; Q.dq = h->dq; Q.loss_part = h->loss_part;
+        Q.alpha = (float)cfg->alpha; Q.gamma = (float)cfg->gamma;
+        auto dq_job = [&](int slot, int img, int q, float *C) {
+            DGJob j{};
+            j.type = DG_DGRAD_Q; j.M = B; j.N = h1; j.K = h2; j.slot = slot;
+            j.A = h->H2c4 + img * H2C; j.lda = B; j.B = h->c4_q[q]; j.ldb = Kp1;
+            j.gw = Pm + vW3[q]; j.gdq = nullptr; j.gconst = -1.0f / (float)Bv;
+            j.mask = h->H1r4 + img * H1I; j.ldmask = h->Lp1; j.C = C; j.ldc = h->Lp1; j.adam_off = -1;
+            return j;
+        };
+        {
+            DGJob j = dq_job(2, 3, 0, nullptr);
+            j.wa = Pm + L.q_W1[0]; j.wa_d0 = o; j.da_part = h->da_part; j.nact = a;
+            dg_add(Q, j);
+        }
+        dg_add(Q, dq_job(0, 1, 0, h->dZ1r4));
+        dg_add(Q, dq_job(1, 2, 1, h->dZ1r4 + H1I));
+        dg_add(Q, dq_job(3, 4, 2, h->dZ1r4 + 2 * H1I));
+    }
+    float *G = h->grad;
+    const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, nullptr, L.n_pi_int,
+                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
+                      (float)cfg->polyak, (float)(1.0 - cfg->polyak), 0u};
+    auto wgrad_j4 = [&](const float *A, const float *Bm, long long w_off, long long b_off, float *shadow) {
+        DGJob j{};
+        j.type = DG_WGRAD_J4; j.M = h1 + 1; j.N = h2; j.K = B;
+        j.A = A; j.lda = h->Lp1; j.B = Bm; j.ldb = h->Lp2;
+        j.adam_off = w_off; j.ldc = Np2; j.bias_off = b_off; j.bias_row = h1; j.shadow = shadow; j.ld_sh = Kp1;
+        return j;
+    };
+    auto wgrad_rm = [&](const float *A, int lda, int M, const float *Bm, int ldb, int N, long long off) {
+        DGJob j{};
+        j.type = DG_WGRAD_RM; j.M = M; j.N = N; j.K = B; j.A = A; j.lda = lda; j.B = Bm; j.ldb = ldb; j.adam_off = off; j.ldc = N;
+        return j;
+    };
+    const int img1[3] = {1, 2, 4}, img2r[3] = {1, 2, 3};   // H1r4 / H2r4 slots of q1(x,a), q2(x,a), v(x)
+    {   // ---- backward launch 2: policy-head backward tiles, loss means, layer-2 + head wgrads of the three value networks
+        DGJobs &M = h->dg_mid;
+        M = DGJobs{};
+        M.B = B; M.Bv = Bv; M.ad = ctx;
+        DGJob rc{};
+        rc.type = DG_ROWS_C; rc.M = B; rc.N = h2; rc.K = 0; rc.nact = a; rc.adam_off = -1;
+        rc.h2c4 = h->H2c4; rc.dap = h->da_part; rc.nparts = (h1 + 31) / 32; rc.save0 = h->save0;
+        rc.wmu = Pm + L.pi_Wmu; rc.wls = Pm + L.pi_Wls; rc.dz_c4 = h->dzpi_c4; rc.dz_r4 = h->dzpi_r4; rc.dhead_r4 = h->dhead_r4;
+        rc.ld_r4 = h->Lp2; rc.alpha = (float)cfg->alpha; rc.scale = (float)cfg->act_scale;
+        dg_add(M, rc);
+        DGJob ls{};
+        ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 4;
+        dg_add(M, ls);
+        for (int q = 0; q < 3; ++q) {
+            DGJob j = wgrad_j4(h->H1r4 + img1[q] * H1I, h->H2r4 + img2r[q] * H2R, vW2[q], vb2[q], h->c4_q[q]);
+            j.bgen = 1; j.gw = Pm + vW3[q]; j.gdq = h->dq + (long long)q * B;
+            dg_add(M, j);
+        }
+        for (int q = 0; q < 3; ++q) dg_add(M, wgrad_rm(h->H2r4 + img2r[q] * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, vW3[q]));
+    }
+    {   // ---- backward launch 3: policy dgrad (+ layer-1 wgrad partials), policy wgrads, layer-1 wgrads of the value networks
+        DGJobs &P = h->dg_pi;
+        P = DGJobs{};
+        P.B = B; P.Bv = Bv; P.ad = ctx;
+        DGJob d{};
+        d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->dzpi_c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
+        d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = nullptr; d.ldc = h->Lp1; d.adam_off = -1;
+        d.part_x = h->xp; d.part = h->part; d.part_nk = o + 1; d.part_ldx = h->ldxp;
+        d.part_cnt = h->part_cnt; d.part_adam_off = L.pi_W1;
+        dg_add(P, d);
+        dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));
+        dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4, 32, a, L.pi_Wmu));
+        dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4 + (long long)a * 4, 32, a, L.pi_Wls));
+        for (int q = 0; q < 3; ++q) {
+            DGJob j = wgrad_rm(q < 2 ? h->xa_r4 : h->xv_r4, 32, (q < 2 ? o + a : o) + 1, h->dZ1r4 + q * H1I, h->Lp1, h1, vW1[q]);
+            j.type = DG_WGRAD_W1Y;
+            dg_add(P, j);
+        }
+    }
+    h->rc = RowsC{};
+    h->rc.nl = 4;
+    h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, L.total_int, L.n_pi_int, 0,
+                     (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
+                     (float)cfg->polyak, (float)(1.0 - cfg->polyak),
+                     h->part, L.pi_W1 / 4, (long long)(o + 1) * h1 / 4, (long long)(o + 1) * h1 / 4, (B + 31) / 32, 0u};
+    h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
+    h->fuse_apply = false; h->sample_armed = false;
+    return DDRL_OK;
+}
+
 extern "C" {
 
 int ddrl_sac1_param_counts(const ddrl_sac1_config_t *cfg, int64_t *n_pi, int64_t *n_q) {
@@ -920,13 +1084,14 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         ALLOC(H1, (size_t)NEVAL * B * h->ldh1); ALLOC(H2, (size_t)NEVAL * B * h->ldh2);
         ALLOC(dZ2, (size_t)5 * B * h2); ALLOC(dZ1, (size_t)5 * B * h1);
     } else {
-        ALLOC(H1r4, (size_t)4 * B * h->Lp1); ALLOC(H2c4, (size_t)4 * Np2 * B); ALLOC(H2r4, (size_t)3 * B * h->Lp2);
-        ALLOC(dZ1r4, (size_t)2 * B * h->Lp1); ALLOC(dzpi_c4, (size_t)Np2 * B); ALLOC(dzpi_r4, (size_t)B * h->Lp2);
-        ALLOC(dhead_r4, (size_t)B * 32); ALLOC(xa_r4, (size_t)B * 32); ALLOC(da_part, (size_t)16 * B * 4); ALLOC(dq, (size_t)2 * B + 256);
-        for (int i = 0; i < 2; ++i) {
-            items.push_back(Item{&h->c4_pi[i], reserve((size_t)Np2 * Kp1)});
-            items.push_back(Item{&h->c4_q[i], reserve((size_t)Np2 * Kp1)});
-        }
+        // image slots: SAC1 — H1r4 / H2c4: pi(x) q1(x,a) q2(x,a) q1(x,pi); H2r4: pi q1 q2; dZ1r4: q1 q2.  SAC-v adds V to each.
+        const int xv = cfg->variant == DDRL_SAC_V ? 1 : 0;
+        ALLOC(H1r4, (size_t)(4 + xv) * B * h->Lp1); ALLOC(H2c4, (size_t)(4 + xv) * Np2 * B); ALLOC(H2r4, (size_t)(3 + xv) * B * h->Lp2);
+        ALLOC(dZ1r4, (size_t)(2 + xv) * B * h->Lp1); ALLOC(dzpi_c4, (size_t)Np2 * B); ALLOC(dzpi_r4, (size_t)B * h->Lp2);
+        ALLOC(dhead_r4, (size_t)B * 32); ALLOC(xa_r4, (size_t)B * 32); ALLOC(xv_r4, (size_t)B * 32); ALLOC(da_part, (size_t)16 * B * 4);
+        ALLOC(dq, (size_t)3 * B + 256);
+        for (int i = 0; i < 2; ++i) items.push_back(Item{&h->c4_pi[i], reserve((size_t)Np2 * Kp1)});
+        for (int i = 0; i < 2 + xv; ++i) items.push_back(Item{&h->c4_q[i], reserve((size_t)Np2 * Kp1)});
     }
     ALLOC(xa, (size_t)B * h->ldxa); ALLOC(xp, (size_t)B * h->ldxp);
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
@@ -959,9 +1124,11 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H1, (long long)NEVAL * B, h->ldh1, h1, 1.0f);
         k_fill_col<<<(NEVAL * B + 255) / 256, 256>>>(h->H2, (long long)NEVAL * B, h->ldh2, h2, 1.0f);
     } else {  // x4 images [row/4][ld][4]: "column" c of every row = four consecutive floats per row group
-        k_fill_col4<<<(4 * B / 4 + 255) / 256, 256>>>(h->H1r4, (long long)4 * B / 4, h->Lp1, h1);
-        k_fill_col4<<<(3 * B / 4 + 255) / 256, 256>>>(h->H2r4, (long long)3 * B / 4, h->Lp2, h2);
+        const int xv = cfg->variant == DDRL_SAC_V ? 1 : 0;
+        k_fill_col4<<<((4 + xv) * B / 4 + 255) / 256, 256>>>(h->H1r4, (long long)(4 + xv) * B / 4, h->Lp1, h1);
+        k_fill_col4<<<((3 + xv) * B / 4 + 255) / 256, 256>>>(h->H2r4, (long long)(3 + xv) * B / 4, h->Lp2, h2);
         k_fill_col4<<<(B / 4 + 255) / 256, 256>>>(h->xa_r4, (long long)B / 4, 32, o + a);
+        k_fill_col4<<<(B / 4 + 255) / 256, 256>>>(h->xv_r4, (long long)B / 4, 32, o);
     }
     k_fill_col<<<(B + 255) / 256, 256>>>(h->xa, B, h->ldxa, o + a, 1.0f);
     k_fill_col<<<(B + 255) / 256, 256>>>(h->xp, B, h->ldxp, o, 1.0f);
@@ -969,7 +1136,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     DDRL_HIP_CHECK(hipDeviceSynchronize());
 
     if (cfg->variant == DDRL_SAC_V) {
-        rc = build_sacv(h);
+        rc = h->fused ? build_sacv_direct(h, Bv, B) : build_sacv(h);
         if (rc != DDRL_OK) { sac1_free(h); return rc; }
         *out = h;
         return DDRL_OK;
@@ -1062,6 +1229,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 F.scale = (float)cfg->act_scale;
                 F.act0 = h->act0; F.act2 = h->act2; F.logp0 = h->logp0; F.logp1 = h->logp1; F.save0 = h->save0;
                 F.php1 = h->hp + 1 * HP; F.pbmu1 = Pm + L.pi_bmu; F.pbls1 = Pm + L.pi_bls; F.peps1 = h->in[st][6];
+                F.pev_pack = 0 | (2 << 2) | (2 << 4);   // q1(x, pi(x)) <- evaluation 0; the target Qs <- evaluation 2 (pi_targ(x2))
                 F.noise_on = 0; F.n_each = Bv * a; F.Bv = Bv; F.noise_seed = 0;
                 F.e0 = h->in[st][5]; F.e1 = h->in[st][6]; F.e2 = h->in[st][7]; F.opt = h->opt;
             };
@@ -1104,7 +1272,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             // ---- backward launch 1: the three Q dgrads (slot 2 first: its dQ/da partials are what the next launch waits for)
             DGJobs &Q = h->dg_bq[st];
             Q = DGJobs{};
-            Q.hp = h->hp; Q.B = B; Q.Bv = Bv;
+            Q.hp = h->hp; Q.B = B; Q.Bv = Bv; Q.sacv = 0; Q.q_ev0 = 3; Q.q_nev = 5;
             Q.b3q1 = Pm + L.q_b3[0]; Q.b3q2 = Pm + L.q_b3[1]; Q.b3q1t = Pt + L.q_b3[0]; Q.b3q2t = Pt + L.q_b3[1];
             Q.rew = h->in[st][3]; Q.done = h->in[st][4]; Q.logp0 = h->logp0; Q.logp1 = h->logp1;
             Q.q1o = h->q1o; Q.q2o = h->q2o; Q.dq = h->dq; Q.loss_part = h->loss_part;
@@ -1321,6 +1489,7 @@ static void refresh_shadows(ddrl_sac1 *h, hipStream_t s) {
     const dim3 grid((h1 + 31) / 32, (h2 / 4 + 7) / 8);
     k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.pi_W2, h->c4_pi[h->sh_cur], h1, h2, L.Np2, L.Kp1);
     for (int q = 0; q < 2; ++q) k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.q_W2[q], h->c4_q[q], h1, h2, L.Np2, L.Kp1);
+    if (h->cfg.variant == DDRL_SAC_V) k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.v_W2, h->c4_q[2], h1, h2, L.Np2, L.Kp1);
 }
 
 static void launch_rows_c(ddrl_sac1 *h, hipStream_t s) {

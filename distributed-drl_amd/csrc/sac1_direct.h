@@ -85,7 +85,8 @@ struct DFArgs {
     int njobs, tiles_n, act, Lp1, Lp2, h2;
     float scale;
     float *act0, *act2, *logp0, *logp1, *save0;
-    const float *php1, *pbmu1, *pbls1, *peps1;  // pi_main @ x2: only its log-prob is needed (actor_learner.py:62)
+    const float *php1, *pbmu1, *pbls1, *peps1;  // pi_main @ x2: only its log-prob is needed (actor_learner.py:62); php1 == nullptr: no such evaluation (SAC-v)
+    int pev_pack;            // phase 1: 2 bits per job = the policy evaluation (head-partial slot) its sampled action comes from
     int noise_on, n_each;    // n_each = valid rows * act (element index of a flat [3][rows * act] fill)
     int Bv;                  // valid rows: the batch; rows up to the next multiple of 32 are padding (zero inputs, no loss terms)
     uint32_t noise_seed;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     // this job's network: bits [5:4] of its pack field = 0 policy / 1 q1 / 2 q2, bit [3] = target copy; the three networks sit
     // at fixed distances inside a parameter buffer (policy first, then the two Q networks)
     const int net = (jp >> 4) & 3;
-    const int d1 = PH == 1 ? act : (net > 0 ? act : 0);  // phase 0: a Q network's second input is the stored action
+    const int d1 = PH == 1 ? act : ((net == 1 || net == 2) ? act : 0);  // phase 0: a Q network's second input is the stored action (network 3 = V: none)
     const int w1o = ((jp & 8) ? targ_off : main_off) + (net == 0 ? 0 : npi + (net - 1) * perq);
     const int x2_off = x_off + ((B * d0 + 63) & ~63), a_off = x2_off + ((B * d0 + 63) & ~63);  // the input set's buffers are consecutive 256-B aligned slab items
     const float *W1 = base + w1o, *W2p = W1 + ((K + 31) & ~31) * 16;  // the k4-interleaved W2 follows the 16-floats-per-unit layer-1 block array
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     // Phase 1: what its longest chain starts with — the policy-head partials of this tile's rows (-> action -> layer-1 input);
     // lanes of half 0 fetch the mu heads, half 1 the log_std heads (head index clamped: no branch in front of a load).
     const int D = d0 + d1;
-    const bool two = PH == 1 && ji == 1 && first_n;  // block-uniform: pi_main @ x2 rides here (log-prob only)
+    const bool two = PH == 1 && ji == 1 && first_n && a.php1 != nullptr;  // block-uniform: pi_main @ x2 rides here (log-prob only)
     float4 hv[2][4][DNT / 4];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (e == 0 || two) {  // block-uniform
-                const float *hp = base + hp_off + (e == 0 ? (ji == 0 ? 0 : 2) : 1) * HPq;
+                const float *hp = base + hp_off + (e == 0 ? ((a.pev_pack >> (2 * ji)) & 3) : 1) * HPq;
                 const float4 *p0 = reinterpret_cast<const float4 *>(hp + ((long long)(h * d1) * B + m0 + l31) * DNT);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -752,9 +753,12 @@ struct DGJobs {
     AdamCtx ad;
     // DGRAD_Q prologue (actor_learner.py:58-69)
     const float *hp;   // head partials [NEVAL][DFH][B][DNT]
-    const float *b3q1, *b3q2, *b3q1t, *b3q2t;
+    const float *b3q1, *b3q2, *b3q1t, *b3q2t;   // SAC-v: b3q1t = main V's b3, b3q2t = target V's b3
     const float *rew, *done, *logp0, *logp1;
     float *q1o, *q2o, *dq, *loss_part;
+    float *vo, *vto;   // SAC-v outputs v(x), v_targ(x2)
+    int sacv;          // 0: SAC1 losses (actor_learner.py:58-69);  1: SAC-v (example/model.py:38-50)
+    int q_ev0, q_nev;  // the head-partial slots the prologue sums: evaluations q_ev0 .. q_ev0 + q_nev - 1
     float alpha, gamma;
     int B, Bv;         // rows of every image (a multiple of 32), valid rows (the batch: means and loss terms run over these)
     DGJob job[MAX_DG_JOBS];
@@ -900,7 +904,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     {
         const int c = tid >> 5;
         const long long HP = (long long)DFH * Bn * DNT;
-        const float4 *p4 = reinterpret_cast<const float4 *>(jobs.hp + (3 + (c < 5 ? c : 0)) * HP + (long long)(m0 + r) * DNT);
+        const float4 *p4 = reinterpret_cast<const float4 *>(jobs.hp + (jobs.q_ev0 + (c < jobs.q_nev ? c : 0)) * HP + (long long)(m0 + r) * DNT);
 #pragma unroll
         for (int q = 0; q < DNT / 4; ++q) qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (need_q) {  // block-uniform
@@ -1020,7 +1024,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             for (int q = 0; q < DNT / 4; ++q) { qsum += qv[q].x; qsum += qv[q].y; qsum += qv[q].z; qsum += qv[q].w; }
             s_q[tid >> 5][tid & 31] = qsum;
             __syncthreads();
-            if (w == 0) {
+            if (w == 0 && !jobs.sacv) {
                 const int row = m0 + l31;
                 const float q1v = s_q[0][l31] + b3_1, q2v = s_q[1][l31] + b3_2, q1pi = s_q[2][l31] + b3_1;
                 const float q1t = s_q[3][l31] + b3_1t, q2t = s_q[4][l31] + b3_2t;
@@ -1039,6 +1043,29 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                         jobs.loss_part[row * 3 + 2] = e2 * e2;                  // :68
                         jobs.dq[row] = dq1;
                         jobs.dq[Bn + row] = dq2;
+                    }
+                }
+            } else if (w == 0) {
+                // SAC-v (example/model.py:38-50); summed evaluations: q1(x,a) q2(x,a) v(x) v_targ(x2) q1(x,pi) q2(x,pi)
+                const int row = m0 + l31;
+                const float q1v = s_q[0][l31] + b3_1, q2v = s_q[1][l31] + b3_2, vv = s_q[2][l31] + b3_1t, vt = s_q[3][l31] + b3_2t;
+                const float q1pi = s_q[4][l31] + b3_1, q2pi = s_q[5][l31] + b3_2;
+                const float q_backup = rew + (jobs.gamma * (1.0f - done)) * vt;        // model.py:41
+                const float v_backup = fminf(q1pi, q2pi) - jobs.alpha * lp0;           // :38,42
+                const float e1 = q_backup - q1v, e2 = q_backup - q2v, ev = v_backup - vv;
+                const float inv_b = row < Bv ? 1.0f / (float)Bv : 0.f;
+                const float dq1 = -e1 * inv_b, dq2 = -e2 * inv_b, dv = -ev * inv_b;
+                if (lane < 32) {
+                    s_g[l31] = jb.slot == 0 ? dq1 : (jb.slot == 1 ? dq2 : dv);
+                    if (first_n && jb.slot == 0) {
+                        jobs.q1o[row] = q1v; jobs.q2o[row] = q2v; jobs.vo[row] = vv; jobs.vto[row] = vt;
+                        jobs.loss_part[row * 4 + 0] = jobs.alpha * lp0 - q1pi;  // :45
+                        jobs.loss_part[row * 4 + 1] = e1 * e1;                  // :46
+                        jobs.loss_part[row * 4 + 2] = e2 * e2;                  // :47
+                        jobs.loss_part[row * 4 + 3] = ev * ev;                  // :48
+                        jobs.dq[row] = dq1;
+                        jobs.dq[Bn + row] = dq2;
+                        jobs.dq[2 * Bn + row] = dv;
                     }
                 }
             }

@@ -252,7 +252,7 @@ class _DsacArgs:
         self.polyak, self.lr, self.alpha, self.batch_size, self.seed, self.max_ep_len = 0.995, 1e-3, 0.2, batch_size, seed, 1000
 
 
-@pytest.mark.parametrize("hid,batch", [((400, 300), 100), ((64, 48), 37)])
+@pytest.mark.parametrize("hid,batch", [((400, 300), 100), ((300, 300), 100), ((64, 48), 37), ((50, 34), 20)])
 def test_sacv_model_matches_oracle(ddrl, hid, batch):
     """N4: the SAC-v learner of example/model.py (policy + twin Q + V + target V, batch 100, lr 1e-3,
     alpha 0.2 as example/dsac.py sets them): losses within 1e-5 relative of the float64 oracle over
@@ -263,6 +263,10 @@ def test_sacv_model_matches_oracle(ddrl, hid, batch):
     from oracle import sacv_oracle as sv
     args = _DsacArgs(hid=hid, batch_size=batch, seed=3)
     model = Model(args)
+    # the direct-operand kernels whenever the hidden sizes allow (example/dsac.py's own 300 x 2 at batch 100 included);
+    # (50, 34) stays on the generic kernels
+    import os
+    assert model._lib.ddrl_sac1_is_fused(model._h) == (1 if hid[0] % 4 == 0 and hid[1] % 4 == 0 and not os.environ.get("DDRL_SAC1_GENERIC") else 0)
     cfg = so.Config(obs_dim=8, act_dim=2, hidden1=hid[0], hidden2=hid[1], batch=batch, alpha=0.2, gamma=0.99, lr=1e-3, polyak=0.995)
     keys, vals = model.get_weights()
     assert keys == [n for n, _ in sv.param_specs(cfg)]
