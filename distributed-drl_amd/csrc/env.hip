@@ -397,13 +397,16 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
     if (i < n) {
         // ---- loads first: head partials (mu heads 0..act-1, log_std heads act..2act-1), the acted-on observation, the env state
         const int nq = (a.nt2 + 3) >> 2;  // float4 groups of a partial row that hold tiles
-        float4 hv[NH][4];
+        // (two statically indexed register arrays: one array indexed by `c + act` would live in scratch memory)
+        constexpr int NA = NH / 2;
+        float4 hm[NA][4], hl[NA][4];
 #pragma unroll
-        for (int c = 0; c < NH; ++c)
+        for (int c = 0; c < NA; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cc = c < 2 * a.act ? c : 0, qq = q < nq ? q : 0;
-                hv[c][q] = *reinterpret_cast<const float4 *>(a.hp + ((long long)cc * n + i) * 16 + 4 * qq);
+                const int cm = c < a.act ? c : 0, qq = q < nq ? q : 0;
+                hm[c][q] = *reinterpret_cast<const float4 *>(a.hp + ((long long)cm * n + i) * 16 + 4 * qq);
+                hl[c][q] = *reinterpret_cast<const float4 *>(a.hp + ((long long)(a.act + cm) * n + i) * 16 + 4 * qq);
             }
         float o1[8];
         {
@@ -418,12 +421,14 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float sm = 0.f, sl = 0.f;
+            if (c < NA) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < nq) {  // n-tile order; slots beyond nt2 hold 0
-                    const float4 m4 = hv[c < NH ? c : 0][q], l4 = hv[(c + a.act) & (NH - 1)][q];
-                    sm += m4.x; sm += m4.y; sm += m4.z; sm += m4.w;
-                    sl += l4.x; sl += l4.y; sl += l4.z; sl += l4.w;
+                for (int q = 0; q < 4; ++q) {
+                    if (q < nq) {  // n-tile order; slots beyond nt2 hold 0
+                        const float4 m4 = hm[c < NA ? c : 0][q], l4 = hl[c < NA ? c : 0][q];
+                        sm += m4.x; sm += m4.y; sm += m4.z; sm += m4.w;
+                        sl += l4.x; sl += l4.y; sl += l4.z; sl += l4.w;
+                    }
                 }
             }
             const int cc = c < a.act ? c : 0;
