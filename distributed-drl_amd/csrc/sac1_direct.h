@@ -28,9 +28,11 @@
 //              policy's layer 1), policy wgrads, Q layer-1 wgrads, Adam + polyak, optimizer bookkeeping
 
 #ifdef DDRL_STAMPS  // diagnostic builds only (tools/upd_bench.hip): per-workgroup cycle stamps of thread 0
-__device__ unsigned long long *g_st = nullptr;  // [kernel id][1024 workgroups][16]
-#define DST(kid, i) do { if (g_st && threadIdx.x == 0) g_st[((kid) * 1024 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DRT(kid, i) do { if (g_st && threadIdx.x == 0) g_st[((kid) * 1024 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// the stamp buffer travels in the kernel arguments ([kernel id][1024 workgroups][16]): a __device__ pointer variable would
+// have to be LOADED in front of every stamp, and the compiler drains every outstanding load before it uses that value
+static unsigned long long *g_st_host = nullptr;
+#define DST(kid, i) do { if (st_ && threadIdx.x == 0) st_[((kid) * 1024 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DRT(kid, i) do { if (st_ && threadIdx.x == 0) st_[((kid) * 1024 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define DST(kid, i) do { } while (0)
 #define DRT(kid, i) do { } while (0)
@@ -86,6 +88,9 @@ struct DFArgs {
     float scale;
     float *act0, *act2, *logp0, *logp1, *save0;
     const float *php1, *pbmu1, *pbls1, *peps1;  // pi_main @ x2: only its log-prob is needed (actor_learner.py:62); php1 == nullptr: no such evaluation (SAC-v)
+#ifdef DDRL_STAMPS
+    unsigned long long *st;
+#endif
     int pev_pack;            // phase 1: 2 bits per job = the policy evaluation (head-partial slot) its sampled action comes from
     int noise_on, n_each;    // n_each = valid rows * act (element index of a flat [3][rows * act] fill)
     int Bv;                  // valid rows: the batch; rows up to the next multiple of 32 are padding (zero inputs, no loss terms)
@@ -235,6 +240,9 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     __shared__ float s_wh[DFH][32];
     const int tpj = tpj_tm & 0xffff, tiles_m = (tpj_tm >> 16) & 0xfff, njobs = (unsigned)tpj_tm >> 28;
     const int K = K_Np & 0xfff, Np = (K_Np >> 12) & 0xfff, B = B_d0 & 0xffff, d0 = (B_d0 >> 16) & 0xff, act = B_d0 >> 24;
+#ifdef DDRL_STAMPS
+    unsigned long long *const st_ = a.st;
+#endif
     DRT(PH, 14); DST(PH, 0);
     if (PH == 1 && (int)blockIdx.x == njobs * tpj) {  // only launched when a.do_sample
         ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
@@ -496,7 +504,13 @@ static int dfwd_mt(int B, int tiles_n) {
 }
 
 template <int PH>
-static void launch_dfwd(const DFHead &d, const DFArgs &F, hipStream_t s) {
+static void launch_dfwd(const DFHead &d, const DFArgs &F_, hipStream_t s) {
+#ifdef DDRL_STAMPS
+    DFArgs F = F_;
+    F.st = g_st_host;
+#else
+    const DFArgs &F = F_;
+#endif
     const int mt = PH == 0 ? dfwd_mt(d.B, F.tiles_n) : 1;
     const int tiles_m = d.B / (32 * mt), tpj = tiles_m * F.tiles_n;
     const int grid = F.njobs * tpj + ((PH == 1 && F.do_sample) ? 1 : 0);
@@ -757,6 +771,9 @@ struct DGJobs {
     const float *rew, *done, *logp0, *logp1;
     float *q1o, *q2o, *dq, *loss_part;
     float *vo, *vto;   // SAC-v outputs v(x), v_targ(x2)
+#ifdef DDRL_STAMPS
+    unsigned long long *st;
+#endif
     int sacv;          // 0: SAC1 losses (actor_learner.py:58-69);  1: SAC-v (example/model.py:38-50)
     int q_ev0, q_nev;  // the head-partial slots the prologue sums: evaluations q_ev0 .. q_ev0 + q_nev - 1
     float alpha, gamma;
@@ -775,6 +792,9 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     __shared__ __attribute__((aligned(16))) float s_gw[512];
     __shared__ int s_last;
     int t, ji;
+#ifdef DDRL_STAMPS
+    unsigned long long *const st_ = jobs.st;
+#endif
     DRT(kid, 14); DST(kid, 0);
     {
         const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
@@ -1276,7 +1296,13 @@ static void dg_add(DGJobs &js, DGJob j) {
     js.tile_start[js.njobs] = j.tile_start;
     js.job[js.njobs++] = j;
 }
-static void launch_dg(const DGJobs &J, hipStream_t s, int kid = 0) {
+static void launch_dg(const DGJobs &J_, hipStream_t s, int kid = 0) {
+#ifdef DDRL_STAMPS
+    DGJobs J = J_;
+    J.st = g_st_host;
+#else
+    const DGJobs &J = J_;
+#endif
     const int *ts = J.tile_start;
     int per_wave = 0;  // deepest 8-group count of a wave over the launch's GEMM jobs
     for (int i = 0; i < J.njobs; ++i) {

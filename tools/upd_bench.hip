@@ -56,8 +56,19 @@ int main(int argc, char **argv) {
     unsigned long long *st;
     const size_t NS = (size_t)5 * 1024 * 16;
     hipMalloc(&st, NS * 8); hipMemset(st, 0, NS * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_st), &st, sizeof(st));
-    hipGraphLaunch(ge, s); hipStreamSynchronize(s);
+    g_st_host = st;   // the stamp pointer travels in the kernel arguments: capture the same graph again, now stamped
+    hipGraph_t g2; hipGraphExec_t ge2;
+    hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < per_graph; ++i) one();
+    ddrl_sac1_internal_opt_sync(h, s);
+    hipStreamEndCapture(s, &g2);
+    if (hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return 1; }
+    hipGraphLaunch(ge2, s); hipStreamSynchronize(s);
+    hipEventRecord(e0, s);
+    for (int k = 0; k < 4; ++k) hipGraphLaunch(ge2, s);
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("stamped graph: %.2f us/update\n", ms * 1000.f / (4 * per_graph));
     std::vector<unsigned long long> hs(NS);
     hipMemcpy(hs.data(), st, NS * 8, hipMemcpyDeviceToHost);
     const char *kn[5] = {"k_dfwd<0>", "k_dfwd<1>", "k_dg bq", "k_dg mid", "k_dg pi"};
