@@ -244,6 +244,33 @@ def stage_measurements(args, opt, rb, roll, d):
                            "frac_of_hbm_peak": K * B * 164 / t / 1e9 / PEAK_HBM_GBPS,
                            "what": "the block of batches a shard owner draws for one step of a remote learner (configs 3/4): "
                                    "one sequential MT19937 index draw + one gather sweep"}
+    try:   # the reference's num_learners > 1 (example/dsac.py:233: unsynchronised learners, last writer wins) on ONE GPU
+        from distributed_drl_amd.workers import TrainDevice
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        tds = []
+        for i in range(2):
+            ri = d.ReplayBufferSAC1(8, 2, 200000, seed=11 + i)
+            fill_replay(ri, 200000, 500 + i)
+            tds.append(TrainDevice(None, ri, opt, learner_index=10 + i, updates_per_graph=16))
+        torch.cuda.synchronize()
+
+        def both(n):
+            for td, st in zip(tds, streams):
+                with torch.cuda.stream(st):
+                    td.run(n)
+        both(64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        both(3200)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        out["two_learners_one_gpu"] = {"updates_per_s_total": 2 * 3200 / t, "us_per_update_each": t / 3200 * 1e6,
+                                       "what": "two independent SAC1 learner loops (own ring, own stream, 16 updates per graph) running "
+                                               "concurrently on the one GPU: the update's launches are latency chains at 1-2 workgroups per "
+                                               "CU, a second learner fills the gaps"}
+        del tds
+    except Exception as e:  # noqa
+        out["two_learners_one_gpu"] = {"error": repr(e)[:200]}
     try:   # example/dsac.py's own algorithm (SAC-v: policy + twin Q + V + target V, batch 100, hidden 300 x 2, lr 1e-3)
         from distributed_drl_amd.agent import Model
 
