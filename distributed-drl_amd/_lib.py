@@ -85,6 +85,8 @@ SIGNATURES = {
     "ddrl_sac1_get_weights": (c_int, [_P, _P, _P]),
     "ddrl_sac1_export": (c_int, [_P, c_int, _P, _P]),
     "ddrl_sac1_import": (c_int, [_P, c_int, _P, _P]),
+    "ddrl_sac1_grad_buffer": (c_int, [_P, POINTER(_P), POINTER(c_int64)]),
+    "ddrl_sac1_grad_finalize": (c_int, [_P, _P]),
     "ddrl_sac1_opt_steps": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), _P]),
     "ddrl_sac1_step": (c_int, [_P] + [_P] * 12 + [_P]),
     "ddrl_sac1_compute_grads": (c_int, [_P] + [_P] * 12 + [_P]),

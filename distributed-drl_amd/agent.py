@@ -276,6 +276,32 @@ class Learner(_Net):
         _lib.check(self._lib.ddrl_sac1_compute_grads(self._h, *ptrs, _lib.stream_ptr()))
         return self.export(_lib.SAC1_GRAD, out)
 
+    def dp_stepper(self, ring):
+        """Data-parallel learner iteration with the host work done once (partition.py, config 4): returns (grads, apply, g) —
+        grads() draws the next batch of `ring`'s sampler (its feed plan included) straight into input set 0 and runs forward +
+        backward there, leaving the COMPLETE gradient in the learner's own buffer `g` (a view, internal layout) for an in-place
+        all-reduce; apply() steps Adam + polyak with it.  No staging, export or import copies, no per-call argument building."""
+        from .replay import _view
+        lib, sp = self._lib, _lib.stream_ptr
+        bufs = (ctypes.c_void_p * 8)()
+        _lib.check(lib.ddrl_sac1_input_buffers(self._h, 0, bufs))
+        in0 = [ctypes.c_void_p(bufs[i]) for i in range(8)]
+        gp, gn = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(lib.ddrl_sac1_grad_buffer(self._h, ctypes.byref(gp), ctypes.byref(gn)))
+        g = _view(gp.value, (int(gn.value),), torch.device("cuda", torch.cuda.current_device()))
+        B, h, rh, seed, nul = int(self.cfg.batch), self._h, ring._h, self._noise_seed, ctypes.c_void_p(None)
+
+        def grads():
+            s = sp()
+            _lib.check(lib.ddrl_replay_sample(rh, B, in0[0], in0[1], in0[2], in0[3], in0[4], nul, s))
+            _lib.check(lib.ddrl_sac1_fill_noise(h, seed, s))
+            _lib.check(lib.ddrl_sac1_compute_grads(h, *in0, nul, nul, nul, nul, s))
+            _lib.check(lib.ddrl_sac1_grad_finalize(h, s))
+
+        def apply():
+            _lib.check(lib.ddrl_sac1_apply_grads(h, sp()))
+        return grads, apply, g
+
     def compute_gradients(self, batch, eps=None):
         """Forward + backward only (the stubbed compute_gradients of actor_learner.py:144-145)."""
         keep, ptrs, _ = self._args(batch, eps, False)

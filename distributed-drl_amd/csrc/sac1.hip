@@ -1411,6 +1411,29 @@ int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream) {
     return DDRL_OK;
 }
 
+int ddrl_sac1_grad_buffer(ddrl_sac1_t *h, float **grad_d, int64_t *n) {
+    DDRL_REQUIRE(h != nullptr && grad_d != nullptr && n != nullptr, "NULL pointer");
+    *grad_d = h->grad;
+    *n = h->L.total_int;
+    return DDRL_OK;
+}
+
+int ddrl_sac1_grad_finalize(ddrl_sac1_t *h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    ddrl::DeviceGuard g(h->device);
+    if (h->fused_l1_wgrad && !h->grad_imported) {  // the pi layer-1 gradient exists only as row-tile partials: sum them into the buffer
+        const long long n = (long long)(h->cfg.obs_dim + 1) * h->cfg.hidden1;
+        if (h->fused)
+            k_reduce_parts_w1y<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->part, h->grad + h->L.pi_W1, h->cfg.obs_dim + 1,
+                                                                                               h->cfg.hidden1, h->ad.nparts);
+        else
+            k_reduce_parts<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->part, h->grad + h->L.pi_W1, n, n, h->ad.nparts);
+        DDRL_LAUNCH_CHECK();
+    }
+    h->grad_imported = true;  // apply_grads takes the buffer as it is (e.g. after an in-place all-reduce)
+    return DDRL_OK;
+}
+
 int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *stream) {
     DDRL_REQUIRE(h != nullptr && flat_d != nullptr, "NULL pointer");
     float *buf = which_buf(h, which);
@@ -1486,10 +1509,12 @@ static void refresh_shadows(ddrl_sac1 *h, hipStream_t s) {
     if (!h->fused) return;
     const Layout &L = h->L;
     const int h1 = h->cfg.hidden1, h2 = h->cfg.hidden2;
-    const dim3 grid((h1 + 31) / 32, (h2 / 4 + 7) / 8);
-    k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.pi_W2, h->c4_pi[h->sh_cur], h1, h2, L.Np2, L.Kp1);
-    for (int q = 0; q < 2; ++q) k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.q_W2[q], h->c4_q[q], h1, h2, L.Np2, L.Kp1);
-    if (h->cfg.variant == DDRL_SAC_V) k_shadow<<<grid, 256, 0, s>>>(h->main_p + L.v_W2, h->c4_q[2], h1, h2, L.Np2, L.Kp1);
+    ShadowJobs sj{};
+    int n = 0;
+    sj.j4[n] = h->main_p + L.pi_W2; sj.c4[n++] = h->c4_pi[h->sh_cur];
+    for (int q = 0; q < 2; ++q) { sj.j4[n] = h->main_p + L.q_W2[q]; sj.c4[n++] = h->c4_q[q]; }
+    if (h->cfg.variant == DDRL_SAC_V) { sj.j4[n] = h->main_p + L.v_W2; sj.c4[n++] = h->c4_q[2]; }
+    k_shadow<<<dim3((h1 + 31) / 32, (h2 / 4 + 7) / 8, n), 256, 0, s>>>(sj, h1, h2, L.Np2, L.Kp1);   // one launch for all networks
 }
 
 static void launch_rows_c(ddrl_sac1 *h, hipStream_t s) {

@@ -1316,7 +1316,13 @@ static void launch_dg(const DGJobs &J_, hipStream_t s, int kid = 0) {
 }
 
 // The dgrad image [N/4][ld][4] of a k4-interleaved kernel [K/4][Np][4] (after a set_weights / import / flat Adam step)
-__global__ void __launch_bounds__(256) k_shadow(const float *__restrict__ j4, float *__restrict__ c4, int K, int N, int Np, int ld_sh) {
+struct ShadowJobs {
+    const float *j4[4];
+    float *c4[4];
+};
+__global__ void __launch_bounds__(256) k_shadow(ShadowJobs sj, int K, int N, int Np, int ld_sh) {
+    const float *__restrict__ j4 = sj.j4[blockIdx.z];
+    float *__restrict__ c4 = sj.c4[blockIdx.z];
     const int k = blockIdx.x * 32 + (threadIdx.x & 31), ng = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (k >= K || 4 * ng >= N) return;
     float v[4];

@@ -195,7 +195,7 @@ class PartitionedRun:
             if self.lgroup is None:
                 self.loop = _Loop(self.learner, self.feed_ring, updates_per_graph)
             else:
-                self.grad_buf = torch.empty(self.learner.n_params, dtype=torch.float32, device=self.device)
+                self.dp_grads, self.dp_apply, self.dp_g = self.learner.dp_stepper(self.feed_ring)
         self.send_bufs, self.regions = {}, {}
         self.plan_d, self.plan_h = None, None
         self.sends = []
@@ -275,10 +275,9 @@ class PartitionedRun:
     def _train_eager(self, n):
         """Several learners: per update, the plan's batch -> gradients -> all-reduce (mean) -> Adam + polyak."""
         for _ in range(n):
-            batch = sample_packed(self.feed_ring, self.B, self.batch_buf)
-            g = self.learner.compute_gradients_device(batch, out=self.grad_buf)
-            comm.allreduce_mean_(g, group=self.lgroup)
-            self.learner.apply_gradients(g)
+            self.dp_grads()
+            comm.allreduce_mean_(self.dp_g, group=self.lgroup)
+            self.dp_apply()
 
     def _tick(self, key, t0):
         """DDRL_PART_TIMING=1: wall time per phase (device drained at every phase boundary — diagnosis only)."""

@@ -207,6 +207,12 @@ typedef enum {
 } ddrl_sac1_buffer;
 int ddrl_sac1_export(ddrl_sac1_t *h, int which, float *flat_d, void *stream);
 int ddrl_sac1_import(ddrl_sac1_t *h, int which, const float *flat_d, void *stream);
+/* Data-parallel learners without the export / import copies: after ddrl_sac1_compute_grads, ddrl_sac1_grad_finalize makes
+ * the learner's own gradient buffer complete (sums the layer-1 partials) and marks it as final; ddrl_sac1_grad_buffer
+ * returns that buffer (device pointer, *n floats, the learner's INTERNAL parameter-shaped layout, identical on every learner
+ * of the same config; padding elements are zero) for an in-place all-reduce; ddrl_sac1_apply_grads then steps with it. */
+int ddrl_sac1_grad_buffer(ddrl_sac1_t *h, float **grad_d, int64_t *n);
+int ddrl_sac1_grad_finalize(ddrl_sac1_t *h, void *stream);
 /* Adam step counters of the two optimizers (host outputs); synchronises `stream`. */
 int ddrl_sac1_opt_steps(ddrl_sac1_t *h, int64_t *t_pi_h, int64_t *t_q_h, void *stream);
 /* Optimizer bookkeeping for checkpoint / resume: Adam step counts of the two optimizers and the
