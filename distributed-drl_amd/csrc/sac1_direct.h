@@ -963,7 +963,11 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     ktouch(kl);
     DST(kid, 1);
     // ---- epilogue operands: requested from inside the K loop (behind the MFMAs of the first groups), so that the first
-    // MFMA does not queue behind up to 16 more wave-loads per wave
+    // MFMA does not queue behind up to 16 more wave-loads per wave.  (A wave's loads return in order, so the optimizer state —
+    // cold, from the fabric — still holds up the operand groups requested behind it: +2.8 k / +4.1 k cycles of K loop in the
+    // two optimizer launches against the same launches without the step.  Measured alternative: a fifth "helper" wave per
+    // workgroup that fetches the state into LDS before the combine barrier — the dispatcher then fits one 5-wave workgroup
+    // per CU at 131 VGPRs (59.5 us per update), and capping the kernel at 128 VGPRs spills (55.7 us) against 52.5 us.)
     const bool is_dgrad = type == DG_DGRAD_Q || type == DG_DGRAD;
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     float wa_v = 0.f, px_v[2] = {0.f, 0.f};  // staged into LDS after the K loop

@@ -70,6 +70,8 @@ int main(int argc, char **argv) {
     hipEventElapsedTime(&ms, e0, e1);
     printf("stamped graph: %.2f us/update\n", ms * 1000.f / (4 * per_graph));
     std::vector<unsigned long long> hs(NS);
+    auto anatomy = [&](const char *title) {
+    printf("---- %s\n", title);
     hipMemcpy(hs.data(), st, NS * 8, hipMemcpyDeviceToHost);
     const char *kn[5] = {"k_dfwd<0>", "k_dfwd<1>", "k_dg bq", "k_dg mid", "k_dg pi"};
     const char *pn[6] = {"", "loads-issued", "prologue", "k-loop", "combine-bar", "epilogue"};
@@ -93,6 +95,13 @@ int main(int argc, char **argv) {
         printf(" | mean total %.0f max %llu\n", tot / nwg, lmax);
         prev_end = rmax;
     }
+    };
+    anatomy("inside the update sequence (graph)");
+    // the same launches repeated back to back, WITHOUT the optimizer step in the epilogues (ddrl_sac1_stage_time): inputs stay in the L2s
+    hipMemset(st, 0, NS * 8);
+    for (int stg : {2, 5, 7, 8, 9}) { float ms2; ddrl_sac1_stage_time(h, stg, 40, &ms2, s); }
+    hipStreamSynchronize(s);
+    anatomy("each launch repeated back to back, no optimizer step");
 #endif
     return 0;
 }
