@@ -1187,31 +1187,47 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                     }
                 }
                 if (la) {
+                    // The optimizer state of this column tile's layer-1 parameters does not depend on the partials: every row
+                    // tile requests it BEFORE the hand-off (two elements per thread: part_nk * 32 <= 512), so the workgroup that
+                    // turns out to be last has it by the time its partial loads return — one fabric round trip, not two.
+                    const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
+                    long long off2[2], e2[2];
+                    bool ok2[2];
+                    float am2[2], av2[2], ap2[2], at2[2];
+#pragma unroll
+                    for (int u2 = 0; u2 < 2; ++u2) {
+                        const int idx = tid + 256 * u2, k = idx >> 5, col = idx & 31;
+                        ok2[u2] = idx < jb.part_nk * 32 && n0 + col < jb.N;
+                        e2[u2] = ok2[u2] ? (long long)k * jb.N + n0 + col : 0;
+                        off2[u2] = jb.part_adam_off + (ok2[u2] ? w1y_index(k, n0 + col) : 0);
+                        am2[u2] = jobs.ad.m[off2[u2]]; av2[u2] = jobs.ad.v[off2[u2]]; ap2[u2] = jobs.ad.p[off2[u2]]; at2[u2] = jobs.ad.t[off2[u2]];
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (tid == 0) s_last = __hip_atomic_fetch_add(jb.part_cnt + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __syncthreads();
                     if (s_last == tiles_m - 1) {
-                        const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
-                        for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
-                            const int k = idx >> 5, col = idx & 31;
-                            if (n0 + col < jb.N) {
-                                const long long e = (long long)k * jb.N + n0 + col, off = jb.part_adam_off + w1y_index(k, n0 + col);
-                                float am_ = jobs.ad.m[off], av_ = jobs.ad.v[off], ap_ = jobs.ad.p[off], at_ = jobs.ad.t[off];
-                                float g = 0.f;
-                                for (int q0 = 0; q0 < tiles_m; q0 += 8) {  // 8 partials per round trip, summed in tile order (as k_adam_polyak)
-                                    float u[8];
+                        float g2[2] = {0.f, 0.f};
+                        for (int q0 = 0; q0 < tiles_m; q0 += 8) {  // 8 partials per element and round trip, summed in tile order (as k_adam_polyak)
+                            float u[2][8];
 #pragma unroll
-                                    for (int q = 0; q < 8; ++q)
-                                        u[q] = __hip_atomic_load(jb.part + (long long)(q0 + q < tiles_m ? q0 + q : 0) * jb.part_nk * jb.N + e, __ATOMIC_RELAXED,
+                            for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    u[u2][q] = __hip_atomic_load(jb.part + (long long)(q0 + q < tiles_m ? q0 + q : 0) * jb.part_nk * jb.N + e2[u2], __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                                    for (int q = 0; q < 8; ++q)
-                                        if (q0 + q < tiles_m) g += u[q];
-                                }
-                                adam1(g, am_, av_, ap_, at_, omb1, omb2, al_pi, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
-                                jobs.ad.g[off] = g;
-                                jobs.ad.m[off] = am_; jobs.ad.v[off] = av_; jobs.ad.p[off] = ap_; jobs.ad.t[off] = at_;
+                            for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    if (q0 + q < tiles_m) g2[u2] += u[u2][q];
+                        }
+#pragma unroll
+                        for (int u2 = 0; u2 < 2; ++u2) {
+                            if (ok2[u2]) {
+                                adam1(g2[u2], am2[u2], av2[u2], ap2[u2], at2[u2], omb1, omb2, al_pi, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
+                                jobs.ad.g[off2[u2]] = g2[u2];
+                                jobs.ad.m[off2[u2]] = am2[u2]; jobs.ad.v[off2[u2]] = av2[u2]; jobs.ad.p[off2[u2]] = ap2[u2]; jobs.ad.t[off2[u2]] = at2[u2];
                             }
                         }
                         if (tid == 0) {
