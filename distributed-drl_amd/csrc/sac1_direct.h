@@ -56,6 +56,12 @@ __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v
 // Activation images are written once and read by later launches on other XCDs: streaming (nontemporal) stores leave no
 // dirty lines for the end-of-kernel write-back and do not push the optimizer state out of the L2s (50.8 -> 49.5 us per
 // update; the same hint on the optimizer-state stores themselves: no change).
+// (`tools/xcd_latency_bench.hip`: a dependent load of data the previous launch wrote costs 237 cycles on the writer's own XCD,
+// 550 on another XCD after plain or sc1 (write-through) stores, 620-870 after nontemporal ones.  In the update: images
+// nontemporal 49.6 us, sc1 50.8; the smaller dgrad outputs sc1 49.4.)
+#ifndef DDRL_ST_SC1
+#define DDRL_ST_SC1 1
+#endif
 __device__ __forceinline__ void st_img(float *p, const float4 &v) {
 #if DDRL_NT_STORES
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -68,7 +74,11 @@ __device__ __forceinline__ void st_img(float *p, const float4 &v) {
 __device__ __forceinline__ void st_nt(float *p, const float4 &v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v t = {v.x, v.y, v.z, v.w};
+#if DDRL_ST_SC1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#else
     __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
+#endif
 }
 __device__ __forceinline__ void st_dg(float *p, const float4 &v) {
 #if DDRL_NT_DG

@@ -18,6 +18,9 @@ __global__ void __launch_bounds__(256) k_prod(int *buf, int salt) {
         if (MODE == 0) r[i] = nxt;
         if (MODE == 1) __builtin_nontemporal_store(nxt, r + i);
         if (MODE == 2) __hip_atomic_store(r + i, nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 3) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(r + i), "v"(nxt) : "memory");
+        if (MODE == 4) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(r + i), "v"(nxt) : "memory");
+        if (MODE == 5) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(r + i), "v"(nxt) : "memory");
     }
 }
 template <int LMODE>
@@ -58,10 +61,13 @@ int main() {
     int *buf, *sink; unsigned long long *out;
     CK(hipMalloc(&buf, (size_t)256 * REG * 4)); CK(hipMalloc(&out, 256 * 8)); CK(hipMalloc(&sink, 4));
     hipStream_t s; CK(hipStreamCreate(&s));
-    for (int shift : {0, 1, 4}) {
+    for (int shift : {0, 1}) {
         if (run<0, 0>("plain stores, plain loads", shift, buf, out, sink, s)) return 1;
         if (run<1, 0>("nontemporal stores, plain loads", shift, buf, out, sink, s)) return 1;
         if (run<2, 0>("agent-scope atomic (write-through) stores, plain loads", shift, buf, out, sink, s)) return 1;
+        if (run<3, 0>("sc1 stores (asm), plain loads", shift, buf, out, sink, s)) return 1;
+        if (run<4, 0>("sc0 sc1 stores (asm), plain loads", shift, buf, out, sink, s)) return 1;
+        if (run<5, 0>("sc0 stores (asm), plain loads", shift, buf, out, sink, s)) return 1;
         if (run<0, 1>("plain stores, agent-scope atomic loads", shift, buf, out, sink, s)) return 1;
         if (run<1, 1>("nontemporal stores, agent-scope atomic loads", shift, buf, out, sink, s)) return 1;
     }
