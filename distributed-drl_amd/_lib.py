@@ -94,6 +94,7 @@ SIGNATURES = {
     "ddrl_sac1_opt_state_get": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_uint64), _P]),
     "ddrl_sac1_opt_state_set": (c_int, [_P, c_int64, c_int64, c_uint64, _P]),
     "ddrl_sac1_step_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
+    "ddrl_sac1_compute_grads_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_apply_grads_and_sample": (c_int, [_P, _P, c_int, _P]),
     "ddrl_sac1_input_buffers": (c_int, [_P, c_int, POINTER(_P)]),
     "ddrl_sac1_is_fused": (c_int, [_P]),

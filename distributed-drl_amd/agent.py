@@ -278,25 +278,37 @@ class Learner(_Net):
 
     def dp_stepper(self, ring):
         """Data-parallel learner iteration with the host work done once (partition.py, config 4): returns (grads, apply, g) —
-        grads() draws the next batch of `ring`'s sampler (its feed plan included) straight into input set 0 and runs forward +
-        backward there, leaving the COMPLETE gradient in the learner's own buffer `g` (a view, internal layout) for an in-place
+        grads() runs forward + backward on the batch `ring`'s sampler (its feed plan included) drew into one of the two input
+        sets — the draw of the following batch rides in that update's forward launch — leaving the COMPLETE gradient in the learner's own buffer `g` (a view, internal layout) for an in-place
         all-reduce; apply() steps Adam + polyak with it.  No staging, export or import copies, no per-call argument building."""
         from .replay import _view
         lib, sp = self._lib, _lib.stream_ptr
-        bufs = (ctypes.c_void_p * 8)()
-        _lib.check(lib.ddrl_sac1_input_buffers(self._h, 0, bufs))
-        in0 = [ctypes.c_void_p(bufs[i]) for i in range(8)]
+        ins = []
+        for st in range(2):
+            bufs = (ctypes.c_void_p * 8)()
+            _lib.check(lib.ddrl_sac1_input_buffers(self._h, st, bufs))
+            ins.append([ctypes.c_void_p(bufs[i]) for i in range(8)])
         gp, gn = ctypes.c_void_p(), ctypes.c_int64()
         _lib.check(lib.ddrl_sac1_grad_buffer(self._h, ctypes.byref(gp), ctypes.byref(gn)))
         g = _view(gp.value, (int(gn.value),), torch.device("cuda", torch.cuda.current_device()))
         B, h, rh, seed, nul = int(self.cfg.batch), self._h, ring._h, self._noise_seed, ctypes.c_void_p(None)
+        state = {"cur": 0, "primed": False}
 
-        def grads():
-            s = sp()
-            _lib.check(lib.ddrl_replay_sample(rh, B, in0[0], in0[1], in0[2], in0[3], in0[4], nul, s))
+        def grads(last=False):
+            """`last`: the final update before the ring / its feed plan changes (end of a step): nothing is drawn ahead."""
+            s, cur = sp(), state["cur"]
+            if not state["primed"]:
+                i = ins[cur]
+                _lib.check(lib.ddrl_replay_sample(rh, B, i[0], i[1], i[2], i[3], i[4], nul, s))
             _lib.check(lib.ddrl_sac1_fill_noise(h, seed, s))
-            _lib.check(lib.ddrl_sac1_compute_grads(h, *in0, nul, nul, nul, nul, s))
+            if last:
+                _lib.check(lib.ddrl_sac1_compute_grads(h, *ins[cur], nul, nul, nul, nul, s))
+                state["primed"] = False
+            else:   # the next batch's sampler rides in this update's forward launch, into the other input set
+                _lib.check(lib.ddrl_sac1_compute_grads_and_sample(h, cur, rh, cur ^ 1, s))
+                state["primed"], state["cur"] = True, cur ^ 1
             _lib.check(lib.ddrl_sac1_grad_finalize(h, s))
+            self._dp_last_set = cur
 
         def apply():
             _lib.check(lib.ddrl_sac1_apply_grads(h, sp()))

@@ -1780,6 +1780,28 @@ int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
 
 extern "C" {
 
+int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream) {
+    DDRL_REQUIRE(h != nullptr && replay != nullptr && (set_in == 0 || set_in == 1) && (set_out == 0 || set_out == 1) && set_in != set_out,
+                 "NULL pointer, or input sets not {0,1} / not distinct");
+    ddrl::DeviceGuard g(h->device);
+    float **b = h->in[set_in];
+    if (!h->fused || !ddrl_replay_can_fuse(replay, h->cfg.batch)) {  // generic kernels: the sampler as its own launch
+        int rc = ddrl_sac1_compute_grads(h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr, stream);
+        if (rc != DDRL_OK) return rc;
+        float **o = h->in[set_out];
+        return ddrl_replay_sample(replay, h->cfg.batch, o[0], o[1], o[2], o[3], o[4], nullptr, stream);
+    }
+    const ddrl_replay_dev::SamplerView v = ddrl_replay_sampler_view(replay);
+    DDRL_REQUIRE(v.ring.n_arr == 5 && v.ring.w[0] == h->cfg.obs_dim && v.ring.w[1] == h->cfg.obs_dim && v.ring.w[2] == h->cfg.act_dim &&
+                     v.ring.w[3] == 1 && v.ring.w[4] == 1,
+                 "replay row shape differs from the learner's (obs1, obs2, acts, rews, done)");
+    h->sample_armed = true; h->smp_rs = v.state; h->smp_ring = v.ring; h->smp_set = set_out;
+    const int rc = ddrl_sac1_compute_grads(h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr, stream);
+    h->sample_armed = false;
+    if (rc == DDRL_OK) ddrl_replay_note_sample(replay);
+    return rc;
+}
+
 int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream) {
     DDRL_REQUIRE(h != nullptr && replay != nullptr && (set_in == 0 || set_in == 1) && (set_out == 0 || set_out == 1) && set_in != set_out,
                  "NULL pointer, or input sets not {0,1} / not distinct");

@@ -272,10 +272,10 @@ class PartitionedRun:
         self.stats["remote_batches"] += n - owners.count(me)
         self.last_plan = plan
 
-    def _train_eager(self, n):
+    def _train_eager(self, n, end_of_step=False):
         """Several learners: per update, the plan's batch -> gradients -> all-reduce (mean) -> Adam + polyak."""
-        for _ in range(n):
-            self.dp_grads()
+        for i in range(n):
+            self.dp_grads(last=end_of_step and i == n - 1)
             comm.allreduce_mean_(self.dp_g, group=self.lgroup)
             self.dp_apply()
 
@@ -310,7 +310,7 @@ class PartitionedRun:
                 if self.loop is not None:
                     self.loop.run(seg)
                 else:
-                    self._train_eager(seg)
+                    self._train_eager(seg, end_of_step=(left == seg))
             t = self._tick("s_updates", t)
             self.cnt += seg
             left -= seg

@@ -255,6 +255,9 @@ int ddrl_sac1_apply_grads_and_sample(ddrl_sac1_t *h, ddrl_replay_t *replay, int 
  * (actor_learner.py:135-142).  On the fused path the sampler rides in a forward launch and the
  * optimizer in the last backward launch; otherwise == compute_grads + apply_grads_and_sample. */
 int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream);
+/* The same without the optimizer step (data-parallel learners: all-reduce, then ddrl_sac1_apply_grads): forward + backward on
+ * input set set_in while the sampler of the NEXT batch rides in a forward launch and gathers into set_out. */
+int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream);
 
 /* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
  * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of

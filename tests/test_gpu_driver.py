@@ -342,3 +342,35 @@ def test_actor_learner_loop_at_config2_sizes_counters_and_mt_state():
     assert pos == ora.rng.pos and (np.asarray(key) == ora.rng.key).all()
     assert loop.trainer.agent.opt_steps() == (3 * 2048, 3 * 2048)
     assert ps.version >= 1 + (3 * 2048) // 300
+
+
+def test_dp_stepper_ride_along_sampler_equals_plain_sequence():
+    """Data-parallel learner iteration (partition.py, config 4): drawing the next batch inside the current update's forward
+    launch (ddrl_sac1_compute_grads_and_sample) trains on exactly the batches, in exactly the order, of draw -> gradients ->
+    apply one at a time — parameters, targets and Adam moments bit for bit, and the sampler ends in the same state."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    opt = HyperParameters()
+    opt.batch_size, opt.seed = 256, 4
+    rs = np.random.RandomState(3)
+    n = 6000
+    data = [rs.randn(n, 8).astype(np.float32), rs.uniform(-1, 1, (n, 2)).astype(np.float32), rs.randn(n).astype(np.float32),
+            rs.randn(n, 8).astype(np.float32), (rs.rand(n) < 0.05).astype(np.float32)]
+    outs = []
+    for ride in (False, True):
+        rb = ddrl.ReplayBufferSAC1(8, 2, 8192, seed=21)
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in data))
+        L = Learner(opt, job="learner", index=0)
+        grads, apply, g = L.dp_stepper(rb)
+        for step in range(3):            # three "steps" of five updates: nothing is drawn ahead across a step's end
+            for u in range(5):
+                grads(last=(u == 4) or not ride)
+                g.mul_(1.0)              # (where the in-place all-reduce goes)
+                apply()
+        outs.append(([L.export(w).clone() for w in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V)],
+                     rb.get_counts(), rb.mt_state(), L.opt_steps()))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert outs[0][1] == outs[1][1] == (15, n, n) and outs[0][3] == outs[1][3] == (15, 15)
+    assert outs[0][2][1] == outs[1][2][1] and (outs[0][2][0] == outs[1][2][0]).all()

@@ -118,8 +118,8 @@ def _gpu_worker(rank, world, port, q, num_learners):
             if run.loop is not None:   # single learner: the device loop gathered update u's batch into input set u & 1
                 v = run.learner.input_batch(u & 1)
                 trained.append(torch.cat([v[k].reshape(-1) for k in ("obs1", "obs2", "acts", "rews", "done")]).cpu().numpy().copy())
-            elif run.learner is not None:   # data-parallel learners: every batch is drawn into input set 0
-                v = run.learner.input_batch(0)
+            elif run.learner is not None:   # data-parallel learners: the input set the update just trained on
+                v = run.learner.input_batch(run.learner._dp_last_set)
                 trained.append(torch.cat([v[k].reshape(-1) for k in ("obs1", "obs2", "acts", "rews", "done")]).cpu().numpy().copy())
         everything = [None] * w
         dist.all_gather_object(everything, handed)

@@ -15,8 +15,8 @@ L = Learner(opt, job="learner", index=0)
 grads, apply, g = L.dp_stepper(rb)
 
 
-def it():
-    grads()
+def it(last=False):
+    grads(last)
     apply()
 
 
