@@ -244,6 +244,25 @@ def stage_measurements(args, opt, rb, roll, d):
                            "frac_of_hbm_peak": K * B * 164 / t / 1e9 / PEAK_HBM_GBPS,
                            "what": "the block of batches a shard owner draws for one step of a remote learner (configs 3/4): "
                                    "one sequential MT19937 index draw + one gather sweep"}
+    try:   # config 5's learner: Double-DQN (algos/dqn/actor_learner.py) on 84x84x4 = 28 224-wide observations, batch 512
+        from distributed_drl_amd import dqn
+
+        class O5L:
+            obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed = 84 * 84 * 4, 4, [400, 300], 0.99, 1e-3, 0.995, 512, 2
+        l5 = dqn.Learner(O5L, "learner")
+        b5 = {"obs1": torch.rand(512, O5L.obs_dim, device="cuda"), "obs2": torch.rand(512, O5L.obs_dim, device="cuda"),
+              "acts": torch.randint(0, 4, (512,), device="cuda").float(), "rews": torch.randn(512, device="cuda"),
+              "done": (torch.rand(512, device="cuda") < 0.01).float()}
+        t = timed(lambda: l5.train(b5, 0), 20, warm=3)
+        # three forwards (main @ x, main @ x2, target @ x2) + the wgrad of main @ x for every layer, + the dgrad of layers 2, 3
+        fl = 2.0 * 512 * (4 * O5L.obs_dim * 400 + 5 * (400 * 300 + 300 * 4))
+        out["ddqn_update_cfg5"] = {"batch": 512, "obs_dim": O5L.obs_dim, "ms": t * 1e3, "updates_per_s": 1.0 / t,
+                                   "approx_TFLOPs": fl / t / 1e12, "frac_of_f32_mfma_peak": fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "what": "one Double-DQN update at config 5's observation width (generic k_gemm path: layer 1 is a "
+                                           "K = 28 224 GEMM), eager"}
+        del l5, b5
+    except Exception as e:  # noqa
+        out["ddqn_update_cfg5"] = {"error": repr(e)[:200]}
     try:   # the reference's num_learners > 1 (example/dsac.py:233: unsynchronised learners, last writer wins) on ONE GPU
         from distributed_drl_amd.workers import TrainDevice
         streams = [torch.cuda.Stream() for _ in range(2)]
