@@ -43,15 +43,6 @@ constexpr int DNT = 16;   // n-tile slots of a head-partial row (hidden2 <= 512)
 constexpr int DGMAX = 16; // 8-deep contraction groups per wave (contraction <= 512)
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
-#ifndef DDRL_NT_STORES
-#define DDRL_NT_STORES 1
-#endif
-#ifndef DDRL_NT_DG
-#define DDRL_NT_DG 1
-#endif
-#ifndef DDRL_NT_OPT
-#define DDRL_NT_OPT 0
-#endif
 
 // Activation images are written once and read by later launches on other XCDs: streaming (nontemporal) stores leave no
 // dirty lines for the end-of-kernel write-back and do not push the optimizer state out of the L2s (50.8 -> 49.5 us per
@@ -59,41 +50,17 @@ __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v
 // (`tools/xcd_latency_bench.hip`: a dependent load of data the previous launch wrote costs 237 cycles on the writer's own XCD,
 // 550 on another XCD after plain or sc1 (write-through) stores, 620-870 after nontemporal ones.  In the update: images
 // nontemporal 49.6 us, sc1 50.8; the smaller dgrad outputs sc1 49.4.)
-#ifndef DDRL_ST_SC1
-#define DDRL_ST_SC1 1
-#endif
-__device__ __forceinline__ void st_img(float *p, const float4 &v) {
-#if DDRL_NT_STORES
+__device__ __forceinline__ void st_img(float *p, const float4 &v) {   // activation images: streaming
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
-#else
-    *reinterpret_cast<float4 *>(p) = v;
-#endif
 }
-__device__ __forceinline__ void st_nt(float *p, const float4 &v) {
+__device__ __forceinline__ void st_dg(float *p, const float4 &v) {    // dgrad outputs: write-through
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v t = {v.x, v.y, v.z, v.w};
-#if DDRL_ST_SC1
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-#else
-    __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
-#endif
 }
-__device__ __forceinline__ void st_dg(float *p, const float4 &v) {
-#if DDRL_NT_DG
-    st_nt(p, v);
-#else
-    *reinterpret_cast<float4 *>(p) = v;
-#endif
-}
-__device__ __forceinline__ void st_opt(float *p, const float4 &v) {
-#if DDRL_NT_OPT
-    st_nt(p, v);
-#else
-    *reinterpret_cast<float4 *>(p) = v;
-#endif
-}
+__device__ __forceinline__ void st_opt(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }   // optimizer state: plain
 __device__ __forceinline__ int d_slot(int s, int h) { return s < 4 ? 4 * h + s : 8 + 2 * (s - 4) + h; }
 __device__ __forceinline__ float relu1(float x) {
     float y;
@@ -201,25 +168,12 @@ struct DOps {
 // Only the first DPRE blocks are requested before the K loop; block bi + DPRE is requested when block bi's MFMAs are
 // issued, so the fetch path (one wave-load per ~15 cycles and CU: ~3.6k cycles for the 8 waves of two workgroups) works
 // beside the matrix pipe instead of in front of it.
-#ifndef DDRL_DPRE
-#define DDRL_DPRE 1
-#endif
-#ifndef DDRL_DGP
-#define DDRL_DGP 2
-#endif
-#ifndef DDRL_DGMID
-#define DDRL_DGMID 4
-#endif
-#ifndef DDRL_XIN_FIRST
-#define DDRL_XIN_FIRST 1
-#endif
-#ifndef DDRL_XIN_MASK
-#define DDRL_XIN_MASK 0
-#endif
-#ifndef DDRL_MID
-#define DDRL_MID 1
-#endif
-constexpr int DPRE = DDRL_DPRE;
+// Measured at config 2 (us per update): DPRE 1 / 2 / 3 / 4 (= everything up front) 54.1 / 54.5 / 55.2 / 55.3; the input rows
+// requested in front of the operand blocks 54.0, the epilogue operands from inside the loop 53.7; DGP 1 / 2 / 4 / 8 / 16
+// 52.4 / 52.35 / 52.6 / 53.2 / 53.7; DGMID 1 / 2 / 4 / 6 / 8 52.3 / 52.3 / 52.0 / 52.1 / 52.3.
+constexpr int DPRE = 1;    // operand blocks of k_dfwd requested before its K loop
+constexpr int DGP0 = 2;    // 8-deep operand groups of k_dg requested before its K loop
+constexpr int DGMID = 4;   // k_dg: the group behind whose MFMAs the epilogue operands are requested
 struct DSrc {
     const float *W1, *W2p;
     int Np, b0, nb, n0;
@@ -270,12 +224,10 @@ __device__ __forceinline__ void dkloop(DOps &o, const DSrc &src, int K, int lane
                 }
             }
         }
-#if DDRL_MID
         if (bi == 0) {  // whatever the epilogue needs and nothing in the K loop does: requested behind block 0's MFMAs
             mid();
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
     }
 }
 
@@ -363,10 +315,6 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     DOps ops;
     const DSrc src{W1, W2p, Np, b0, nb, n0};
     constexpr int PRE = DPRE;
-    if (!DDRL_XIN_FIRST) {
-#pragma unroll
-        for (int bi = 0; bi < PRE; ++bi) dops_load_block(ops, src, bi, lane);
-    }
     {
         // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
         float xin[MT][7];
@@ -381,16 +329,12 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
                     const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
                     const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
                     // (no select on the loaded value: the compiler would sink the load into a branch.)  Column D: the bias row
-#if DDRL_XIN_MASK
-                    xin[tt][s] = *p * ((f0 || f1) ? 1.0f : 0.f) + ((!f0 && !f1 && d == D) ? 1.0f : 0.f);
-#else
-                    const float v = *p;
+                    const float v = *p;   // (masking by multiplication instead of the select: +1.5 us per update)
                     xin[tt][s] = (f0 || f1) ? v : (d == D ? 1.0f : 0.f);
-#endif
                 }
             }
         }
-        if (DDRL_XIN_FIRST) {  // behind the input rows: a wave's loads return in order and the first MFMA needs those first
+        {   // behind the input rows: a wave's loads return in order and the first MFMA needs those first
 #pragma unroll
             for (int bi = 0; bi < PRE; ++bi) dops_load_block(ops, src, bi, lane);
         }
@@ -470,9 +414,6 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
         float *h1r4 = (jb.H1r4 && first_n) ? jb.H1r4 : nullptr;
-#if !DDRL_MID
-        epilogue_operands();
-#endif
         {
             if (ns == 4) dkloop<4, MT, PRE>(ops, src, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
             else if (ns == 5) dkloop<5, MT, PRE>(ops, src, K, lane, xin, acc, h1r4, a.Lp1, m0, tr[w], epilogue_operands);
@@ -1008,7 +949,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     };
     // only the first DGP groups are requested up front; group g + DGP is requested when group g's MFMAs are issued (the
     // fetch path then works beside the matrix pipe, and the first MFMA does not queue behind the whole stream)
-    constexpr int DGP = DDRL_DGP < GMAX ? DDRL_DGP : GMAX;
+    constexpr int DGP = DGP0 < GMAX ? DGP0 : GMAX;
 #pragma unroll
     for (int g = 0; g < DGP; ++g) fetch_group(g);
     ktouch(kl);
@@ -1082,9 +1023,6 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             }
         }
     };
-#if !DDRL_DGMID
-    epilogue_operands();
-#endif
     // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
     float dqr = m0 + l31 < Bv ? jb.gconst : 0.f;
     if (has_gen) { s_gw[tid] = gv0; s_gw[tid + 256] = gv1; }
@@ -1159,12 +1097,10 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             fetch_group(g + DGP);
             __builtin_amdgcn_sched_barrier(0);
         }
-#if DDRL_DGMID
-        if (g == DDRL_DGMID) {
+        if (g == DGMID) {
             epilogue_operands();
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         if (g < ng) {
             float4 av4 = a4[g], bv4 = b4[g];
             if (type == DG_DGRAD_Q) {
