@@ -66,6 +66,7 @@ SIGNATURES = {
     "ddrl_replay_sample_ex": (c_int, [_P, c_int64, POINTER(_P), _P, _P]),
     "ddrl_replay_sample_many": (c_int, [_P, c_int64, c_int64, POINTER(_P), _P]),
     "ddrl_replay_set_feed": (c_int, [_P, _P, c_int32, c_int32, c_int32, POINTER(_P), POINTER(c_int32), _P]),
+    "ddrl_replay_take_error": (c_int, [_P, _P, _P]),
     "ddrl_replay_gather_ex": (c_int, [_P, _P, c_int64, POINTER(_P), _P]),
     "ddrl_replay_buffers_ex": (c_int, [_P, POINTER(_P), POINTER(c_int32), POINTER(c_int32)]),
     "ddrl_replay_counts": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), _P]),

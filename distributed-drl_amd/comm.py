@@ -8,8 +8,9 @@ Mapping of the reference's cross-process traffic:
   * replay shards (algos/sac1/sac_ray.py:137-141,246; algos/dqn/train.py:191-199,277-279):
         every rank appends to its LOCAL shard (no collective on store); a sampled batch comes
         from ONE shard chosen as np.random.choice(num_shards) on the learner's seeded stream
-        (`ShardPicker`); the owner gathers and the 20 KB batch moves with one broadcast from the
-        owner (`fetch_batch`).
+        (`ShardPicker`); the owner draws all the batches it owes a learner for one step in one
+        launch sequence and sends them as ONE point-to-point block (partition.py: `_serve` /
+        `_receive`, RCCL send/recv) — no per-batch message, no broadcast.
   * 2 learners (BASELINE config 4) -> all-reduce(sum)/k of the flat gradient between learner ranks
         (`allreduce_mean_`); the reference's multi-learner is unsynchronised last-writer-wins
         (example/dsac.py:59-62,233), so this is a documented new synchronous semantics.
@@ -22,12 +23,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for 1 process)."""
+def init_from_env(backend=None, force=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for 1 process, unless `force` /
+    DDRL_DIST_FORCE=1 asks for a world-size-1 group: the same RCCL code path as N > 1 on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("DDRL_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -132,25 +136,3 @@ class ShardPicker:
 
     def next(self):
         return int(self.rs.randint(0, self.num_shards))
-
-
-def fetch_batch(local_batch_fn, owner, like, group=None):
-    """Move one sampled batch from the shard owner to every rank of the group (the learner uses
-    it; at 20 KB the transfer is latency-bound, one broadcast per tensor of the dict is avoided
-    by packing the batch into one flat buffer).
-
-    local_batch_fn() -> dict(obs1, obs2, acts, rews, done) is called on the owner only;
-    `like` is a dict of tensors giving shapes/dtypes/device on the receivers."""
-    names = ("obs1", "obs2", "acts", "rews", "done")
-    sizes = [int(like[k].numel()) for k in names]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=like["rews"].device)
-    if rank() == owner:
-        b = local_batch_fn()
-        torch.cat([b[k].reshape(-1) for k in names], out=flat)
-    if dist.is_initialized():
-        dist.broadcast(flat, src=owner, group=group)
-    out, off = {}, 0
-    for k, n in zip(names, sizes):
-        out[k] = flat[off:off + n].view(like[k].shape)
-        off += n
-    return out

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, Sto
     // (64-bit div/mod per element made this kernel 10x slower than the copy it is).
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool v4 = (width & 3) == 0;
+    const bool v4 = (width & 3) == 0 && aligned16(dst, src);
     const int wv = v4 ? width >> 2 : width;  // row width in vector elements
     const long long total = (n - skip) * wv;
     const long long base_row = (ptr + skip) % cap;  // ring row of source row `skip` (skip = n - cap is unbounded: reduce it once per thread)
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_store_masked(RingState *st, RingPtrs ri
     const float *src = srcs.a[which];
     float *dst = ring.a[which];
     const int width = ring.w[which];
-    const bool v4 = (width & 3) == 0;
+    const bool v4 = (width & 3) == 0 && aligned16(dst, src);
     const int wv = v4 ? width >> 2 : width;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * wv; e += stride) {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, co
     const int width = ring.w[j];
     const float *src = ring.a[j] + row * width;
     float *dst = out.a[j] + (long long)b * width;
-    if ((width & 3) == 0) {
+    if ((width & 3) == 0 && aligned16(out.a[j], ring.a[j])) {
         const int w4 = width >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, co
 // (or 4-B) element, all rows of an array in one grid-stride sweep — k_gather's workgroup-per-row would be launch-bound.
 __global__ void __launch_bounds__(256) k_gather_small(RingPtrs ring, BatchPtrs out, const long long *__restrict__ idx, int B) {
     const int j = blockIdx.y, width = ring.w[j];
-    const bool v4 = (width & 3) == 0;
+    const bool v4 = (width & 3) == 0 && aligned16(out.a[j], ring.a[j]);  // packed blocks start arrays at any float offset
     const unsigned wv = v4 ? width >> 2 : width, total = (unsigned)B * wv;
     for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
         const unsigned b = e / wv, c = e - b * wv;
@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(256) k_gather_small(RingPtrs ring, BatchPtrs o
 }
 
 __global__ void k_set_feed(RingState *st, Feed f) { st->feed = f; }
+__global__ void k_take_error(RingState *st, int *out) { *out = st->error; st->error = 0; }
 __global__ void k_add_samples(RingState *st, long long inc) { st->sample_times += inc; }
 
 __global__ void k_set_counts(RingState *st, long long ptr, long long size, long long steps, long long samples) {
@@ -230,6 +231,18 @@ static int refresh_counts(ddrl_replay *h, hipStream_t s) {
     DDRL_HIP_CHECK(hipStreamSynchronize(s));
     h->h_ptr = tmp.ptr; h->h_size = tmp.size; h->h_steps = tmp.steps; h->h_samples = tmp.sample_times;
     h->h_dirty = false;
+    if (tmp.error != 0) {
+        // a sampler that ran inside a graph / another kernel could not report to its caller: the first host call that
+        // looks at the ring does (and clears the flag, so that the caller can repair the plan and go on)
+        DDRL_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(h->state) + offsetof(RingState, error), 0, sizeof(int), s));
+        DDRL_HIP_CHECK(hipStreamSynchronize(s));
+        if (tmp.error == DDRL_ERR_EMPTY_BUFFER) {
+            ddrl::set_error("high <= 0");  // the sampler drew from an empty ring (the reference's ValueError)
+            return DDRL_ERR_EMPTY_BUFFER;
+        }
+        ddrl::set_error("a feed-plan entry was out of range (wrong batch size, region or batch index): that update trained on a stale input set");
+        return tmp.error;
+    }
     return DDRL_OK;
 }
 
@@ -506,6 +519,14 @@ int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_
     if (size_h) *size_h = h->h_size;
     if (steps_h) *steps_h = h->h_steps;
     if (sample_times_h) *sample_times_h = h->h_samples;
+    return DDRL_OK;
+}
+
+int ddrl_replay_take_error(ddrl_replay_t *h, int32_t *out_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && out_d != nullptr, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    k_take_error<<<1, 1, 0, ddrl::as_stream(stream)>>>(h->state, out_d);
+    DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
 

@@ -12,7 +12,7 @@ constexpr int SAMPLE_THREADS = 256;
 constexpr int MAX_FUSED_BATCH = 4096;          // idx staged in LDS for the fused sample+gather
 constexpr long long MAX_FUSED_BYTES = 1 << 18;  // fuse the gather when the whole batch is <= 256 KiB
 
-constexpr int MAX_FEED = 8;
+constexpr int MAX_FEED = 16;
 
 // Batches drawn on OTHER ranks' shards (partition.py): the learner's sampler follows a per-update plan held in
 // device memory — entry -1 = draw from the local ring, entry (r << 24 | i) = take batch i of region r, a block of
@@ -89,9 +89,13 @@ __device__ __forceinline__ void mt_twist_lds(uint32_t *mt, int tid) {
     __syncthreads();
 }
 
+__device__ __forceinline__ bool aligned16(const void *a, const void *b) {
+    return ((reinterpret_cast<unsigned long long>(a) | reinterpret_cast<unsigned long long>(b)) & 15ull) == 0;
+}
+
 __device__ __forceinline__ void gather_rows(const float *__restrict__ ring, float *__restrict__ out,
                                             const unsigned *s_idx, int B, int width, int tid, int nthreads) {
-    if ((width & 3) == 0) {
+    if ((width & 3) == 0 && aligned16(ring, out)) {
         const int w4 = width >> 2;
         const float4 *r4 = reinterpret_cast<const float4 *>(ring);
         float4 *o4 = reinterpret_cast<float4 *>(out);

@@ -37,6 +37,9 @@ import torch.distributed as dist
 from . import comm
 
 
+MAX_FEED_REGIONS = 16     # csrc/replay_device.h: MAX_FEED
+
+
 class Roles:
     """Who learns, who rolls out, who owns which shard."""
 
@@ -51,6 +54,12 @@ class Roles:
             self.learners = list(range(n_l))
             self.rollouts = list(range(n_l, self.world))          # config 4 at world 8: 2 learners + 6 rollout ranks
         self.shard_owner = list(self.rollouts)                     # shard s lives on rank shard_owner[s]
+        if not self.learners or not self.rollouts:
+            raise ValueError("world %d with %d learner rank(s) leaves no rollout rank / replay shard: need at least one of each"
+                             % (self.world, len(self.learners)))
+        if len(self.shard_owner) > MAX_FEED_REGIONS:
+            raise ValueError("%d shard owners: a learner's sampler follows at most %d remote blocks per step (ddrl_replay_set_feed)"
+                             % (len(self.shard_owner), MAX_FEED_REGIONS))
 
     @property
     def is_learner(self):
@@ -70,6 +79,9 @@ class Roles:
         return "%d learner rank(s) %s%s, %d rollout rank(s) %s with one replay shard each; batches = owner gather, one P2P block per (owner, learner) and step, params = RCCL broadcast" % (
             len(self.learners), self.learners, " (gradient all-reduce)" if len(self.learners) > 1 else "",
             len(self.rollouts), self.rollouts)
+
+
+PLAN_STAGES = 4           # pinned staging buffers for the step plan = how many steps the host may run ahead
 
 
 def _is_gloo():
@@ -97,7 +109,8 @@ class _Recv:
     def wait(self):
         self.work.wait()
         if self.stage is not None:
-            self.buf.copy_(self.stage, non_blocking=False)
+            # pinned staging: the host allocator keeps the block alive until the copy's event has passed
+            self.buf.copy_(self.stage, non_blocking=self.stage.is_pinned())
         return self.buf
 
 
@@ -167,7 +180,8 @@ class PartitionedRun:
     only learner, eager compute / all-reduce / apply per update with several; every `push_freq` updates learner 0
     broadcasts the flat parameter vector and the rollout ranks adopt it."""
 
-    def __init__(self, opt, roles, make_replay, make_rollout, make_learner, seed=0, push_freq=None, device=None, updates_per_graph=16):
+    def __init__(self, opt, roles, make_replay, make_rollout, make_learner, seed=0, push_freq=None, device=None, updates_per_graph=16,
+                 force_dp=False):
         self.opt, self.roles = opt, roles
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.B = int(opt.batch_size)
@@ -179,10 +193,11 @@ class PartitionedRun:
         from .agent import param_specs
         self.n_params = int(sum(int(np.prod(sh)) for _, sh in param_specs(opt.obs_dim, opt.act_dim, opt.hidden_sizes[0], opt.hidden_sizes[1],
                                                                           ("pi", "q1", "q2"))))
-        self.bcast = comm.ParamBroadcast(self.n_params, self.device, src=roles.learners[0]) if roles.world > 1 else None
+        # (a world-size-1 process group still broadcasts: the one-GPU box drives the same RCCL calls as N > 1)
+        self.bcast = comm.ParamBroadcast(self.n_params, self.device, src=roles.learners[0]) if (roles.world > 1 or dist.is_initialized()) else None
         self.roll = make_rollout(self.rb) if roles.is_rollout else None
         self.lgroup = None
-        if len(roles.learners) > 1 and dist.is_initialized():
+        if (len(roles.learners) > 1 or force_dp) and dist.is_initialized():   # force_dp: the data-parallel step with a group of one
             self.lgroup = dist.new_group(ranks=roles.learners)   # collective: every rank calls it
         self.cnt = 0                                  # updates done (per learner)
         self.feed_ring, self.loop, self.batch_buf = None, None, None
@@ -197,7 +212,11 @@ class PartitionedRun:
             else:
                 self.dp_grads, self.dp_apply, self.dp_g = self.learner.dp_stepper(self.feed_ring)
         self.send_bufs, self.regions = {}, {}
-        self.plan_d, self.plan_h = None, None
+        # the step's plan goes host -> device with an async copy while the host runs ahead of the device by whole
+        # steps: a pinned staging buffer is rewritten only after the event behind its last copy has completed
+        self.plan_d, self.plan_stage, self.plan_turn = None, [], 0
+        self.err_d = torch.zeros(1, dtype=torch.int32, device=self.device) if self.learner is not None else None
+        self.err_stage = []                           # [(pinned int32[1], event)] of the steps in flight
         self.sends = []
         self.stats = {"local_batches": 0, "remote_batches": 0, "sent_batches": 0, "sent_blocks": 0, "pushes": 0}
         self.last_plan = None
@@ -262,9 +281,15 @@ class PartitionedRun:
         n = len(owners)
         if self.plan_d is None or self.plan_d.numel() < n:
             self.plan_d = torch.empty(max(n, 64), dtype=torch.int32, device=self.device)
-            self.plan_h = torch.empty(max(n, 64), dtype=torch.int32).pin_memory()
-        self.plan_h[:n].copy_(torch.from_numpy(plan))
-        self.plan_d[:n].copy_(self.plan_h[:n], non_blocking=True)
+            self.plan_stage = [[torch.empty(max(n, 64), dtype=torch.int32).pin_memory(), None] for _ in range(PLAN_STAGES)]
+        stage = self.plan_stage[self.plan_turn % PLAN_STAGES]
+        self.plan_turn += 1
+        if stage[1] is not None:
+            stage[1].synchronize()                    # the copy that last read this staging buffer is done
+        stage[0][:n].copy_(torch.from_numpy(plan))
+        self.plan_d[:n].copy_(stage[0][:n], non_blocking=True)   # stream order puts it behind the previous step's updates
+        stage[1] = torch.cuda.Event()
+        stage[1].record()
         self.feed_ring.set_feed(self.plan_d[:n], self.B, regions)
         for r in recvs:
             r.wait()
@@ -290,7 +315,25 @@ class PartitionedRun:
             self.stats[key] = self.stats.get(key, 0.0) + (t1 - t0)
         return t1
 
+    def _poll_error(self, drain=False):
+        """The sampler's sticky device-side error (a plan entry out of range, a local draw from an empty ring) of the steps
+        whose updates have finished — one step behind the host, so that the device keeps running ahead."""
+        while self.err_stage and (drain or len(self.err_stage) >= PLAN_STAGES - 1 or self.err_stage[0][1].query()):
+            word, ev = self.err_stage.pop(0)
+            ev.synchronize()
+            rc = int(word[0])
+            if rc != 0:
+                raise ValueError("replay sampler error %d on rank %d: %s" % (rc, self.roles.rank,
+                                 "local draw from an empty ring (high <= 0)" if rc == -2 else "a feed-plan entry was out of range; that update trained on a stale input set"))
+
+    def check(self):
+        """Drain the device and raise what its samplers reported."""
+        if self.learner is not None:
+            self._poll_error(drain=True)
+
     def step(self, n_updates):
+        if self.learner is not None:
+            self._poll_error()
         t = self._tick(None, 0.0)
         if self.roll is not None:
             self.roll.step()
@@ -320,4 +363,11 @@ class PartitionedRun:
         for w in self.sends:
             w.wait()
         self.sends = []
+        if self.learner is not None:
+            self.feed_ring.take_error(self.err_d)
+            word = torch.empty(1, dtype=torch.int32).pin_memory()
+            word.copy_(self.err_d, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.err_stage.append((word, ev))
         self._tick("s_drain", t)

@@ -125,6 +125,11 @@ class ReplayBuffer:
         _lib.check(self._lib.ddrl_replay_set_feed(self._h, _lib.dptr(plan), int(plan.numel()), int(batch_size), n, base, cnt, _lib.stream_ptr()))
         self._feed_keep = (plan, [t for t, _ in regions])   # the kernels read these until the next set_feed
 
+    def take_error(self, out):
+        """Move the sampler's sticky device-side error into out[0] (int32 device tensor) and clear it; no sync."""
+        assert out.dtype == torch.int32 and out.is_cuda
+        _lib.check(self._lib.ddrl_replay_take_error(self._h, _lib.dptr(out), _lib.stream_ptr()))
+
     def get_counts(self):
         """example/dsac.py:47-48: number of store() calls so far."""
         return self._counts()[2]

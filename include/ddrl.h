@@ -120,9 +120,16 @@ int ddrl_replay_sample_many(ddrl_replay_t *h, int64_t batch, int64_t count, floa
  * region r instead, consuming no local draw.  Region r is a block that ddrl_replay_sample_many produced on the
  * owning rank: region_base_h[r] (device) -> [obs1 | obs2 | ...] with each array [region_count_h[r]*batch, w_j].
  * The plan position restarts at 0 on every call; plan_d and the regions must stay valid while attached.
- * plan_d == NULL detaches.  n_regions <= 8.  A plan entry out of range sets the ring's sticky error. */
+ * plan_d == NULL detaches.  n_regions <= 16.  A plan entry that is out of range (wrong batch, region or batch index)
+ * or a local draw from an empty ring cannot fail the call that launched it (it may run inside a captured graph): it
+ * leaves the output untouched and sets the ring's sticky device-side error, which the next ddrl_replay_counts
+ * returns (DDRL_ERR_BAD_ARG / DDRL_ERR_EMPTY_BUFFER) and clears. */
 int ddrl_replay_set_feed(ddrl_replay_t *h, const int32_t *plan_d, int32_t plan_len, int32_t batch, int32_t n_regions,
                          const float *const *region_base_h, const int32_t *region_count_h, void *stream);
+/* Move the ring's sticky device-side error (0 = none) to out_d[0] (DEVICE int32) and clear it, in stream order and
+ * without synchronising: a caller that keeps the device running ahead (partition.py) copies the word back behind an
+ * event and looks at it one step later. */
+int ddrl_replay_take_error(ddrl_replay_t *h, int32_t *out_d, void *stream);
 int ddrl_replay_buffers_ex(ddrl_replay_t *h, float **arrays_h, int32_t *widths_h, int32_t *n_arrays_h);
 
 /* Raw ring pointers (device) for checkpointing / inspection (algos/dqn/train.py:82-90 saves
@@ -267,7 +274,8 @@ int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t
 int ddrl_sac1_input_buffers(ddrl_sac1_t *h, int set, float **bufs_h);
 /* The batch size the learner was created with. */
 int ddrl_sac1_batch(ddrl_sac1_t *h);
-/* 1 when this handle's shape runs the fused 6-launch update (csrc/sac1_fused.h), 0 on the generic 9-launch path. */
+/* 1 when this handle's shape runs the five-launch direct-operand update (csrc/sac1_direct.h: hidden sizes % 4 == 0 and
+ * <= 512, obs + act <= 12, act <= 4), 0 on the generic 9-launch path (k_l1 / k_gemm / k_rows_* / k_adam_polyak). */
 int ddrl_sac1_is_fused(ddrl_sac1_t *h);
 /* Arm noise generation for the NEXT ddrl_sac1_step / compute_grads: its first kernel fills the
  * three noise buffers of the input set in use with N(0,1) from the counter generator
@@ -279,11 +287,16 @@ int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream);
 /* Roofline accounting (bench.py): launch one stage of the update `reps` times back to back on
  * `stream` between two HIP events (after 3 untimed launches) and return the mean milliseconds
  * per launch (host output); synchronises `stream`.  The stages read the buffers left by the last
- * ddrl_sac1_step and are idempotent.  Stage ids (launch order of one update):
- * 1 layer1 (8 nets; + noise) 2 gemm fwd(A: 5 nets) 3 heads(A) + 2nd-phase layer1 4 (folded into 3)
- * 5 gemm fwd(B: 3 nets) 6 heads(B)+losses 7 gemm bwd(Q: 3 dgrad + 4 wgrad) 8 policy-head bwd
- * 9 gemm bwd(pi: 1 dgrad [+ fused layer-1 wgrad partials] + 5 wgrad) 10 (pi layer-1 wgrad; only
- * when the fused form is unavailable).  [0 = input staging copy, 11 = adam+polyak: not idempotent] */
+ * ddrl_sac1_step and are idempotent.  Stage ids:
+ *   direct-operand path (ddrl_sac1_is_fused == 1), the five launches of one update in launch order:
+ *     2 k_dfwd<0> (evaluations 0-4: layer 1 + layer 2 + head partials)   5 k_dfwd<1> (evaluations 5-7; + the next
+ *     batch's sampler when one is armed)   7 k_dg "bq" (Q heads / losses / the three Q dgrads)   8 k_dg "mid" (policy-head
+ *     backward + Q layer-2 / head wgrads)   9 k_dg "pi" (policy dgrad + policy wgrads + Q layer-1 wgrads); 8 and 9 run with
+ *     their optimizer epilogues exactly as the last step left them armed; 1, 3, 4, 6, 10 are no-ops there;
+ *   generic path: 1 layer 1 (8 nets; + noise) 2 gemm fwd (A: 5 nets) 3 heads (A) + 2nd-phase layer 1 5 gemm fwd (B: 3
+ *     nets) 6 heads (B) + losses 7 gemm bwd (Q: 3 dgrad + 4 wgrad) 8 policy-head bwd 9 gemm bwd (pi: 1 dgrad + 5 wgrad)
+ *     10 pi layer-1 wgrad.
+ *   [0 = input staging copy, 11 = adam + polyak: not idempotent, not timed here] */
 #define DDRL_SAC1_STAGES 12
 int ddrl_sac1_stage_time(ddrl_sac1_t *h, int stage, int reps, float *ms_per_launch_h, void *stream);
 

@@ -1,0 +1,90 @@
+"""Child of tests/test_gpu_rccl.py (a fresh process: the process group must be created before anything else touches the
+GPU).  World size 1 on backend "nccl" (= RCCL): every torch.distributed call the N > 1 runs make — init, broadcast,
+all-reduce AVG, barrier, new_group, and PartitionedRun's own step — goes through RCCL here, with no gloo branch taken.
+The reference traffic these replace: ps.push / ps.pull (example/dsac.py:59-65), the per-shard sample RPC
+(algos/sac1/sac_ray.py:137-141)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", DDRL_DIST_FORCE="1")
+os.environ.setdefault("MASTER_PORT", "29517")
+os.environ.pop("DDRL_DIST_BACKEND", None)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import distributed_drl_amd as d  # noqa: E402
+from distributed_drl_amd import _lib, comm, partition  # noqa: E402
+from distributed_drl_amd.agent import HyperParameters, Learner  # noqa: E402
+from distributed_drl_amd.workers import RolloutDevice  # noqa: E402
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    r, w, local = comm.init_from_env()
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl", dist.get_backend()
+    assert not partition._is_gloo()
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    # ---- comm.py over RCCL ---------------------------------------------------------------------
+    n = 375106
+    pb = comm.ParamBroadcast(n, dev, src=0)
+    flat = torch.arange(n, dtype=torch.float32, device=dev) * 0.25
+    assert torch.equal(pb.sync(flat), flat) and pb.version == 1
+    g = torch.randn(n, device=dev)
+    g0 = g.clone()
+    comm.allreduce_mean_(g)                                    # ReduceOp.AVG inside RCCL
+    assert torch.equal(g, g0)
+    grp = dist.new_group(ranks=[0])
+    comm.allreduce_mean_(g, group=grp)
+    assert torch.equal(g, g0)
+    comm.barrier()
+    assert comm.allreduce_max(3.5, device=dev) == 3.5 and comm.allreduce_sum(2.0, device=dev) == 2.0
+    print("rccl comm ok", flush=True)
+    if what == "comm":
+        return
+
+    # ---- PartitionedRun at world 1 through the N > 1 code path --------------------------------
+    opt = HyperParameters()
+    opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = 64, 32, 5, -1, 50, 6
+
+    def shard():
+        rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 4096, seed=100)
+        rs = np.random.RandomState(0)
+        m = 500
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in (
+            rs.randn(m, 8).astype(np.float32), rs.uniform(-1, 1, (m, 2)).astype(np.float32), np.arange(m, dtype=np.float32),
+            rs.randn(m, 8).astype(np.float32), np.zeros(m, np.float32))))
+        return rb
+
+    def run_it(force_dp, per_graph):
+        roles = partition.Roles(1, 0)
+        run = partition.PartitionedRun(opt, roles, shard, lambda rb: RolloutDevice(None, rb, opt, worker_index=0),
+                                       lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=per_graph, force_dp=force_dp)
+        assert run.bcast is not None and (run.lgroup is not None) == force_dp
+        for _ in range(5):
+            run.step(4)                                        # 20 updates: pushes (RCCL broadcasts) at 6, 12, 18 + the initial one
+        torch.cuda.synchronize()
+        run.check()
+        assert run.learner.opt_steps() == (20, 20) and run.stats["pushes"] == 4
+        assert run.rb.get_counts() == (20, 500 + 5 * 64, 500 + 5 * 64)
+        n_pi = run.roll.actor.n_params
+        assert torch.equal(run.roll.actor.get_weights_flat(), run.bcast.buf[:n_pi])     # the rollout runs push #3's policy
+        return run.learner.get_weights_flat().cpu().numpy()
+
+    w_loop = run_it(False, 2)          # single learner: graph-captured loop + broadcast
+    w_dp = run_it(True, 0)             # data-parallel step with a group of one: gradients -> RCCL all-reduce AVG -> apply
+    np.testing.assert_array_equal(w_loop, w_dp)
+    print("rccl partition ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    print("RCCL_WORLD1_OK", flush=True)

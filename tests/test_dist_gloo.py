@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: world_size-2 gloo process group exercising comm.py (parameter broadcast,
-shard choice, batch fetch from the shard owner, gradient mean)."""
+"""N > 1 path on CPU: world_size-2 gloo process group exercising comm.py (parameter broadcast, shard choice,
+gradient mean) and partition.py's block transport (one point-to-point message per owner, learner and step)."""
 import os
 import socket
 import sys
@@ -43,26 +43,39 @@ def _worker(rank, world, port, q):
         off, cnt = pb.span(("main/pi/a", "main/pi/b"))
         assert torch.equal(pb.pull_flat(off, cnt), want[:125104])
 
-        # ---- replay shards: local store, shard choice on a shared stream, owner gathers ------
+        # ---- replay shards: local store, shard choice on a shared stream, ONE P2P block per (owner, learner, step) ----
+        from distributed_drl_amd import partition
+        B, n_upd = 16, 11
         shard = ReplayBufferOracle(8, 2, 64, seed=100 + rank)   # test double for the device ring
         rs = np.random.RandomState(rank)
         for i in range(40):
             shard.store(rs.randn(8), rs.randn(2), float(rank * 1000 + i), rs.randn(8), i % 5 == 0)
-        picker = comm.ShardPicker(world, seed=7)
-        like = dict(obs1=torch.empty(16, 8), obs2=torch.empty(16, 8), acts=torch.empty(16, 2),
-                    rews=torch.empty(16), done=torch.empty(16))
-        owners = []
-        for it in range(6):
-            owner = picker.next()
-            owners.append(owner)
-            b = comm.fetch_batch(lambda: {k: torch.from_numpy(v) for k, v in shard.sample_batch(16).items()},
-                                 owner, like)
-            # a batch never mixes shards (sac_ray.py:137-141): rewards carry the owner's tag
-            assert ((b["rews"] >= owner * 1000) & (b["rews"] < owner * 1000 + 40)).all()
-            assert b["obs1"].shape == (16, 8) and b["acts"].shape == (16, 2)
-        np.random.seed(7)   # the reference's call: np.random.choice(num_shards, 1)[0]
-        assert owners == [int(np.random.choice(world, 1)[0]) for _ in range(6)]
-        assert shard.sample_times == owners.count(rank)   # only the owner's stream advanced
+        roles = partition.Roles(world, rank)                    # config 3: learner on rank 0, a shard on both ranks
+        sched = partition.Schedule(roles, seed=7)
+        nf = partition.batch_floats(8, 2, B)
+        served = 0
+        for step in range(2):
+            plans = [sched.next() for _ in range(n_upd)]
+            owners = [p[0][1] for p in plans]
+            if step == 0:
+                np.random.seed(7)   # the reference's call: np.random.choice(num_shards, 1)[0]
+                assert owners == [int(np.random.choice(world, 1)[0]) for _ in range(n_upd)]
+            k = owners.count(1)
+            if rank == 1:           # owner: the k batches it owes the learner, as one block [obs1 | obs2 | acts | rews | done]
+                drawn = [shard.sample_batch(B) for _ in range(k)]
+                blk = torch.from_numpy(np.concatenate([np.concatenate([b[key].reshape(-1) for b in drawn])
+                                                       for key in ("obs1", "obs2", "acts", "rews", "done")]).astype(np.float32))
+                assert blk.numel() == k * nf
+                partition._send(blk, 0).wait()
+                served += k
+                assert shard.sample_times == served
+            else:                   # learner: one receive; batch i of the block = rows [i B, (i + 1) B) of every array
+                got = partition._Recv(torch.empty(k * nf), 1).wait()
+                rews = got[k * B * 18: k * B * 19].view(k, B)
+                assert ((rews >= 1000) & (rews < 1040)).all()   # a batch never mixes shards (sac_ray.py:137-141)
+                v = partition.batch_views(got[: nf], 8, 2, B) if k == 1 else None
+                assert v is None or v["obs1"].shape == (B, 8)
+                assert shard.sample_times == 0                  # only the owner's stream advanced for the remote batches
 
         # ---- learner gradient all-reduce (mean) ------------------------------------------------
         g = torch.full((1000,), float(rank + 1))
@@ -98,8 +111,3 @@ def test_single_process_fallbacks():
     assert comm.allreduce_mean_(g) is g and comm.allreduce_max(3.0) == 3.0
     pb = comm.ParamBroadcast(10, torch.device("cpu"))
     assert torch.equal(pb.sync(torch.arange(10.0)), torch.arange(10.0))
-    b = comm.fetch_batch(lambda: dict(obs1=torch.ones(2, 8), obs2=torch.zeros(2, 8), acts=torch.ones(2, 2),
-                                      rews=torch.arange(2.0), done=torch.zeros(2)),
-                         0, dict(obs1=torch.empty(2, 8), obs2=torch.empty(2, 8), acts=torch.empty(2, 2),
-                                 rews=torch.empty(2), done=torch.empty(2)))
-    assert torch.equal(b["rews"], torch.arange(2.0))

@@ -341,3 +341,54 @@ def test_feed_plan_interleaves_remote_blocks_with_local_draws(ddrl):
     got = _packed(ghost.sample_batch_device(B, fresh=True))
     blk = blocks[1].cpu().numpy()
     np.testing.assert_array_equal(got[:B * 8], blk[B * 8: 2 * B * 8])
+    # the ghost's second call has no plan entry left -> a local draw from the empty ring: the launch itself cannot fail
+    # (it may be a graph node), the next look at the counters raises the reference's error and clears it
+    ghost.sample_batch_device(B, fresh=True)
+    with pytest.raises(ValueError, match="high <= 0"):
+        ghost.get_counts()
+    assert ghost.get_counts() == (0, 0, 0)
+
+
+def test_bad_feed_plan_entry_is_reported_not_swallowed(ddrl):
+    """A plan entry that names a batch / region the step does not have leaves the output untouched on the device — the
+    host must hear about it: ddrl_replay_counts returns the sticky error once, ddrl_replay_take_error moves it without
+    a sync."""
+    B, nf = 64, 64 * 20
+    owner = _filled(ddrl, 7, data_seed=1)
+    blk = owner.sample_many(B, 3, torch.empty(3 * nf, dtype=torch.float32, device="cuda"))
+    local = _filled(ddrl, 9)
+    for bad in (0 << 24 | 3, 1 << 24 | 0):                      # batch index == count; region index == n_regions
+        local.set_feed(torch.tensor([bad], dtype=torch.int32, device="cuda"), B, [(blk, 3)])
+        local.sample_batch_device(B, fresh=True)
+        with pytest.raises(ValueError, match="feed-plan"):
+            local.get_counts()
+        local.get_counts()                                       # cleared
+    local.set_feed(torch.tensor([0 << 24 | 2], dtype=torch.int32, device="cuda"), B + 1, [(blk, 3)])   # plan laid for another batch size
+    local.sample_batch_device(B, fresh=True)
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    local.take_error(word)
+    assert int(word.item()) == -1
+    local.take_error(word)
+    assert int(word.item()) == 0
+    local.get_counts()
+
+
+@pytest.mark.parametrize("obs,act,B,K", [(3, 4, 5, 3), (3, 4, 33, 1), (4, 4, 7, 3), (5, 8, 4097, 1)])
+def test_packed_blocks_at_unaligned_float_offsets(ddrl, obs, act, B, K):
+    """sample_many packs the arrays back to back: an array whose width is a multiple of 4 can start at a float offset
+    that is not (obs 3, act 4, K*B odd -> acts at 6 K B floats) — the gathers must not assume 16-byte alignment.  Rows
+    checked against the ring at NumPy's own indices; K*B >= 4096 takes the many-small-rows gather."""
+    n = 3000
+    a = _filled(ddrl, 11, n=n, obs=obs, act=act)
+    nf = B * (2 * obs + act + 2)
+    base = torch.empty(K * nf + 1, dtype=torch.float32, device="cuda")
+    for shift in (0, 1):                                         # shift 1: every array base off by 4 bytes as well
+        a.seed(11)
+        blk = a.sample_many(B, K, base[shift:shift + K * nf]).cpu().numpy()
+        np.random.seed(11)
+        idx = np.random.randint(0, n, B * K)
+        g, off = a.rings(), 0
+        for name, w in (("obs1_buf", obs), ("obs2_buf", obs), ("acts_buf", act), ("rews_buf", 1), ("done_buf", 1)):
+            want = g[name].cpu().numpy().reshape(-1, w)[idx].reshape(-1)
+            np.testing.assert_array_equal(blk[off: off + K * B * w], want, err_msg="%s shift %d" % (name, shift))
+            off += K * B * w

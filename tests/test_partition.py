@@ -27,6 +27,11 @@ def test_roles_match_the_baseline_configs():
     assert [r.is_learner for r in rs] == [True, True] + [False] * 6 and rs[1].my_shard is None and rs[5].my_shard == 3
     assert Roles(4, 0).learners == [0] and Roles(4, 3).rollouts == [1, 2, 3]
     assert "gradient all-reduce" in rs[0].describe()
+    # sizes the partition cannot serve fail at construction with a clear message, not in the middle of a run
+    for world, nl in ((2, 2), (3, 3), (24, None)):
+        with pytest.raises(ValueError, match="rollout rank|shard owners"):
+            Roles(world, 0, num_learners=nl)
+    assert len(Roles(16, 0).shard_owner) == 12                  # 12 remote blocks per step <= MAX_FEED (16)
 
 
 def test_schedule_is_the_reference_choice_stream_and_identical_on_every_rank():
@@ -155,11 +160,68 @@ def _gpu_worker(rank, world, port, q, num_learners):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def _spawn(world, num_learners):
+def _gpu_worker_async(rank, world, port, q, num_learners):
+    """The same partitioned run twice — once drained after every step (the order the test above checks batch by batch),
+    once with the host running whole steps ahead of the device (graph-captured loop, several updates per step, no
+    synchronisation until the end): identical parameters, counters and sampler state, i.e. no staging buffer, plan or
+    region was rewritten under a step still in flight."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          DDRL_DIST_BACKEND="gloo")
+        import distributed_drl_amd as d
+        from distributed_drl_amd import _lib, comm, partition
+        from distributed_drl_amd.agent import HyperParameters, Learner
+        from distributed_drl_amd.workers import RolloutDevice
+        r, w, _ = comm.init_from_env()
+        torch.cuda.set_device(0)
+        _lib.require_gpu()
+        opt = HyperParameters()
+        opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = 64, 32, 5, -1, 50, 7
+        roles = partition.Roles(w, r, num_learners=num_learners)
+        n_steps, per_step = 9, 5        # 45 updates: pushes at 7, 14, ... fall inside steps; 9 steps > PLAN_STAGES
+
+        def one(drain):
+            run = partition.PartitionedRun(opt, roles, lambda: _prefilled_shard(d, opt, r), lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
+                                           lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=2)
+            for _ in range(n_steps):
+                run.step(per_step)
+                if drain:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            run.check()
+            out = {"stats": {k: v for k, v in run.stats.items() if not k.startswith("s_")}}
+            if run.learner is not None:
+                out["w"] = run.learner.get_weights_flat().cpu().numpy()
+                out["opt"] = run.learner.opt_steps()
+            if run.rb is not None:
+                out["counts"] = run.rb.get_counts()
+                out["mt"] = run.rb.mt_state()[1]
+            if run.roll is not None:
+                out["pi"] = run.roll.actor.get_weights_flat().cpu().numpy()
+            comm.barrier()
+            return out
+
+        a, b = one(True), one(False)
+        assert a["stats"] == b["stats"], (a["stats"], b["stats"])
+        for k in ("opt", "counts", "mt"):
+            assert a.get(k) == b.get(k), (k, a.get(k), b.get(k))
+        for k in ("w", "pi"):
+            if k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        if roles.is_learner:
+            assert a["opt"] == (n_steps * per_step,) * 2 and a["stats"]["pushes"] == 1 + (n_steps * per_step) // 7
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def _spawn(world, num_learners, target=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, num_learners)) for r in range(world)]
+    procs = [ctx.Process(target=target or _gpu_worker, args=(r, world, port, q, num_learners)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -180,3 +242,11 @@ def test_config4_roles_three_ranks_on_one_gpu_two_learners_one_shard():
     """Config 4's roles at the smallest size (2 data-parallel learner ranks + 1 rollout rank with the shard): the owner
     serves both learners' blocks, the learners all-reduce their gradients and stay bit-identical."""
     _spawn(3, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,num_learners", [(2, None), (3, 2)])
+def test_host_running_steps_ahead_of_the_device_changes_nothing(world, num_learners):
+    """No per-step synchronisation, graph-captured learner loop with a feed attached, several updates per step: the end
+    state equals the drained run's (staged plans / blocks are never rewritten under a step in flight)."""
+    _spawn(world, num_learners, target=_gpu_worker_async)
