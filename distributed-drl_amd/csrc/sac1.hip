@@ -747,7 +747,7 @@ struct ddrl_sac1 {
     DGJobs dg_bq[2], dg_mid, dg_pi;
     // direct-path activations (x4 images, see sac1_direct.h) and the dgrad images of the main layer-2 kernels
     int Lp1, Lp2;
-    float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq;
+    float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq, *w3snap;
     float *c4_pi[2], *c4_q[3];   // c4_q[2]: V (SAC-v)
     float *xv_r4;                // SAC-v: the [x | 1] image of V's layer-1 wgrad
     int *part_cnt;       // arrival counters of the policy layer-1 partials (one per column tile)
@@ -961,9 +961,10 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
             j.wa = Pm + L.q_W1[0]; j.wa_d0 = o; j.da_part = h->da_part; j.nact = a;
             dg_add(Q, j);
         }
-        dg_add(Q, dq_job(0, 1, 0, h->dZ1r4));
-        dg_add(Q, dq_job(1, 2, 1, h->dZ1r4 + H1I));
-        dg_add(Q, dq_job(3, 4, 2, h->dZ1r4 + 2 * H1I));
+        // (the W3 snapshots for the next launch's generated wgrad operands: one per value network)
+        { DGJob j = dq_job(0, 1, 0, h->dZ1r4); j.gw_snap = h->w3snap; dg_add(Q, j); }
+        { DGJob j = dq_job(1, 2, 1, h->dZ1r4 + H1I); j.gw_snap = h->w3snap + 512; dg_add(Q, j); }
+        { DGJob j = dq_job(3, 4, 2, h->dZ1r4 + 2 * H1I); j.gw_snap = h->w3snap + 1024; dg_add(Q, j); }
     }
     float *G = h->grad;
     const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, nullptr, L.n_pi_int,
@@ -997,7 +998,7 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
         dg_add(M, ls);
         for (int q = 0; q < 3; ++q) {
             DGJob j = wgrad_j4(h->H1r4 + img1[q] * H1I, h->H2r4 + img2r[q] * H2R, vW2[q], vb2[q], h->c4_q[q]);
-            j.bgen = 1; j.gw = Pm + vW3[q]; j.gdq = h->dq + (long long)q * B;
+            j.bgen = 1; j.gw = h->w3snap + 512 * q; j.gdq = h->dq + (long long)q * B;   // (W3 as the previous launch saw it)
             dg_add(M, j);
         }
         for (int q = 0; q < 3; ++q) dg_add(M, wgrad_rm(h->H2r4 + img2r[q] * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, vW3[q]));
@@ -1089,7 +1090,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         ALLOC(H1r4, (size_t)(4 + xv) * B * h->Lp1); ALLOC(H2c4, (size_t)(4 + xv) * Np2 * B); ALLOC(H2r4, (size_t)(3 + xv) * B * h->Lp2);
         ALLOC(dZ1r4, (size_t)(2 + xv) * B * h->Lp1); ALLOC(dzpi_c4, (size_t)Np2 * B); ALLOC(dzpi_r4, (size_t)B * h->Lp2);
         ALLOC(dhead_r4, (size_t)B * 32); ALLOC(xa_r4, (size_t)B * 32); ALLOC(xv_r4, (size_t)B * 32); ALLOC(da_part, (size_t)16 * B * 4);
-        ALLOC(dq, (size_t)3 * B + 256);
+        ALLOC(dq, (size_t)3 * B + 256); ALLOC(w3snap, (size_t)3 * 512);
         for (int i = 0; i < 2; ++i) items.push_back(Item{&h->c4_pi[i], reserve((size_t)Np2 * Kp1)});
         for (int i = 0; i < 2 + xv; ++i) items.push_back(Item{&h->c4_q[i], reserve((size_t)Np2 * Kp1)});
     }
@@ -1290,8 +1291,9 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 j.wa = Pm + L.q_W1[0]; j.wa_d0 = o; j.da_part = h->da_part; j.nact = a;
                 dg_add(Q, j);
             }
-            dg_add(Q, dq_job(0, 1, 0, h->dZ1r4));
-            dg_add(Q, dq_job(1, 2, 1, h->dZ1r4 + H1I));
+            // (the W3 snapshots for the next launch's generated wgrad operands)
+            { DGJob j = dq_job(0, 1, 0, h->dZ1r4); j.gw_snap = h->w3snap; dg_add(Q, j); }
+            { DGJob j = dq_job(1, 2, 1, h->dZ1r4 + H1I); j.gw_snap = h->w3snap + 512; dg_add(Q, j); }
         }
         float *G = h->grad;
         const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, nullptr, L.n_pi_int,
@@ -1324,7 +1326,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             dg_add(M, ls);
             for (int q = 0; q < 2; ++q) {
                 DGJob j = wgrad_j4(h->H1r4 + (1 + q) * H1I, h->H2r4 + (1 + q) * H2R, L.q_W2[q], L.q_b2[q], h->c4_q[q]);
-                j.bgen = 1; j.gw = Pm + L.q_W3[q]; j.gdq = h->dq + (long long)q * B;
+                j.bgen = 1; j.gw = h->w3snap + 512 * q; j.gdq = h->dq + (long long)q * B;   // (W3 as the previous launch saw it)
                 dg_add(M, j);
             }
             for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));

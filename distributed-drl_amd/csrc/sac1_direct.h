@@ -716,6 +716,9 @@ struct DGJob {
     // generated operands
     const float *gw;         // DGRAD_Q: W3[k] (A = dq[row] * W3[k] * (H2 > 0));  WGRAD with bgen: W3[n] (B = dq[r] * W3[n] * (H2 > 0))
     const float *gdq;        // DGRAD_Q: nullptr -> the constant gconst;  bgen: dq[r] (flat [B])
+    float *gw_snap;          // DGRAD_Q (nullable): tile (0, 0) copies W3 here for the NEXT launch's generated wgrad operand — that launch
+                             // also steps W3 (Adam in the head-wgrad epilogue), and a gradient must see the pre-update kernel whichever
+                             // workgroup runs first
     float gconst;
     int bgen;
     int slot;                // DGRAD_Q: 0 q1(x,a)  1 q2(x,a)  2 q1(x,pi)
@@ -935,6 +938,10 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         gv0 = gp[tid < glen ? tid : 0];
         gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
         if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
+        if (type == DG_DGRAD_Q && jb.gw_snap && t == 0) {  // block-uniform
+            if (tid < glen) jb.gw_snap[tid] = gv0;
+            if (tid + 256 < glen) jb.gw_snap[tid + 256] = gv1;
+        }
     }
     // both operand streams of this wave: unconditional loads, groups beyond ng re-read the last one (a branch or a
     // select in front of a load makes the compiler wait for the previous load before issuing the next)

@@ -180,37 +180,67 @@ def _gpu_worker_async(rank, world, port, q, num_learners):
         opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = 64, 32, 5, -1, 50, 7
         roles = partition.Roles(w, r, num_learners=num_learners)
         n_steps, per_step = 9, 5        # 45 updates: pushes at 7, 14, ... fall inside steps; 9 steps > PLAN_STAGES
+        if os.environ.get("DIAG_TRACE") == "2":
+            n_steps, per_step = 45, 1
+        per_graph = int(os.environ.get("DIAG_PER_GRAPH", "2"))
+        opt.push_freq = int(os.environ.get("DIAG_PUSH_FREQ", "7"))
 
         def one(drain):
             run = partition.PartitionedRun(opt, roles, lambda: _prefilled_shard(d, opt, r), lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
-                                           lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=2)
+                                           lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=per_graph)
+            import zlib
+            trace = []
+            crc = lambda t: zlib.crc32(t.detach().cpu().numpy().tobytes())
             for _ in range(n_steps):
                 run.step(per_step)
                 if drain:
                     torch.cuda.synchronize()
+                    if os.environ.get("DIAG_TRACE") and run.learner is not None:
+                        from distributed_drl_amd import _lib as L_
+                        item = {"w": crc(run.learner.get_weights_flat()), "plan": [int(v) for v in run.last_plan]}
+                        for nm, wh in (("g", L_.SAC1_GRAD), ("m", L_.SAC1_ADAM_M), ("t", L_.SAC1_TARGET)):
+                            item[nm] = crc(run.learner.export(wh))
+                        if os.environ.get("DIAG_TRACE") == "2":
+                            item["_g"] = run.learner.export(L_.SAC1_GRAD).cpu().numpy()
+                        for st in (0, 1):
+                            item.update({"in%d_%s" % (st, k): crc(v) for k, v in run.learner.input_batch(st).items()})
+                        item.update({"region%d" % o: crc(t) for o, t in run.regions.items()})
+                        trace.append(item)
             torch.cuda.synchronize()
             run.check()
-            out = {"stats": {k: v for k, v in run.stats.items() if not k.startswith("s_")}}
+            out = {"trace": trace, "stats": {k: v for k, v in run.stats.items() if not k.startswith("s_")}}
             if run.learner is not None:
                 out["w"] = run.learner.get_weights_flat().cpu().numpy()
                 out["opt"] = run.learner.opt_steps()
             if run.rb is not None:
                 out["counts"] = run.rb.get_counts()
                 out["mt"] = run.rb.mt_state()[1]
+                import zlib
+                out["ring"] = {k: zlib.crc32(v.cpu().numpy().tobytes()) for k, v in run.rb.rings().items()}
             if run.roll is not None:
                 out["pi"] = run.roll.actor.get_weights_flat().cpu().numpy()
             comm.barrier()
             return out
 
-        a, b = one(True), one(False)
-        assert a["stats"] == b["stats"], (a["stats"], b["stats"])
-        for k in ("opt", "counts", "mt"):
-            assert a.get(k) == b.get(k), (k, a.get(k), b.get(k))
-        for k in ("w", "pi"):
-            if k in a:
-                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        a, a2, b = one(True), one(True), one(False)
+        for st, (u, v) in enumerate(zip(a["trace"], a2["trace"])):
+            diff = sorted(k for k in u if not k.startswith("_") and u[k] != v[k])
+            extra = ""
+            if diff and "_g" in u:
+                ix = np.flatnonzero(u["_g"] != v["_g"])
+                extra = " grad differs in %d elements: %s ... %s; max abs diff %.3g of max %.3g" % (ix.size, ix[:12].tolist(), ix[-4:].tolist(),
+                        float(np.abs(u["_g"] - v["_g"]).max()), float(np.abs(u["_g"]).max()))
+            assert not diff, "drained twice: step %d differs in %s (plan %s)%s" % (st, diff, u["plan"], extra)
+        for tag, x in (("drained twice", a2), ("running ahead", b)):
+            assert a["stats"] == x["stats"], (tag, a["stats"], x["stats"])
+            for k in ("opt", "counts", "mt", "ring"):
+                assert a.get(k) == x.get(k), (tag, k, a.get(k), x.get(k))
+            for k in ("w", "pi"):
+                if k in a:
+                    bad = np.flatnonzero(a[k] != x[k])
+                    assert bad.size == 0, "%s: %s differs in %d of %d elements, first at %d" % (tag, k, bad.size, a[k].size, bad[0])
         if roles.is_learner:
-            assert a["opt"] == (n_steps * per_step,) * 2 and a["stats"]["pushes"] == 1 + (n_steps * per_step) // 7
+            assert a["opt"] == (n_steps * per_step,) * 2 and a["stats"]["pushes"] == 1 + (n_steps * per_step) // opt.push_freq
         q.put((rank, "ok"))
     except Exception:  # noqa
         import traceback
