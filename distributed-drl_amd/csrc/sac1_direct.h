@@ -172,8 +172,14 @@ struct DOps {
 // requested in front of the operand blocks 54.0, the epilogue operands from inside the loop 53.7; DGP 1 / 2 / 4 / 8 / 16
 // 52.4 / 52.35 / 52.6 / 53.2 / 53.7; DGMID 1 / 2 / 4 / 6 / 8 52.3 / 52.3 / 52.0 / 52.1 / 52.3.
 constexpr int DPRE = 1;    // operand blocks of k_dfwd requested before its K loop
-constexpr int DGP0 = 2;    // 8-deep operand groups of k_dg requested before its K loop
-constexpr int DGMID = 4;   // k_dg: the group behind whose MFMAs the epilogue operands are requested
+#ifndef DDRL_DGP0
+#define DDRL_DGP0 2
+#endif
+#ifndef DDRL_DGMID
+#define DDRL_DGMID 4
+#endif
+constexpr int DGP0 = DDRL_DGP0;    // 8-deep operand groups of k_dg requested before its K loop
+constexpr int DGMID = DDRL_DGMID;   // k_dg: the group behind whose MFMAs the epilogue operands are requested
 struct DSrc {
     const float *W1, *W2p;
     int Np, b0, nb, n0;
@@ -707,12 +713,22 @@ __global__ void __launch_bounds__(256) k_actor_fwd(ActFwdArgs a) {
 // in 8-deep groups; both operands are x4 images read straight into the MFMA lane layout.
 // ==========================================================================================
 enum { DG_DGRAD_Q = 0, DG_DGRAD = 1, DG_WGRAD_J4 = 2, DG_WGRAD_RM = 3, DG_ROWS_C = 4, DG_LOSS = 5, DG_WGRAD_W1Y = 6 };
-struct DGJob {
-    int type;
-    int M, N, K;             // output M x N, contraction length K
-    int tiles_m, tile_start, ntiles;
+// The first 64 bytes are the "hot line": every scalar the first operand loads of a tile need.  k_dg fetches it with ONE
+// s_load_dwordx16 (and starts one load per remaining line of the record and of the launch header at the same time), waits ONCE,
+// and issues its operand loads; the compiler's own field loads — issued where the fields are used, each behind its own
+// s_waitcnt — made the prologue a chain of five to nine cold scalar-cache misses (2.7-4.1 k cycles from wave start to the first
+// operand load requested, tools/upd_bench.hip -DDDRL_STAMPS).
+struct alignas(64) DGJob {
     const float *A, *B;      // x4 images: [K/4][lda][4], [K/4][ldb][4]
+    const float *gp;         // the generated operand's vector along the contraction: DGRAD_Q: gw (W3[k]);  bgen: gdq (dq[r]) — set by dg_add
     int lda, ldb;
+    int K, type;             // contraction length; DG_*
+    int tiles_m, tile_start;
+    int slot;                // DGRAD_Q: 0 q1(x,a)  1 q2(x,a)  2 q1(x,pi)
+    int bgen;
+    int N, ntiles;           // output columns; tiles of the job
+    // ---- end of the hot line
+    int M;                   // output rows
     // generated operands
     const float *gw;         // DGRAD_Q: W3[k] (A = dq[row] * W3[k] * (H2 > 0));  WGRAD with bgen: W3[n] (B = dq[r] * W3[n] * (H2 > 0))
     const float *gdq;        // DGRAD_Q: nullptr -> the constant gconst;  bgen: dq[r] (flat [B])
@@ -720,8 +736,6 @@ struct DGJob {
                              // also steps W3 (Adam in the head-wgrad epilogue), and a gradient must see the pre-update kernel whichever
                              // workgroup runs first
     float gconst;
-    int bgen;
-    int slot;                // DGRAD_Q: 0 q1(x,a)  1 q2(x,a)  2 q1(x,pi)
     // dgrad epilogue
     const float *mask;       // H1r4 [M/4][ldmask][4]
     int ldmask;
@@ -791,19 +805,63 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     unsigned long long *const st_ = jobs.st;
 #endif
     DRT(kid, 14); DST(kid, 0);
-    {
+    {   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, private L2s); each XCD
+        // takes a contiguous run of the launch's panel-major tile list, so that an operand panel is fetched by one or two L2s
+        // instead of all eight (speed only).  Measured alternatives (us per update, tools/patches/): every job spread over all
+        // XCDs with its own runs 52.3, panel-cyclic ownership (XCD x owns column panel x of every job in every launch) 52.0,
+        // this 50.2: what an XCD saves in re-fetched operand panels outweighs both a job's tail and inter-launch L2 reuse
+        // (which does not happen anyway: an XCD's footprint per update is the size of its L2).
         const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     static_assert(MAX_DG_JOBS == 8, "k_dg takes tile_start[1..7] as scalar arguments");
     ji = (t >= ts1) + (t >= ts2) + (t >= ts3) + (t >= ts4) + (t >= ts5) + (t >= ts6) + (t >= ts7);
     const DGJob &jb = jobs.job[ji];
-    const int kl = kline<sizeof(DGJob)>(&jb) | kline<offsetof(DGJobs, job)>(&jobs);
-    t -= jb.tile_start;
+    // ONE round trip to the kernarg segment: the hot line of the job record into SGPRs + one touch per other line of the record and
+    // of the launch header (so that every later field load hits the scalar cache), one wait
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    static_assert(sizeof(DGJob) == 6 * 64 && offsetof(DGJob, M) == 64, "DGJob: hot line = the first 64 bytes, at most 6 lines");
+    static_assert(offsetof(DGJobs, job) == 5 * 64, "DGJobs: header of at most 5 lines, records 64-byte aligned");
+    v16i hot;
+    int kl;
+    {
+        // (addresses from the kernarg segment pointer: taking &jobs would make the compiler copy the by-value struct to scratch.)
+        // Kernarg layout: nine ints, then DGJobs at the next multiple of its 64-byte alignment.
+        constexpr int JOBS_OFF = 64;
+        static_assert(alignof(DGJobs) == 64 && 9 * sizeof(int) <= JOBS_OFF, "kernarg offset of k_dg's DGJobs argument");
+        const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+        const int jboff = __builtin_amdgcn_readfirstlane(JOBS_OFF + (int)offsetof(DGJobs, job) + ji * (int)sizeof(DGJob));  // (wave-uniform: an SGPR address)
+        const void *hdp = ka + JOBS_OFF, *jbp = ka + jboff;
+        int k1, k2, k3, k4, k5, k6, k7, k8, k9, k10;
+        asm volatile("s_load_dwordx16 %0, %11, 0x0\n\t"
+                     "s_load_dword %1, %11, 0x40\n\t"
+                     "s_load_dword %2, %11, 0x80\n\t"
+                     "s_load_dword %3, %11, 0xc0\n\t"
+                     "s_load_dword %4, %11, 0x100\n\t"
+                     "s_load_dword %5, %11, 0x140\n\t"
+                     "s_load_dword %6, %12, 0x0\n\t"
+                     "s_load_dword %7, %12, 0x40\n\t"
+                     "s_load_dword %8, %12, 0x80\n\t"
+                     "s_load_dword %9, %12, 0xc0\n\t"
+                     "s_load_dword %10, %12, 0x100\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(hot), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7), "=&s"(k8), "=&s"(k9), "=&s"(k10)
+                     : "s"(jbp), "s"(hdp)
+                     : "memory");
+        kl = k1 | k2 | k3 | k4 | k5 | k6 | k7 | k8 | k9 | k10;
+    }
+    // (the pointers are rebuilt from SGPR halves: the cast goes through the GLOBAL address space, or every load through them
+    // would be a flat_load — counted out of order, the compiler then waits for vmcnt(0) in front of every MFMA group)
+    typedef const float __attribute__((address_space(1))) *gfp;
+    auto mkptr = [](int lo, int hi) { return (const float *)(gfp)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo); };
+    const float *const hot_A = mkptr(hot[0], hot[1]), *const hot_B = mkptr(hot[2], hot[3]), *const hot_gp = mkptr(hot[4], hot[5]);
+    const int hot_lda = hot[6], hot_ldb = hot[7], hot_K = hot[8], hot_type = hot[9], hot_tiles_m = hot[10], hot_tile_start = hot[11];
+    const int hot_slot = hot[12], hot_bgen = hot[13], hot_N = hot[14];
+    t -= hot_tile_start;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int type = jb.type;
+    const int type = hot_type;
     const int Bn = jobs.B, Bv = jobs.Bv;
 
     if (type == DG_LOSS) {
@@ -827,7 +885,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         }
         return;
     }
-    const int tiles_m = jb.tiles_m;
+    const int tiles_m = hot_tiles_m;
     const int mt = t % tiles_m, nt = t / tiles_m;
     const int m0 = mt * 32, n0 = nt * 32;
     const int r = tid & 31, cg = tid >> 5;
@@ -906,15 +964,15 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     }
 
     // ---- GEMM tiles.  This wave's 8-deep contraction groups: the waves at the END get the extra ones
-    const int Kc = jb.K, lda = jb.lda, ldb = jb.ldb;
-    const float *Aop = jb.A, *Bop = jb.B;
+    const int Kc = hot_K, lda = hot_lda, ldb = hot_ldb;
+    const float *Aop = hot_A, *Bop = hot_B;
     const int G = (Kc + 7) >> 3, gs = G >> 2, grem = G & 3;
     const int ng = gs + (w >= 4 - grem ? 1 : 0);
     const int g0 = w * gs + (w > 4 - grem ? w - (4 - grem) : 0);
     const bool first_n = nt == 0;
 
     // DGRAD_Q: the Q-head partials of this tile's rows (-> dq -> the generated A operand); c = 0..4 <-> evaluations 3..7.
-    const bool need_q = type == DG_DGRAD_Q && jb.slot != 2;
+    const bool need_q = type == DG_DGRAD_Q && hot_slot != 2;
     float4 qv[DNT / 4];
     {
         const int c = tid >> 5;
@@ -930,14 +988,14 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     // generated-operand inputs: W3 along the contraction (DGRAD_Q) or dq along it (generated wgrad operand).  The same 16
     // bytes for all 32 lanes of a half-wave: a per-lane load of them would cost the fetch path as much as a tile load,
     // so the vector is staged once per workgroup in LDS (two coalesced loads per thread) and read from there in the K loop.
-    const bool has_gen = type == DG_DGRAD_Q || jb.bgen;  // block-uniform
+    const bool has_gen = type == DG_DGRAD_Q || hot_bgen;  // block-uniform
     float gv0 = 0.f, gv1 = 0.f, gwn = 0.f;
     if (has_gen) {
-        const float *gp = type == DG_DGRAD_Q ? jb.gw : jb.gdq;
+        const float *gp = hot_gp;
         const int glen = 8 * G;  // (W3 / dq are followed by readable memory up to the next multiple of 8)
         gv0 = gp[tid < glen ? tid : 0];
         gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
-        if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < jb.N) ? n0 + l31 : 0];
+        if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < hot_N) ? n0 + l31 : 0];
         if (type == DG_DGRAD_Q && jb.gw_snap && t == 0) {  // block-uniform
             if (tid < glen) jb.gw_snap[tid] = gv0;
             if (tid + 256 < glen) jb.gw_snap[tid + 256] = gv1;
@@ -1302,6 +1360,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
 }
 
 static void dg_add(DGJobs &js, DGJob j) {
+    j.gp = j.type == DG_DGRAD_Q ? j.gw : j.gdq;
     j.tiles_m = (j.M + 31) / 32;
     j.ntiles = j.type == DG_LOSS ? 1 : j.tiles_m * ((j.N + 31) / 32);
     j.tile_start = js.total_tiles;

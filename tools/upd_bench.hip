@@ -94,6 +94,26 @@ int main(int argc, char **argv) {
         for (int i = 1; i < 6; ++i) printf(" %s=%.0f", pn[i], ph[i] / nwg);
         printf(" | mean total %.0f max %llu\n", tot / nwg, lmax);
         prev_end = rmax;
+        // per job of a k_dg launch: when its workgroups start / end relative to the launch's first start (100 MHz real-time counter)
+        const DGJobs *J = k == 2 ? &h->dg_bq[0] : (k == 3 ? &h->dg_mid : (k == 4 ? &h->dg_pi : nullptr));
+        if (J) {
+            const int nwgs = J->total_tiles;
+            for (int ji = 0; ji < J->njobs; ++ji) {
+                double ssum = 0, esum = 0, emax = 0, csum = 0, cmax = 0, psum[6] = {0}; int n = 0;
+                for (int b = 0; b < nwgs; ++b) {
+                    const int q = nwgs >> 3, r = nwgs & 7, x = b & 7;
+                    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+                    if (t < J->job[ji].tile_start || t >= J->job[ji].tile_start + J->job[ji].ntiles) continue;
+                    const unsigned long long *p = &hs[((size_t)k * 1024 + b) * 16];
+                    if (!p[15]) continue;
+                    ++n; ssum += (p[14] - rmin) / 100.0; const double e = (p[15] - rmin) / 100.0; esum += e; emax = std::max(emax, e);
+                    const double c = (double)(p[5] - p[0]); csum += c; cmax = std::max(cmax, c);
+                    for (int i = 1; i < 6; ++i) if (p[i] && p[i - 1]) psum[i] += (double)(p[i] - p[i - 1]);
+                }
+                if (n) printf("      job %d type %d M %4d N %4d K %4d: %3d wgs  start +%.2f us  end mean +%.2f max +%.2f us | cycles mean %.0f max %.0f | loads %.0f prol %.0f kloop %.0f bar %.0f epi %.0f\n", ji, J->job[ji].type,
+                              J->job[ji].M, J->job[ji].N, J->job[ji].K, n, ssum / n, esum / n, emax, csum / n, cmax, psum[1] / n, psum[2] / n, psum[3] / n, psum[4] / n, psum[5] / n);
+            }
+        }
     }
     };
     anatomy("inside the update sequence (graph)");
