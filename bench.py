@@ -19,8 +19,12 @@ N > 1 — the north star's rank-role partitioning (distributed-drl_amd/partition
                         parameters travel as one RCCL broadcast every 300 updates
     N = 8 (configs[3])  ranks 0-1 learners (gradient all-reduce per update), ranks 2-7 rollout ranks x 8192 envs + shard
     other N             N // 4 learners (at least one), the rest rollout ranks
-  A step = one vector env step on every rollout rank + the same 2048 updates on every learner rank ("weak": per-rank
-  work fixed; the learner ranks bound the step, env-steps scale with the rollout ranks).
+  A step = one vector env step on every rollout rank + the updates the reference's actor/learner gate owes for those env
+  steps (steps / sample_times <= a_l_ratio, algos/sac1/sac1.py:25,203-207): env steps of the step / a_l_ratio batches,
+  shared over the learner ranks (a data-parallel update of k learners draws k batches).  `--gate free` drops the gate
+  (2048 updates per learner rank whatever the env steps: the round-2 figure, rollout scaling only).  Next to `value` the
+  line carries what lets a 1 -> 8 curve be read as rollout scaling vs learner scaling: `env_steps_per_sample`, every
+  rank's busy time inside the timed block, per-role phase times (one extra, drained block) and learner-only updates/s.
 Synthetic data: rings pre-filled to capacity with seeded synthetic transitions; glorot / zeros weights.
 Inputs are resident in HBM when timing starts.
 
@@ -73,12 +77,15 @@ def parse_args():
     ap.add_argument("--a-l-ratio", type=float, default=2.0)
     ap.add_argument("--updates-per-graph", type=int, default=50)  # divides push_freq = 300: no eager remainder between pushes
     ap.add_argument("--num-learners", type=int, default=None)
+    ap.add_argument("--gate", choices=("hold", "free"), default="hold",
+                    help="hold: updates per step = env steps of the step / a_l_ratio over the learner ranks (the reference's gate); "
+                         "free: 2048 updates per learner rank per step whatever the env steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the rollout / store / sample / config-5 stage measurements")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds per CPU-baseline leg")
     ap.add_argument("--gpu-seconds", type=float, default=10.0, help="keep repeating the timed block until the GPU legs lasted this long")
     ap.add_argument("--stage-samples", type=int, default=200)
-    ap.add_argument("--cfg5-capacity", type=int, default=32768, help="transitions of the config-5 gather ring (225 804 B each)")
+    ap.add_argument("--cfg5-capacity", type=int, default=294912, help="transitions of the config-5 ring (225 804 B each; default 66.6 GB)")
     return ap.parse_args()
 
 
@@ -244,25 +251,6 @@ def stage_measurements(args, opt, rb, roll, d):
                            "frac_of_hbm_peak": K * B * 164 / t / 1e9 / PEAK_HBM_GBPS,
                            "what": "the block of batches a shard owner draws for one step of a remote learner (configs 3/4): "
                                    "one sequential MT19937 index draw + one gather sweep"}
-    try:   # config 5's learner: Double-DQN (algos/dqn/actor_learner.py) on 84x84x4 = 28 224-wide observations, batch 512
-        from distributed_drl_amd import dqn
-
-        class O5L:
-            obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed = 84 * 84 * 4, 4, [400, 300], 0.99, 1e-3, 0.995, 512, 2
-        l5 = dqn.Learner(O5L, "learner")
-        b5 = {"obs1": torch.rand(512, O5L.obs_dim, device="cuda"), "obs2": torch.rand(512, O5L.obs_dim, device="cuda"),
-              "acts": torch.randint(0, 4, (512,), device="cuda").float(), "rews": torch.randn(512, device="cuda"),
-              "done": (torch.rand(512, device="cuda") < 0.01).float()}
-        t = timed(lambda: l5.train(b5, 0), 20, warm=3)
-        # three forwards (main @ x, main @ x2, target @ x2) + the wgrad of main @ x for every layer, + the dgrad of layers 2, 3
-        fl = 2.0 * 512 * (4 * O5L.obs_dim * 400 + 5 * (400 * 300 + 300 * 4))
-        out["ddqn_update_cfg5"] = {"batch": 512, "obs_dim": O5L.obs_dim, "ms": t * 1e3, "updates_per_s": 1.0 / t,
-                                   "approx_TFLOPs": fl / t / 1e12, "frac_of_f32_mfma_peak": fl / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   "what": "one Double-DQN update at config 5's observation width (generic k_gemm path: layer 1 is a "
-                                           "K = 28 224 GEMM), eager"}
-        del l5, b5
-    except Exception as e:  # noqa
-        out["ddqn_update_cfg5"] = {"error": repr(e)[:200]}
     try:   # the reference's num_learners > 1 (example/dsac.py:233: unsynchronised learners, last writer wins) on ONE GPU
         from distributed_drl_amd.workers import TrainDevice
         streams = [torch.cuda.Stream() for _ in range(2)]
@@ -317,7 +305,8 @@ def stage_measurements(args, opt, rb, roll, d):
     except Exception as e:  # noqa
         out["sac_v_update"] = {"error": repr(e)[:200]}
     if args.cfg5_capacity > 0:
-        try:
+        try:   # config 5: DQN (algos/dqn) on 84x84x4 float32 observations, batch 512 — the ring, its sampler and its learner
+            from distributed_drl_amd import dqn
             obs_dim, B5, cap = 84 * 84 * 4, 512, int(args.cfg5_capacity)
 
             class O5:
@@ -326,21 +315,45 @@ def stage_measurements(args, opt, rb, roll, d):
             rb5 = d.ReplayBufferDQN(O5, 0, seed=0)
             g = torch.Generator(device="cuda").manual_seed(0)
             z = torch.zeros(2048, device="cuda")
-            for s in range(0, cap, 2048):
-                n = min(2048, cap - s)
+            for s0 in range(0, cap, 2048):
+                n = min(2048, cap - s0)
                 x = torch.randint(0, 256, (n, obs_dim), device="cuda", generator=g).float()
                 rb5.store_batch(x, z[:n], z[:n], x, z[:n])
+            del x
             T5 = 4 * (2 * obs_dim + 1 + 2)
-            t = timed(lambda: rb5.sample_batch_device(B5), 64)
-            out["config5_gather"] = {"batch": B5, "bytes_per_transition": T5, "ring_GB": cap * T5 / 1e9, "us": t * 1e6,
-                                     "bytes_per_batch": B5 * (2 * T5 + 4), "GBps": B5 * (2 * T5 + 4) / t / 1e9,
-                                     "frac_of_hbm_peak": B5 * (2 * T5 + 4) / t / 1e9 / PEAK_HBM_GBPS,
-                                     "what": "sample_batch(512) of 84x84x4 float32 transitions (MT19937 indices + five gathers), "
-                                             "ring well beyond the 256 MiB Infinity Cache"}
-            del rb5
+            t_g = timed(lambda: rb5.sample_batch_device(B5), 64)
+            out["config5_gather"] = {"batch": B5, "bytes_per_transition": T5, "ring_GB": cap * T5 / 1e9, "ring_transitions": cap,
+                                     "us": t_g * 1e6, "bytes_per_batch": B5 * (2 * T5 + 4), "GBps": B5 * (2 * T5 + 4) / t_g / 1e9,
+                                     "frac_of_hbm_peak": B5 * (2 * T5 + 4) / t_g / 1e9 / PEAK_HBM_GBPS,
+                                     "what": "sample_batch(512) of 84x84x4 float32 transitions (MT19937 indices + five gathers); the "
+                                             "observation arrays are %.1f GB each: byte offsets far beyond 2^32, a ring far beyond the 256 MiB "
+                                             "Infinity Cache" % (cap * obs_dim * 4 / 1e9)}
+
+            class O5L:
+                obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed = 84 * 84 * 4, 4, [400, 300], 0.99, 1e-3, 0.995, 512, 2
+            l5 = dqn.Learner(O5L, "learner")
+            b5 = rb5.sample_batch_device(B5)
+            b5["acts"].random_(0, 4)
+            t_u = timed(lambda: l5.train(b5, 0), 20, warm=3)
+            # three forwards (main @ x, main @ x2, target @ x2) + the wgrad of main @ x for every layer, + the dgrad of layers 2, 3
+            fl = 2.0 * 512 * (4 * O5L.obs_dim * 400 + 5 * (400 * 300 + 300 * 4))
+            out["ddqn_update_cfg5"] = {"batch": 512, "obs_dim": O5L.obs_dim, "ms": t_u * 1e3, "updates_per_s": 1.0 / t_u,
+                                       "approx_TFLOPs": fl / t_u / 1e12, "frac_of_f32_mfma_peak": fl / t_u / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       "what": "one Double-DQN update at config 5's observation width (generic k_gemm path: layer 1 is a "
+                                               "K = 28 224 GEMM), eager"}
+
+            def iteration():   # worker_train's loop body on config 5: sample_batch(512) -> train (algos/dqn/train.py:66-76, actor_learner.py)
+                bb = rb5.sample_batch_device(B5)
+                l5.train(bb, 0)
+            t_i = timed(iteration, 20, warm=3)
+            out["config5_learner_iteration"] = {"ms": t_i * 1e3, "iterations_per_s": 1.0 / t_i, "sample_ms": t_g * 1e3, "update_ms": t_u * 1e3,
+                                                "sample_share": t_g / t_i,
+                                                "what": "sample_batch(512) from the %.0f GB ring + one Double-DQN update, back to back on one stream: the "
+                                                        "K = 28 224 layer-1 GEMMs (MFMA-bound), not the 231 MB gather (HBM-bound), set the rate" % (cap * T5 / 1e9)}
+            del rb5, l5, b5
             torch.cuda.empty_cache()
         except Exception as e:  # noqa  (an out-of-memory box must not lose the headline line)
-            out["config5_gather"] = {"error": str(e)[:200]}
+            out["config5_gather"] = dict(out.get("config5_gather", {}), error=str(e)[:200])
     return out
 
 
@@ -375,7 +388,11 @@ def main():
     opt.start_steps = -1          # policy phase from the first step (the expensive branch)
     opt.max_ep_len = 1000
     opt.seed = 0
-    updates_per_step = max(1, int(round(4096 / args.a_l_ratio)))   # per learner rank, the config-2 figure at every N
+    env_steps_per_step = num_envs * len(roles.rollouts)
+    if args.gate == "hold":   # batches the gate owes for one step's env steps, shared over the learner ranks
+        updates_per_step = max(1, int(round(env_steps_per_step / args.a_l_ratio / len(roles.learners))))
+    else:
+        updates_per_step = max(1, int(round(4096 / args.a_l_ratio)))   # per learner rank, the config-2 figure at every N
     shard_cap = args.capacity // len(roles.shard_owner)
     cfgd = dict(B=opt.batch_size, obs=opt.obs_dim, act=opt.act_dim, h1=opt.hidden_sizes[0], h2=opt.hidden_sizes[1])
 
@@ -403,6 +420,8 @@ def main():
         def one_step():
             run.step(updates_per_step)
 
+    busy = [0.0]
+
     def block():
         torch.cuda.synchronize()
         comm.barrier()
@@ -410,6 +429,7 @@ def main():
         for _ in range(args.steps):
             one_step()
         torch.cuda.synchronize()
+        busy[0] = time.perf_counter() - t0             # this rank's own work (a rollout rank then waits for the learners)
         comm.barrier()
         return comm.allreduce_max(time.perf_counter() - t0, device=dev)
 
@@ -426,6 +446,25 @@ def main():
 
     env_steps = args.steps * num_envs * len(roles.rollouts)
     updates = args.steps * updates_per_step * len(roles.learners)
+    rank_busy = role_times = None
+    if run is not None:
+        import torch.distributed as dist
+        if run.learner is not None:
+            run.check()
+        rank_busy = [None] * world
+        dist.all_gather_object(rank_busy, busy[0])    # of the last repeated block (the same work as block 0, whose max over ranks is `dt`)
+        # one extra block with the device drained at every phase boundary: where each role's time goes (diagnosis, not the metric)
+        run.timing = True
+        for k in [k for k in run.stats if k.startswith("s_")]:
+            del run.stats[k]
+        n_diag = max(1, min(args.steps, 3))
+        for _ in range(n_diag):
+            one_step()
+        torch.cuda.synchronize()
+        run.timing = False
+        mine = {k: round(v / n_diag * 1e3, 4) for k, v in run.stats.items() if k.startswith("s_")}
+        role_times = [None] * world
+        dist.all_gather_object(role_times, mine)
     if rank != 0:
         return
 
@@ -483,6 +522,7 @@ def main():
                                (num_envs, args.capacity, len(roles.shard_owner), args.batch, updates_per_step),
                    "num_envs": num_envs, "replay_capacity": args.capacity, "batch": args.batch,
                    "updates_per_step": updates_per_step, "updates_per_graph": args.updates_per_graph if len(roles.learners) == 1 else 0,
+                   "gate": args.gate, "a_l_ratio": args.a_l_ratio,
                    "env_steps_per_sample": env_steps / max(1, updates), "learner_ranks": roles.learners, "rollout_ranks": roles.rollouts,
                    "backend": (torch.distributed.get_backend() if world > 1 else None), "devices": ndev,
                    "parallelism": roles.describe()},
@@ -492,9 +532,27 @@ def main():
         "roofline": roofline,
     }
     if run is not None:
-        out["partition_stats"] = run.stats
+        out["partition_stats"] = {k: v for k, v in run.stats.items() if not k.startswith("s_")}
+        s_upd = [t.get("s_updates") for t in role_times if t and t.get("s_updates")]
+        out["scaling_readout"] = {
+            "env_steps_per_sample": env_steps / max(1, updates),
+            "rank_busy_s_in_timed_block": [round(b, 4) for b in rank_busy],
+            "roles": ["learner+rollout" if (r in roles.learners and r in roles.rollouts) else ("learner" if r in roles.learners else "rollout") for r in range(world)],
+            "phase_ms_per_step_drained": role_times,
+            "learner_only_updates_per_s": (updates_per_step * len(roles.learners) / (max(s_upd) * 1e-3)) if s_upd else None,
+            "rollout_only_env_steps_per_s_per_rank": [round(num_envs / (t["s_env"] * 1e-3)) if t and t.get("s_env") else None for t in role_times],
+            "note": "value = env steps of the timed block / its wall time (max over ranks); under --gate hold the learner rank(s) bound it. "
+                    "phase times come from one extra block with the device drained at every phase boundary (s_env: vector env step, "
+                    "s_serve: shard owner draws + sends its blocks, s_receive: learner posts receives + lays the plan, s_updates: the "
+                    "updates, s_push: parameter broadcast, s_drain: sends complete)"}
     if world == 1 and not args.no_stages:
         out["stages"] = stage_measurements(args, opt, rb, roll, d)
+    if world == 1:
+        out["scaling_readout"] = {
+            "env_steps_per_sample": env_steps / max(1, updates), "roles": ["learner+rollout"],
+            "learner_only_updates_per_s": (1e6 / roofline["update_us_learner_only"]) if "update_us_learner_only" in roofline else None,
+            "rollout_only_env_steps_per_s_per_rank": [out.get("stages", {}).get("rollout_only", {}).get("env_steps_per_s")],
+            "note": "one rank runs the envs and the learner back to back; under the gate the learner is 99.9 % of the step"}
     out["cpu_baseline"] = cpu_one
     out["cpu_baseline_all_cores"] = cpu_all
     if cpu_one is not None:

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ddrl_sac1_step_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_compute_grads_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_apply_grads_and_sample": (c_int, [_P, _P, c_int, _P]),
+    "ddrl_sac1_graph_sync": (c_int, [_P, _P]),
     "ddrl_sac1_input_buffers": (c_int, [_P, c_int, POINTER(_P)]),
     "ddrl_sac1_is_fused": (c_int, [_P]),
     "ddrl_sac1_batch": (c_int, [_P]),

@@ -312,6 +312,14 @@ class Learner(_Net):
 
         def apply():
             _lib.check(lib.ddrl_sac1_apply_grads(h, sp()))
+
+        def graph_sync():
+            """Before a caller's graph capture and as its last captured call: optimizer state / dgrad image on copy 0; the
+            stepper itself restarts from input set 0 with nothing drawn ahead (a graph ends with a `last` update)."""
+            assert not state["primed"], "a captured sequence must end with grads(last=True)"
+            state["cur"] = 0
+            _lib.check(lib.ddrl_sac1_graph_sync(h, sp()))
+        grads.graph_sync = graph_sync
         return grads, apply, g
 
     def compute_gradients(self, batch, eps=None):

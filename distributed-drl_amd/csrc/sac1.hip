@@ -1782,6 +1782,8 @@ int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
 
 extern "C" {
 
+int ddrl_sac1_graph_sync(ddrl_sac1_t *h, void *stream) { return ddrl_sac1_internal_opt_sync(h, stream); }
+
 int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream) {
     DDRL_REQUIRE(h != nullptr && replay != nullptr && (set_in == 0 || set_in == 1) && (set_out == 0 || set_out == 1) && set_in != set_out,
                  "NULL pointer, or input sets not {0,1} / not distinct");

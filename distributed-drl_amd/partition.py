@@ -181,7 +181,7 @@ class PartitionedRun:
     broadcasts the flat parameter vector and the rollout ranks adopt it."""
 
     def __init__(self, opt, roles, make_replay, make_rollout, make_learner, seed=0, push_freq=None, device=None, updates_per_graph=16,
-                 force_dp=False):
+                 force_dp=False, dp_updates_per_graph=None):
         self.opt, self.roles = opt, roles
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.B = int(opt.batch_size)
@@ -211,6 +211,12 @@ class PartitionedRun:
                 self.loop = _Loop(self.learner, self.feed_ring, updates_per_graph)
             else:
                 self.dp_grads, self.dp_apply, self.dp_g = self.learner.dp_stepper(self.feed_ring)
+                # the data-parallel step captured as ONE graph of k updates (gradients -> RCCL all-reduce -> apply, k times): RCCL
+                # collectives are stream-capturable, gloo's (host staging) are not.  0 = eager.  DDRL_DP_GRAPH overrides.
+                import os
+                k = int(os.environ.get("DDRL_DP_GRAPH", updates_per_graph if dp_updates_per_graph is None else dp_updates_per_graph))
+                self.dp_per_graph = (k & ~1) if (dist.is_initialized() and dist.get_backend(self.lgroup) == "nccl") else 0
+                self.dp_graph = None
         self.send_bufs, self.regions = {}, {}
         # the step's plan goes host -> device with an async copy while the host runs ahead of the device by whole
         # steps: a pinned staging buffer is rewritten only after the event behind its last copy has completed
@@ -297,10 +303,40 @@ class PartitionedRun:
         self.stats["remote_batches"] += n - owners.count(me)
         self.last_plan = plan
 
+    def _capture_dp(self):
+        """k updates of the data-parallel step as one graph.  Every cursor / RNG / optimizer state the launches read lives on
+        the device and the sampler follows the step's plan from device memory, so a replay continues where the stream is;
+        the graph begins with an explicit draw and ends with an update that draws nothing ahead (`last`)."""
+        k = self.dp_per_graph
+        torch.cuda.synchronize()
+        self.dp_grads.graph_sync()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(k):
+                self.dp_grads(last=(i == k - 1))
+                comm.allreduce_mean_(self.dp_g, group=self.lgroup)
+                self.dp_apply()
+            self.dp_grads.graph_sync()
+        self.dp_graph = g
+
     def _train_eager(self, n, end_of_step=False):
-        """Several learners: per update, the plan's batch -> gradients -> all-reduce (mean) -> Adam + polyak."""
-        for i in range(n):
-            self.dp_grads(last=end_of_step and i == n - 1)
+        """Several learners: per update, the plan's batch -> gradients -> all-reduce (mean) -> Adam + polyak; whole graphs of
+        dp_per_graph updates where they fit, the rest eagerly."""
+        k = self.dp_per_graph
+        if k > 0 and n >= k:
+            if self.dp_graph is None:
+                self.dp_grads(last=True)                 # one eager update first: argument / empty-ring errors surface outside the capture
+                comm.allreduce_mean_(self.dp_g, group=self.lgroup)
+                self.dp_apply()
+                n -= 1
+                self._capture_dp()
+            self.dp_grads.graph_sync()
+            while n >= k:
+                self.dp_graph.replay()
+                n -= k
+        for i in range(n):   # (every call ends with nothing drawn ahead: the ring / the plan / a graph may come next)
+            self.dp_grads(last=(i == n - 1))
             comm.allreduce_mean_(self.dp_g, group=self.lgroup)
             self.dp_apply()
 

@@ -266,6 +266,13 @@ int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay,
  * input set set_in while the sampler of the NEXT batch rides in a forward launch and gathers into set_out. */
 int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream);
 
+/* For a caller that captures update sequences into a graph of its own (partition.py captures `gradients -> RCCL all-reduce ->
+ * apply` of the data-parallel learners with torch.cuda.graph; the reference has no counterpart: its learners never
+ * synchronise, example/dsac.py:59-62,233): puts the learner's double-buffered optimizer state / dgrad image on copy 0.  Call
+ * it on the stream right before the capture begins and again as the LAST captured call, so that the graph starts and ends
+ * on the same copy whatever the number of updates it holds (a copy node when that number is odd). */
+int ddrl_sac1_graph_sync(ddrl_sac1_t *h, void *stream);
+
 /* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
  * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of
  * device pointers).  There are two sets (set = 0 or 1) so that a sampler can fill one set while an

@@ -62,15 +62,20 @@ def main():
             rs.randn(m, 8).astype(np.float32), np.zeros(m, np.float32))))
         return rb
 
-    def run_it(force_dp, per_graph):
+    def run_it(force_dp, per_graph, dp_graph=0):
         roles = partition.Roles(1, 0)
         run = partition.PartitionedRun(opt, roles, shard, lambda rb: RolloutDevice(None, rb, opt, worker_index=0),
-                                       lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=per_graph, force_dp=force_dp)
+                                       lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=per_graph, force_dp=force_dp,
+                                       dp_updates_per_graph=dp_graph)
         assert run.bcast is not None and (run.lgroup is not None) == force_dp
+        if force_dp:
+            assert run.dp_per_graph == dp_graph
         for _ in range(5):
             run.step(4)                                        # 20 updates: pushes (RCCL broadcasts) at 6, 12, 18 + the initial one
         torch.cuda.synchronize()
         run.check()
+        if dp_graph:
+            assert run.dp_graph is not None                    # steps 2 and 4 are whole segments of 4 updates: graph replays
         assert run.learner.opt_steps() == (20, 20) and run.stats["pushes"] == 4
         assert run.rb.get_counts() == (20, 500 + 5 * 64, 500 + 5 * 64)
         n_pi = run.roll.actor.n_params
@@ -80,6 +85,8 @@ def main():
     w_loop = run_it(False, 2)          # single learner: graph-captured loop + broadcast
     w_dp = run_it(True, 0)             # data-parallel step with a group of one: gradients -> RCCL all-reduce AVG -> apply
     np.testing.assert_array_equal(w_loop, w_dp)
+    w_dpg = run_it(True, 0, dp_graph=4)   # the same step captured with its RCCL all-reduce as graphs of 4 updates
+    np.testing.assert_array_equal(w_loop, w_dpg)
     print("rccl partition ok", flush=True)
 
 

@@ -374,3 +374,55 @@ def test_dp_stepper_ride_along_sampler_equals_plain_sequence():
         assert torch.equal(a, b)
     assert outs[0][1] == outs[1][1] == (15, n, n) and outs[0][3] == outs[1][3] == (15, 15)
     assert outs[0][2][1] == outs[1][2][1] and (outs[0][2][0] == outs[1][2][0]).all()
+
+
+def test_vectorised_rollout_never_acts_on_weights_older_than_the_reference_worker_would():
+    """DESIGN §7's claim, checked: the reference worker pulls at ITS episode end (example/dsac.py:129-130); the vectorised
+    rollout adopts a push for ALL envs at the end of the first vector step after it.  Pushes land between vector steps;
+    every policy version makes a recognisable action (zero kernels, bias-coded mean, log_std at its floor), so the ring rows
+    tell which version each env acted on.  For every env and step: version used >= the version that env's last episode end
+    would have pulled — and it is exactly the newest version pushed at least two vector steps ago."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    from distributed_drl_amd.workers import RolloutDevice
+    n, steps = 64, 40
+    opt = HyperParameters()
+    opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, 7, 3   # time limit 7: every env ends episodes all the time
+    keys, vals = Learner(opt).get_weights()
+    code = lambda v: 0.08 * (v + 1)
+
+    def weights(v):   # policy version v: mu = atanh-free code (kernels zero -> mu = bmu), log_std = -20 (tanh(-40) = -1)
+        out = []
+        for k, w in zip(keys, vals):
+            w = np.zeros_like(w)
+            if "pi" in k and k.endswith("dense_2/bias"):
+                w[:] = code(v)
+            if "pi" in k and k.endswith("dense_3/bias"):
+                w[:] = -40.0
+            out.append(w)
+        return out
+    ps = ddrl.ParameterServer(keys, weights(0))
+    rb = ddrl.ReplayBufferSAC1(8, 2, n * steps, seed=0)
+    roll = RolloutDevice(ps, rb, opt)
+    assert roll._fused_ready()
+    push_after = {2: 1, 3: 2, 9: 3, 10: 4, 11: 5, 20: 6, 33: 7}          # step -> version pushed right after it
+    EPI = 13                                                          # csrc/env.hip: per-env episode counter
+    epi_before = roll.env.get_state()[EPI].cpu().numpy().copy()
+    last_end = np.full(n, -1)                                         # the step in which env i last ended an episode (-1: the initial pull)
+    pushed_by = lambda s: max([0] + [v for k, v in push_after.items() if k <= s])   # newest version pushed after a step <= s
+    for s in range(steps):
+        roll.step()
+        acts = rb.rings()["acts_buf"][s * n:(s + 1) * n].cpu().numpy()
+        used = np.rint(np.arctanh(np.clip(acts[:, 0], -0.999, 0.999)) / 0.08 - 1).astype(int)
+        assert (used == used[0]).all() and np.allclose(acts[:, 0], np.tanh(code(used[0])), atol=1e-6)
+        # exactly: the push after step k is adopted at the end of step k + 1 and acted on from step k + 2
+        assert used[0] == pushed_by(s - 2), (s, used[0], pushed_by(s - 2))
+        # never staler than the reference: env i pulled at the end of step last_end[i], seeing pushes after steps < last_end[i]
+        ref = np.array([pushed_by(e - 1) if e >= 0 else 0 for e in last_end])
+        assert (used >= ref).all(), (s, used[0], ref.max())
+        epi_after = roll.env.get_state()[EPI].cpu().numpy()
+        last_end[epi_after > epi_before] = s
+        epi_before = epi_after.copy()
+        if s in push_after:
+            ps.push(keys, weights(push_after[s]))
+    assert (last_end >= steps - 8).all() and roll.env.stats()[0] >= n * (steps // 7 - 1)    # the episode ends the bound is about did happen

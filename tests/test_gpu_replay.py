@@ -392,3 +392,46 @@ def test_packed_blocks_at_unaligned_float_offsets(ddrl, obs, act, B, K):
             want = g[name].cpu().numpy().reshape(-1, w)[idx].reshape(-1)
             np.testing.assert_array_equal(blk[off: off + K * B * w], want, err_msg="%s shift %d" % (name, shift))
             off += K * B * w
+
+
+def test_config5_rows_beyond_4gib_byte_offsets(ddrl):
+    """Config 5's row shape (84 x 84 x 4 float32 = 112 896 B per observation) on a ring whose observation arrays pass 2^32
+    BYTES (42 000 rows = 4.7 GB each; one MI355X holds ~1.2 M such transitions): store with wrap, NumPy's own index stream
+    over the whole ring, gathered rows == ring rows at those indices, and caller-supplied indices in the rows beyond the
+    4 GiB mark.  Every row is recognisable: obs1[i, c] = (i * 31 + c) mod 2^20, obs2[i, c] = obs1[i, c] + 0.5."""
+    obs_dim, cap, B = 84 * 84 * 4, 42000, 512
+    assert cap * obs_dim * 4 > 2 ** 32 + 2 ** 28
+
+    class Opt:
+        pass
+    Opt.obs_dim, Opt.buffer_size, Opt.batch_size, Opt.save_dir = obs_dim, cap, B, "."
+    buf = ddrl.ReplayBufferDQN(Opt, 0, seed=12345)
+    cols = torch.arange(obs_dim, device="cuda", dtype=torch.int64)
+
+    def rows_of(first, n):   # what source row `first + j` of the store stream holds
+        i = torch.arange(first, first + n, device="cuda", dtype=torch.int64)
+        x = ((i[:, None] * 31 + cols[None, :]) % (1 << 20)).float()
+        return x, (i % 7).float(), (i % 1000).float() * 0.25, x + 0.5, (i % 97 == 0).float()
+    total, chunk = cap + 4000, 2000          # 46 000 stores: the last 4 000 wrap over rows 0 .. 3 999
+    for s in range(0, total, chunk):
+        buf.store_batch(*rows_of(s, chunk))
+    assert buf.get_counts() == (0, total, cap) and buf.ptr == total - cap
+    src = lambda idx: np.where(idx < total - cap, idx + cap, idx)          # the store-stream row that ring row idx holds now
+
+    def check(g, idx):
+        first = torch.from_numpy(src(idx)).cuda()
+        want1 = ((first[:, None] * 31 + cols[None, :]) % (1 << 20)).float()
+        assert torch.equal(g["obs1"], want1) and torch.equal(g["obs2"], want1 + 0.5)
+        assert torch.equal(g["acts"], (first % 7).float()) and torch.equal(g["rews"], (first % 1000).float() * 0.25)
+        assert torch.equal(g["done"], (first % 97 == 0).float())
+    np.random.seed(12345)
+    for _ in range(3):       # sample_batch: MT19937 index kernel + the chip-wide gather
+        g = buf.sample_batch_device(B, fresh=True, with_indices=True)
+        idx = np.random.randint(0, cap, B)
+        np.testing.assert_array_equal(g["idxs"].cpu().numpy(), idx)
+        assert (idx.astype(np.int64) * obs_dim * 4 >= 2 ** 32).sum() > 10     # rows beyond the 4 GiB mark were drawn
+        check(g, idx)
+    hi = np.concatenate([np.arange(cap - 300, cap), [38043, 38044, 2 ** 32 // (obs_dim * 4), 2 ** 32 // (obs_dim * 4) + 1]]).astype(np.int64)
+    check(buf.gather_device(torch.from_numpy(hi).cuda()), hi)                # ddrl_replay_gather at the far end of the arrays
+    del buf
+    torch.cuda.empty_cache()
