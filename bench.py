@@ -362,6 +362,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    # the ONE JSON line goes to the real stdout; everything else this process (or a library under it: gloo and RCCL print
+    # connection banners from C++) writes to fd 1 is sent to stderr
+    json_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import distributed_drl_amd as d
@@ -557,7 +562,8 @@ def main():
     out["cpu_baseline_all_cores"] = cpu_all
     if cpu_one is not None:
         out["gpu_over_cpu"] = {"env_steps": out["value"] / cpu_one["value"], "updates": out["updates_per_s"] / cpu_one["updates_per_s"]}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
