@@ -445,7 +445,9 @@ class Actor(_Net):
         return self.get_actions(np.asarray(o, np.float32).reshape(1, -1), deterministic, eps)[0].cpu().numpy()
 
     def test(self, test_env, replay_buffer=None, n=25):
-        """Deterministic evaluation episodes (actor_learner.py:199-218); returns the mean return."""
+        """Deterministic evaluation episodes (actor_learner.py:199-218); returns the mean return.  With opt.summary_dir set the
+        reference's TensorBoard scalar goes out too: "Reward" = sum(rew) / 25 at step sample_times (actor_learner.py:210-216;
+        the divisor is the reference's constant, whatever n is)."""
         rew = []
         for _ in range(n):
             o, r, d, ep_ret, ep_len = test_env.reset(), 0, False, 0, 0
@@ -454,4 +456,15 @@ class Actor(_Net):
                 ep_ret += r
                 ep_len += 1
             rew.append(ep_ret)
+        logdir = getattr(self.opt, "summary_dir", None)
+        if logdir:
+            if getattr(self, "_writer", None) is None:
+                from .logx import SummaryWriter
+                self._writer = SummaryWriter(logdir)
+            sample_times = 0
+            if replay_buffer is not None:
+                from .workers import _get, _remote
+                sample_times = _get(_remote(replay_buffer.get_counts))[0]
+            self._writer.add_scalar("Reward", sum(rew) / 25, sample_times)
+            self._writer.flush()
         return sum(rew) / n

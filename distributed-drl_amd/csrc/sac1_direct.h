@@ -1040,6 +1040,10 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     bool okv[4];
     long long j_idx = 0, b_idx = 0;
     bool j_ok = false, b_ok = false;
+    // DGRAD with fused layer-1 partials: the optimizer state of this column tile's layer-1 parameters (two elements per thread)
+    long long off2[2] = {0, 0}, e2[2] = {0, 0};
+    bool ok2[2] = {false, false};
+    float am2[2] = {0.f, 0.f}, av2[2] = {0.f, 0.f}, ap2[2] = {0.f, 0.f}, at2[2] = {0.f, 0.f};
     auto epilogue_operands = [&]() {
         if (is_dgrad) mk = *reinterpret_cast<const float4 *>(jb.mask + ((long long)(m0 / 4 + cg) * jb.ldmask + n0 + r) * 4);  // mapping C: (col r, row group cg)
         if (has_da) {
@@ -1056,6 +1060,18 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                 const bool ok = idx < 32 * 12 && k < jb.part_nk;
                 const float v = jb.part_x[ok ? (long long)(m0 + rr) * jb.part_ldx + k : 0];
                 px_v[u] = ok ? v : 0.f;
+            }
+        }
+        if (has_part && jobs.ad.on && jb.part_cnt != nullptr) {
+            // requested from inside the K loop: by the hand-off (whose drain waits for vmcnt(0)) they have long arrived, and the row tile
+            // that turns out to be last has them without a round trip of its own
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int idx = tid + 256 * u2, k = idx >> 5, col = idx & 31;
+                ok2[u2] = idx < jb.part_nk * 32 && n0 + col < jb.N;
+                e2[u2] = ok2[u2] ? (long long)k * jb.N + n0 + col : 0;
+                off2[u2] = jb.part_adam_off + (ok2[u2] ? w1y_index(k, n0 + col) : 0);
+                am2[u2] = jobs.ad.m[off2[u2]]; av2[u2] = jobs.ad.v[off2[u2]]; ap2[u2] = jobs.ad.p[off2[u2]]; at2[u2] = jobs.ad.t[off2[u2]];
             }
         }
         if (jobs.ad.on) {
@@ -1239,21 +1255,8 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
                     }
                 }
                 if (la) {
-                    // The optimizer state of this column tile's layer-1 parameters does not depend on the partials: every row
-                    // tile requests it BEFORE the hand-off (two elements per thread: part_nk * 32 <= 512), so the workgroup that
-                    // turns out to be last has it by the time its partial loads return — one fabric round trip, not two.
+                    // (the optimizer state of this column tile's layer-1 parameters was requested from inside the K loop: epilogue_operands)
                     const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
-                    long long off2[2], e2[2];
-                    bool ok2[2];
-                    float am2[2], av2[2], ap2[2], at2[2];
-#pragma unroll
-                    for (int u2 = 0; u2 < 2; ++u2) {
-                        const int idx = tid + 256 * u2, k = idx >> 5, col = idx & 31;
-                        ok2[u2] = idx < jb.part_nk * 32 && n0 + col < jb.N;
-                        e2[u2] = ok2[u2] ? (long long)k * jb.N + n0 + col : 0;
-                        off2[u2] = jb.part_adam_off + (ok2[u2] ? w1y_index(k, n0 + col) : 0);
-                        am2[u2] = jobs.ad.m[off2[u2]]; av2[u2] = jobs.ad.v[off2[u2]]; ap2[u2] = jobs.ad.p[off2[u2]]; at2[u2] = jobs.ad.t[off2[u2]];
-                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (tid == 0) s_last = __hip_atomic_fetch_add(jb.part_cnt + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

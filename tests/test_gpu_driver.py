@@ -243,12 +243,17 @@ def test_worker_test_sac1_saves_best_weights(tmp_path):
     from distributed_drl_amd.agent import HyperParameters, Learner
     opt = HyperParameters()
     opt.hidden_sizes, opt.max_ep_len, opt.save_dir, opt.env_name = (64, 32), 60, str(tmp_path), "LunarLanderContinuous-v2"
+    opt.summary_dir = str(tmp_path / "tb")          # the reference's tf.summary scalar (actor_learner.py:210-229)
     keys, vals = Learner(opt).get_weights()
     ps = d.ParameterServer(keys, vals)
     rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 100)
     lines = []
     best = d.worker_test_sac1(ps, rb, opt, log=lines.append, sleep=lambda s: None, max_rounds=2, n=2)
     assert best > -1000 and any("weights saved" in l for l in lines) and any(l.startswith("test_reward:") for l in lines)
+    import glob
+    from distributed_drl_amd import logx
+    ev = logx.read_scalars(glob.glob(str(tmp_path / "tb" / "events.out.tfevents.*"))[0])
+    assert len(ev) == 2 and all(tag == "Reward" and step == 0 for step, tag, _ in ev)   # one scalar per round, at step sample_times
     w = pickle.load(open(tmp_path / "weights.pickle", "rb"))
     assert set(w.keys()) == set(keys)
 

@@ -260,3 +260,17 @@ def test_epoch_logger_progress_file(tmp_path):
     assert json.load(open(tmp_path / "dsac" / "dsac_s3" / "config.json"))["exp_name"] == "dsac"
     with pytest.raises(AssertionError):
         lg.log_tabular("NewKey", 1)
+
+
+def test_tensorboard_event_file_roundtrip(tmp_path):
+    """The scalar stream Actor.test() writes in place of tf.summary.FileWriter (actor_learner.py:210-229): TFRecord framing with
+    masked crc32c (known answer: crc32c(b"123456789") = 0xE3069283), hand-encoded Event / Summary protobufs, read back."""
+    from distributed_drl_amd import logx
+    assert logx._crc32c(b"123456789") == 0xE3069283
+    w = logx.SummaryWriter(str(tmp_path))
+    for step, v in ((0, -183.5), (300, 12.25), (70000, 251.0)):
+        w.add_scalar("Reward", v, step)
+    w.close()
+    assert logx.read_scalars(w.path) == [(0, "Reward", -183.5), (300, "Reward", 12.25), (70000, "Reward", 251.0)]
+    raw = open(w.path, "rb").read()
+    assert b"brain.Event:2" in raw[:64] and os.path.basename(w.path).startswith("events.out.tfevents.")
