@@ -747,7 +747,7 @@ struct ddrl_sac1 {
     DGJobs dg_bq[2], dg_mid, dg_pi;
     // direct-path activations (x4 images, see sac1_direct.h) and the dgrad images of the main layer-2 kernels
     int Lp1, Lp2;
-    float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq, *w3snap;
+    float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq, *w3snap, *xp_r4;
     float *c4_pi[2], *c4_q[3];   // c4_q[2]: V (SAC-v)
     float *xv_r4;                // SAC-v: the [x | 1] image of V's layer-1 wgrad
     int *part_cnt;       // arrival counters of the policy layer-1 partials (one per column tile)
@@ -881,7 +881,7 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
     const int Kp1 = L.Kp1, Np2 = L.Np2, nt2 = (h2 + 31) / 32;
     const float *Pm = h->main_p, *Pt = h->target_p, *S = h->slab;
     DDRL_REQUIRE(L.v_W1 - L.q_W1[1] == L.q_W1[1] - L.q_W1[0], "internal: the value networks must sit at equal distances");
-    h->fused_l1_wgrad = true;
+    h->fused_l1_wgrad = false;   // (direct path: the policy's layer-1 wgrad is a job of its own, no row-tile partials)
     h->sh_cur = 0;
     const long long HP = (long long)DFH * B * DNT;
     const long long H1I = (long long)B * h->Lp1, H2C = (long long)Np2 * B, H2R = (long long)B * h->Lp2;
@@ -919,7 +919,7 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
         {
             DFJob j{};
             j.b2 = Pm + L.pi_b2; j.wh0 = Pm + L.pi_Wmu; j.wh1 = Pm + L.pi_Wls; j.nh = 2 * a; j.hsplit = a; j.hstride = a; j.hp = h->hp;
-            j.H2c4 = h->H2c4; j.H2r4 = h->H2r4; j.H1r4 = h->H1r4; j.aug = h->xp; j.aug_ld = h->ldxp;
+            j.H2c4 = h->H2c4; j.H2r4 = h->H2r4; j.H1r4 = h->H1r4; j.xr4 = h->xp_r4;
             FA.job[0] = j;
         }
         FA.job[1] = vj(Pm, 0, 1); FA.job[1].H2c4 = h->H2c4 + 1 * H2C; FA.job[1].H2r4 = h->H2r4 + 1 * H2R; FA.job[1].H1r4 = h->H1r4 + 1 * H1I;
@@ -983,19 +983,23 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
         return j;
     };
     const int img1[3] = {1, 2, 4}, img2r[3] = {1, 2, 3};   // H1r4 / H2r4 slots of q1(x,a), q2(x,a), v(x)
-    {   // ---- backward launch 2: policy-head backward tiles, loss means, layer-2 + head wgrads of the three value networks
+    {   // ---- backward launch 2: the policy dgrad with its A operand generated in the tile (see the SAC1 tables), the policy-head backward
+        // tiles beside it, layer-2 + head wgrads of the three value networks
         DGJobs &M = h->dg_mid;
         M = DGJobs{};
         M.B = B; M.Bv = Bv; M.ad = ctx;
+        DGJob d{};
+        d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->H2c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
+        d.bgen = 3; d.dap = h->da_part; d.nparts = (h1 + 31) / 32; d.save0 = h->save0; d.wmu = Pm + L.pi_Wmu; d.wls = Pm + L.pi_Wls;
+        d.nact = a; d.alpha = (float)cfg->alpha; d.scale = (float)cfg->act_scale;
+        d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = h->dZ1r4 + 3 * H1I; d.ldc = h->Lp1; d.adam_off = -1;
+        dg_add(M, d);
         DGJob rc{};
         rc.type = DG_ROWS_C; rc.M = B; rc.N = h2; rc.K = 0; rc.nact = a; rc.adam_off = -1;
         rc.h2c4 = h->H2c4; rc.dap = h->da_part; rc.nparts = (h1 + 31) / 32; rc.save0 = h->save0;
         rc.wmu = Pm + L.pi_Wmu; rc.wls = Pm + L.pi_Wls; rc.dz_c4 = h->dzpi_c4; rc.dz_r4 = h->dzpi_r4; rc.dhead_r4 = h->dhead_r4;
         rc.ld_r4 = h->Lp2; rc.alpha = (float)cfg->alpha; rc.scale = (float)cfg->act_scale;
         dg_add(M, rc);
-        DGJob ls{};
-        ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 4;
-        dg_add(M, ls);
         for (int q = 0; q < 3; ++q) {
             DGJob j = wgrad_j4(h->H1r4 + img1[q] * H1I, h->H2r4 + img2r[q] * H2R, vW2[q], vb2[q], h->c4_q[q]);
             j.bgen = 1; j.gw = h->w3snap + 512 * q; j.gdq = h->dq + (long long)q * B;   // (W3 as the previous launch saw it)
@@ -1003,16 +1007,10 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
         }
         for (int q = 0; q < 3; ++q) dg_add(M, wgrad_rm(h->H2r4 + img2r[q] * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, vW3[q]));
     }
-    {   // ---- backward launch 3: policy dgrad (+ layer-1 wgrad partials), policy wgrads, layer-1 wgrads of the value networks
+    {   // ---- backward launch 3: policy wgrads (layer 2, heads, layer 1), layer-1 wgrads of the value networks, loss means, optimizer bookkeeping
         DGJobs &P = h->dg_pi;
         P = DGJobs{};
         P.B = B; P.Bv = Bv; P.ad = ctx;
-        DGJob d{};
-        d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->dzpi_c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
-        d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = nullptr; d.ldc = h->Lp1; d.adam_off = -1;
-        d.part_x = h->xp; d.part = h->part; d.part_nk = o + 1; d.part_ldx = h->ldxp;
-        d.part_cnt = h->part_cnt; d.part_adam_off = L.pi_W1;
-        dg_add(P, d);
         dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));
         dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4, 32, a, L.pi_Wmu));
         dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4 + (long long)a * 4, 32, a, L.pi_Wls));
@@ -1021,13 +1019,22 @@ static int build_sacv_direct(ddrl_sac1 *h, int Bv, int B) {
             j.type = DG_WGRAD_W1Y;
             dg_add(P, j);
         }
+        {
+            DGJob j = wgrad_rm(h->xp_r4, 32, o + 1, h->dZ1r4 + 3 * H1I, h->Lp1, h1, L.pi_W1);
+            j.type = DG_WGRAD_W1Y;
+            dg_add(P, j);
+        }
+        DGJob ls{};
+        ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 4;
+        ls.nparts = -1;   // + the optimizer's books
+        dg_add(P, ls);
     }
     h->rc = RowsC{};
     h->rc.nl = 4;
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, L.total_int, L.n_pi_int, 0,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak),
-                     h->part, L.pi_W1 / 4, (long long)(o + 1) * h1 / 4, (long long)(o + 1) * h1 / 4, (B + 31) / 32, 0u};
+                     h->part, L.pi_W1 / 4, (long long)(o + 1) * h1 / 4, (long long)(o + 1) * h1 / 4, 0, 0u};
     h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
     h->fuse_apply = false; h->sample_armed = false;
     return DDRL_OK;
@@ -1088,8 +1095,8 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         // image slots: SAC1 — H1r4 / H2c4: pi(x) q1(x,a) q2(x,a) q1(x,pi); H2r4: pi q1 q2; dZ1r4: q1 q2.  SAC-v adds V to each.
         const int xv = cfg->variant == DDRL_SAC_V ? 1 : 0;
         ALLOC(H1r4, (size_t)(4 + xv) * B * h->Lp1); ALLOC(H2c4, (size_t)(4 + xv) * Np2 * B); ALLOC(H2r4, (size_t)(3 + xv) * B * h->Lp2);
-        ALLOC(dZ1r4, (size_t)(2 + xv) * B * h->Lp1); ALLOC(dzpi_c4, (size_t)Np2 * B); ALLOC(dzpi_r4, (size_t)B * h->Lp2);
-        ALLOC(dhead_r4, (size_t)B * 32); ALLOC(xa_r4, (size_t)B * 32); ALLOC(xv_r4, (size_t)B * 32); ALLOC(da_part, (size_t)16 * B * 4);
+        ALLOC(dZ1r4, (size_t)(3 + xv) * B * h->Lp1) /* q1 q2 (v) + the policy's (last slot) */; ALLOC(dzpi_c4, (size_t)Np2 * B); ALLOC(dzpi_r4, (size_t)B * h->Lp2);
+        ALLOC(dhead_r4, (size_t)B * 32); ALLOC(xa_r4, (size_t)B * 32); ALLOC(xv_r4, (size_t)B * 32); ALLOC(xp_r4, (size_t)B * 32); ALLOC(da_part, (size_t)16 * B * 4);
         ALLOC(dq, (size_t)3 * B + 256); ALLOC(w3snap, (size_t)3 * 512);
         for (int i = 0; i < 2; ++i) items.push_back(Item{&h->c4_pi[i], reserve((size_t)Np2 * Kp1)});
         for (int i = 0; i < 2 + xv; ++i) items.push_back(Item{&h->c4_q[i], reserve((size_t)Np2 * Kp1)});
@@ -1130,6 +1137,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         k_fill_col4<<<((3 + xv) * B / 4 + 255) / 256, 256>>>(h->H2r4, (long long)(3 + xv) * B / 4, h->Lp2, h2);
         k_fill_col4<<<(B / 4 + 255) / 256, 256>>>(h->xa_r4, (long long)B / 4, 32, o + a);
         k_fill_col4<<<(B / 4 + 255) / 256, 256>>>(h->xv_r4, (long long)B / 4, 32, o);
+        k_fill_col4<<<(B / 4 + 255) / 256, 256>>>(h->xp_r4, (long long)B / 4, 32, o);
     }
     k_fill_col<<<(B + 255) / 256, 256>>>(h->xa, B, h->ldxa, o + a, 1.0f);
     k_fill_col<<<(B + 255) / 256, 256>>>(h->xp, B, h->ldxp, o, 1.0f);
@@ -1209,7 +1217,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     }
     // ---- direct-operand path (sac1_direct.h)
     if (h->fused) {
-        h->fused_l1_wgrad = true;
+        h->fused_l1_wgrad = false;   // (direct path: the policy's layer-1 wgrad is a job of its own, no row-tile partials)
         h->sh_cur = 0;
         const float *S = h->slab;
         const long long HP = (long long)DFH * B * DNT;
@@ -1251,7 +1259,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             DFArgs &FA = h->f_a[st], &FB = h->f_b[st];
             head(HA); args(FA, 5);
             FA.job[0] = pij(Pm, 0); FA.job[0].H2c4 = h->H2c4; FA.job[0].H2r4 = h->H2r4; FA.job[0].H1r4 = h->H1r4;
-            FA.job[0].aug = h->xp; FA.job[0].aug_ld = h->ldxp;
+            FA.job[0].xr4 = h->xp_r4;   // [x | 1] as an x4 image: A operand of the policy's layer-1 wgrad
             FA.job[1] = pij(Pm, 1);
             FA.job[2] = pij(Pt, 2);
             FA.job[3] = qj(Pm, 0, 3); FA.job[3].H2c4 = h->H2c4 + 1 * H2C; FA.job[3].H2r4 = h->H2r4 + 1 * H2R; FA.job[3].H1r4 = h->H1r4 + 1 * H1I;
@@ -1311,19 +1319,24 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             j.type = DG_WGRAD_RM; j.M = M; j.N = N; j.K = B; j.A = A; j.lda = lda; j.B = Bm; j.ldb = ldb; j.adam_off = off; j.ldc = N;
             return j;
         };
-        {   // ---- backward launch 2: policy-head backward tiles, loss means, Q layer-2 + head wgrads (optimizer in the epilogue)
+        {   // ---- backward launch 2: the policy dgrad — its A operand (dZ2 of the policy trunk) generated in the tile from the dQ/da
+            // partials (k_dg, bgen = 3), so it does not wait for the policy-head backward tiles, which run beside it and write the
+            // images the policy wgrads of launch 3 contract over —, the Q layer-2 + head wgrads (optimizer in the epilogue)
             DGJobs &M = h->dg_mid;
             M = DGJobs{};
             M.B = B; M.Bv = Bv; M.ad = ctx;
+            DGJob d{};
+            d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->H2c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;   // (B: launch_stage picks the copy)
+            d.bgen = 3; d.dap = h->da_part; d.nparts = (h1 + 31) / 32; d.save0 = h->save0; d.wmu = Pm + L.pi_Wmu; d.wls = Pm + L.pi_Wls;
+            d.nact = a; d.alpha = (float)cfg->alpha; d.scale = (float)cfg->act_scale;
+            d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = h->dZ1r4 + 2 * H1I; d.ldc = h->Lp1; d.adam_off = -1;
+            dg_add(M, d);
             DGJob rc{};
             rc.type = DG_ROWS_C; rc.M = B; rc.N = h2; rc.K = 0; rc.nact = a; rc.adam_off = -1;
             rc.h2c4 = h->H2c4; rc.dap = h->da_part; rc.nparts = (h1 + 31) / 32; rc.save0 = h->save0;
             rc.wmu = Pm + L.pi_Wmu; rc.wls = Pm + L.pi_Wls; rc.dz_c4 = h->dzpi_c4; rc.dz_r4 = h->dzpi_r4; rc.dhead_r4 = h->dhead_r4;
             rc.ld_r4 = h->Lp2; rc.alpha = (float)cfg->alpha; rc.scale = (float)cfg->act_scale;
             dg_add(M, rc);
-            DGJob ls{};
-            ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 3;
-            dg_add(M, ls);
             for (int q = 0; q < 2; ++q) {
                 DGJob j = wgrad_j4(h->H1r4 + (1 + q) * H1I, h->H2r4 + (1 + q) * H2R, L.q_W2[q], L.q_b2[q], h->c4_q[q]);
                 j.bgen = 1; j.gw = h->w3snap + 512 * q; j.gdq = h->dq + (long long)q * B;   // (W3 as the previous launch saw it)
@@ -1331,17 +1344,12 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             }
             for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
         }
-        {   // ---- backward launch 3: policy dgrad (+ layer-1 wgrad partials), policy wgrads, Q layer-1 wgrads
+        {   // ---- backward launch 3: the wgrads that need launch 2's outputs — policy layer 2 / heads / layer 1, Q layer 1 —, loss means,
+            // optimizer bookkeeping.  No hand-off inside the launch any more: every tile is a plain GEMM tile with its Adam epilogue.
             DGJobs &P = h->dg_pi;
             P = DGJobs{};
             P.B = B; P.Bv = Bv; P.ad = ctx;
-            DGJob d{};
-            d.type = DG_DGRAD; d.M = B; d.N = h1; d.K = h2; d.A = h->dzpi_c4; d.lda = B; d.B = h->c4_pi[0]; d.ldb = Kp1;
-            d.mask = h->H1r4; d.ldmask = h->Lp1; d.C = nullptr; d.ldc = h->Lp1; d.adam_off = -1;
-            d.part_x = h->xp; d.part = h->part; d.part_nk = o + 1; d.part_ldx = h->ldxp;
-            d.part_cnt = h->part_cnt; d.part_adam_off = L.pi_W1;
-            dg_add(P, d);
-            dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));
+            dg_add(P, wgrad_j4(h->H1r4, h->dzpi_r4, L.pi_W2, L.pi_b2, h->c4_pi[1]));   // job 0: launch_stage picks the shadow copy
             dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4, 32, a, L.pi_Wmu));
             dg_add(P, wgrad_rm(h->H2r4, h->Lp2, h2 + 1, h->dhead_r4 + (long long)a * 4, 32, a, L.pi_Wls));
             for (int q = 0; q < 2; ++q) {
@@ -1349,6 +1357,15 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 j.type = DG_WGRAD_W1Y;   // [W1 ; b1] lives in the layer-1 block layout
                 dg_add(P, j);
             }
+            {
+                DGJob j = wgrad_rm(h->xp_r4, 32, o + 1, h->dZ1r4 + 2 * H1I, h->Lp1, h1, L.pi_W1);
+                j.type = DG_WGRAD_W1Y;
+                dg_add(P, j);
+            }
+            DGJob ls{};
+            ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 3;
+            ls.nparts = -1;   // + the optimizer's books
+            dg_add(P, ls);
         }
     }
 
@@ -1550,6 +1567,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 DGJobs &J = h->dg_mid;
                 J.ad.on = h->fuse_apply ? 1 : 0;
                 J.ad.opt = h->opt + h->opt_cur;
+                J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image of the policy's layer-2 kernel ...
                 launch_dg(J, s, 3);
                 break;
             }
@@ -1557,10 +1575,9 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 DGJobs &J = h->dg_pi;
                 J.ad.on = h->fuse_apply ? 1 : 0;
                 J.ad.opt = h->opt + h->opt_cur;
-                J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image ...
-                J.job[1].shadow = h->c4_pi[h->sh_cur ^ 1];  // ... while the optimizer epilogue of the same launch writes the next one
-                J.ad.opt_next = h->opt + (h->opt_cur ^ 1);  // the policy's layer-1 step + the optimizer bookkeeping ride in this launch
-                J.ad.noise_adv = h->noise_pending;          // (last-arriving row tile per column tile, see k_dg)
+                J.job[0].shadow = h->c4_pi[h->sh_cur ^ 1];  // ... the optimizer epilogue of the policy's layer-2 wgrad writes the next one
+                J.ad.opt_next = h->opt + (h->opt_cur ^ 1);  // the optimizer bookkeeping rides in this launch (its loss tile)
+                J.ad.noise_adv = h->noise_pending;
                 launch_dg(J, s, 4);
                 if (J.ad.on) { h->opt_cur ^= 1; h->sh_cur ^= 1; }
                 break;

@@ -769,7 +769,7 @@ struct alignas(64) DGJob {
     float *losses;
     int nl;
 };
-constexpr int MAX_DG_JOBS = 8;
+constexpr int MAX_DG_JOBS = 16;
 struct DGJobs {
     int njobs, total_tiles;
     int tile_start[MAX_DG_JOBS];
@@ -792,13 +792,14 @@ struct DGJobs {
 
 
 template <int GMAX>
-__global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, int ts3, int ts4, int ts5, int ts6, int ts7, int kid, DGJobs jobs) {
+__global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, int tsC, int tsD, int tsE, int tsF, int tsG, int tsH, int kid, DGJobs jobs) {
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ float s_q[8][32];
     __shared__ float s_g[32];
     __shared__ float s_px[32][13];
     __shared__ float s_wa[4][32];
     __shared__ __attribute__((aligned(16))) float s_gw[512];
+    __shared__ __attribute__((aligned(16))) float s_w8[512 * 8];   // agen: the policy's head kernels, [k][Wmu 0..3 | Wls 0..3]
     __shared__ int s_last;
     int t, ji;
 #ifdef DDRL_STAMPS
@@ -814,41 +815,45 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
         const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
-    static_assert(MAX_DG_JOBS == 8, "k_dg takes tile_start[1..7] as scalar arguments");
-    ji = (t >= ts1) + (t >= ts2) + (t >= ts3) + (t >= ts4) + (t >= ts5) + (t >= ts6) + (t >= ts7);
+    static_assert(MAX_DG_JOBS == 16, "k_dg takes tile_start[1..15] as eight scalar arguments, two 16-bit starts each (0xffff: no such job)");
+    {
+        auto ge2 = [&](int p) { return (t >= (p & 0xffff)) + (t >= (int)((unsigned)p >> 16)); };
+        ji = (t >= (int)((unsigned)tsA >> 16)) + ge2(tsB) + ge2(tsC) + ge2(tsD) + ge2(tsE) + ge2(tsF) + ge2(tsG) + ge2(tsH);
+    }
     const DGJob &jb = jobs.job[ji];
     // ONE round trip to the kernarg segment: the hot line of the job record into SGPRs + one touch per other line of the record and
     // of the launch header (so that every later field load hits the scalar cache), one wait
     typedef int v16i __attribute__((ext_vector_type(16)));
     static_assert(sizeof(DGJob) == 6 * 64 && offsetof(DGJob, M) == 64, "DGJob: hot line = the first 64 bytes, at most 6 lines");
-    static_assert(offsetof(DGJobs, job) == 5 * 64, "DGJobs: header of at most 5 lines, records 64-byte aligned");
+    static_assert(offsetof(DGJobs, job) == 6 * 64, "DGJobs: header of 6 lines, records 64-byte aligned");
     v16i hot;
     int kl;
     {
         // (addresses from the kernarg segment pointer: taking &jobs would make the compiler copy the by-value struct to scratch.)
-        // Kernarg layout: nine ints, then DGJobs at the next multiple of its 64-byte alignment.
+        // Kernarg layout: ten ints, then DGJobs at the next multiple of its 64-byte alignment.
         constexpr int JOBS_OFF = 64;
-        static_assert(alignof(DGJobs) == 64 && 9 * sizeof(int) <= JOBS_OFF, "kernarg offset of k_dg's DGJobs argument");
+        static_assert(alignof(DGJobs) == 64 && 10 * sizeof(int) <= JOBS_OFF, "kernarg offset of k_dg's DGJobs argument");
         const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
         const int jboff = __builtin_amdgcn_readfirstlane(JOBS_OFF + (int)offsetof(DGJobs, job) + ji * (int)sizeof(DGJob));  // (wave-uniform: an SGPR address)
         const void *hdp = ka + JOBS_OFF, *jbp = ka + jboff;
-        int k1, k2, k3, k4, k5, k6, k7, k8, k9, k10;
-        asm volatile("s_load_dwordx16 %0, %11, 0x0\n\t"
-                     "s_load_dword %1, %11, 0x40\n\t"
-                     "s_load_dword %2, %11, 0x80\n\t"
-                     "s_load_dword %3, %11, 0xc0\n\t"
-                     "s_load_dword %4, %11, 0x100\n\t"
-                     "s_load_dword %5, %11, 0x140\n\t"
-                     "s_load_dword %6, %12, 0x0\n\t"
-                     "s_load_dword %7, %12, 0x40\n\t"
-                     "s_load_dword %8, %12, 0x80\n\t"
-                     "s_load_dword %9, %12, 0xc0\n\t"
-                     "s_load_dword %10, %12, 0x100\n\t"
+        int k1, k2, k3, k4, k5, k6, k7, k8, k9, k10, k11;
+        asm volatile("s_load_dwordx16 %0, %12, 0x0\n\t"
+                     "s_load_dword %1, %12, 0x40\n\t"
+                     "s_load_dword %2, %12, 0x80\n\t"
+                     "s_load_dword %3, %12, 0xc0\n\t"
+                     "s_load_dword %4, %12, 0x100\n\t"
+                     "s_load_dword %5, %12, 0x140\n\t"
+                     "s_load_dword %6, %13, 0x0\n\t"
+                     "s_load_dword %7, %13, 0x40\n\t"
+                     "s_load_dword %8, %13, 0x80\n\t"
+                     "s_load_dword %9, %13, 0xc0\n\t"
+                     "s_load_dword %10, %13, 0x100\n\t"
+                     "s_load_dword %11, %13, 0x140\n\t"
                      "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(hot), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7), "=&s"(k8), "=&s"(k9), "=&s"(k10)
+                     : "=&s"(hot), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7), "=&s"(k8), "=&s"(k9), "=&s"(k10), "=&s"(k11)
                      : "s"(jbp), "s"(hdp)
                      : "memory");
-        kl = k1 | k2 | k3 | k4 | k5 | k6 | k7 | k8 | k9 | k10;
+        kl = k1 | k2 | k3 | k4 | k5 | k6 | k7 | k8 | k9 | k10 | k11;
     }
     // (the pointers are rebuilt from SGPR halves: the cast goes through the GLOBAL address space, or every load through them
     // would be a flat_load — counted out of order, the compiler then waits for vmcnt(0) in front of every MFMA group)
@@ -883,6 +888,13 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             const float mean = tot / (float)Bv;
             if (lane == 0 && c < jb.nl) jb.losses[c] = c == 0 ? mean : 0.5f * mean;
         }
+        if (lane == 0 && jobs.ad.on && jb.nparts == -1) {   // (nparts = -1: this loss tile also keeps the optimizer's books, once per update)
+            OptState nx = *jobs.ad.opt;
+            nx.b1p_pi *= jobs.ad.b1; nx.b2p_pi *= jobs.ad.b2; nx.b1p_q *= jobs.ad.b1; nx.b2p_q *= jobs.ad.b2;
+            nx.t_pi += 1; nx.t_q += 1;
+            nx.noise_ctr += jobs.ad.noise_adv;
+            *jobs.ad.opt_next = nx;
+        }
         return;
     }
     const int tiles_m = hot_tiles_m;
@@ -910,9 +922,11 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
 #pragma unroll
             for (int a2 = 0; a2 < 4; ++a2) {
                 const long long o = (long long)(okc ? c : 0) * act + (a2 < act ? a2 : 0);
-                const float vm = jb.wmu[o], vl = jb.wls[o];
-                wm[e][a2] = (okc && a2 < act) ? vm : 0.f;
-                wl[e][a2] = (okc && a2 < act) ? vl : 0.f;
+                // (masked by multiplication: behind a select the compiler sinks each of the 32 loads into a branch of its own and
+                // waits for it there — sixteen dependent round trips: 14.3 k cycles per tile against 9.1 k)
+                const float vm = jb.wmu[o], vl = jb.wls[o], keep = (okc && a2 < act) ? 1.0f : 0.f;
+                wm[e][a2] = vm * keep;
+                wl[e][a2] = vl * keep;
             }
         }
         float ga[4] = {0.f, 0.f, 0.f, 0.f};
@@ -989,13 +1003,16 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     // bytes for all 32 lanes of a half-wave: a per-lane load of them would cost the fetch path as much as a tile load,
     // so the vector is staged once per workgroup in LDS (two coalesced loads per thread) and read from there in the K loop.
     const bool has_gen = type == DG_DGRAD_Q || hot_bgen;  // block-uniform
+    const bool agen = hot_bgen == 3;                       // block-uniform: DG_DGRAD of the policy, A = dZ2 generated
     float gv0 = 0.f, gv1 = 0.f, gwn = 0.f;
     if (has_gen) {
         const float *gp = hot_gp;
         const int glen = 8 * G;  // (W3 / dq are followed by readable memory up to the next multiple of 8)
-        gv0 = gp[tid < glen ? tid : 0];
-        gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
-        if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < hot_N) ? n0 + l31 : 0];
+        if (hot_bgen != 3) {   // (3: the policy dgrad generates its A operand from per-row gradients and the head kernels: below)
+            gv0 = gp[tid < glen ? tid : 0];
+            gv1 = gp[tid + 256 < glen ? tid + 256 : 0];
+            if (type != DG_DGRAD_Q) gwn = jb.gw[(n0 + l31 < hot_N) ? n0 + l31 : 0];
+        }
         if (type == DG_DGRAD_Q && jb.gw_snap && t == 0) {  // block-uniform
             if (tid < glen) jb.gw_snap[tid] = gv0;
             if (tid + 256 < glen) jb.gw_snap[tid + 256] = gv1;
@@ -1017,6 +1034,72 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     constexpr int DGP = DGP0 < GMAX ? DGP0 : GMAX;
 #pragma unroll
     for (int g = 0; g < DGP; ++g) fetch_group(g);
+    // ---- policy dgrad with a GENERATED A operand (bgen = 3): A[row][k] = dZ2 of the policy trunk = (H2[row][k] > 0) * sum_a (dmu[row][a]
+    // Wmu[k][a] + dls[row][a] Wls[k][a]) — the policy-head backward of this tile's 32 rows, every lane for its own row (the lane's row IS
+    // the row of its A elements), with the arithmetic of the DG_ROWS_C tiles (which still write the images the policy wgrads contract
+    // over, off this chain).  The dgrad no longer waits for a launch between the dQ/da partials and itself, and the layer-1 wgrad of
+    // the policy becomes a plain job of the last launch instead of a hand-off at the end of the update's longest chain.
+    float pdm[4] = {0.f, 0.f, 0.f, 0.f}, pdl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (agen) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int act = jb.nact, row = m0 + l31;
+        float4 dp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dp[q] = *reinterpret_cast<const float4 *>(jb.dap + ((long long)(q < jb.nparts ? q : 0) * Bn + row) * 4);
+        float4 sv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sv[c] = *reinterpret_cast<const float4 *>(jb.save0 + ((long long)row * act + (c < act ? c : 0)) * 4);
+        // head kernels: thread = contraction index k (and k + 256): Wmu[k][0..act), Wls[k][0..act) -> one [k][8] row of s_w8 (unused action
+        // slots and the rows K .. 8G - 1 are zero), two float2 loads per row when act == 2
+        float4 wm4[2], wl4[2];
+        const int k0 = tid, k1 = tid + 256;
+        const bool ok0 = k0 < Kc, ok1 = k1 < Kc;
+        const long long kb0 = (long long)(ok0 ? k0 : 0) * act, kb1 = (long long)(ok1 ? k1 : 0) * act;
+        if (act == 2) {  // block-uniform; every load of a side is issued before the first use (one wait, not one per row)
+            const float2 a0 = *reinterpret_cast<const float2 *>(jb.wmu + kb0), b0 = *reinterpret_cast<const float2 *>(jb.wls + kb0);
+            const float2 a1 = *reinterpret_cast<const float2 *>(jb.wmu + kb1), b1 = *reinterpret_cast<const float2 *>(jb.wls + kb1);
+            const float e0 = ok0 ? 1.0f : 0.f, e1 = ok1 ? 1.0f : 0.f;
+            wm4[0] = make_float4(a0.x * e0, a0.y * e0, 0.f, 0.f); wl4[0] = make_float4(b0.x * e0, b0.y * e0, 0.f, 0.f);
+            wm4[1] = make_float4(a1.x * e1, a1.y * e1, 0.f, 0.f); wl4[1] = make_float4(b1.x * e1, b1.y * e1, 0.f, 0.f);
+        } else {
+            float am[2][4], al[2][4];
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2) {
+                const int ao = a2 < act ? a2 : 0;
+                am[0][a2] = jb.wmu[kb0 + ao]; al[0][a2] = jb.wls[kb0 + ao]; am[1][a2] = jb.wmu[kb1 + ao]; al[1][a2] = jb.wls[kb1 + ao];
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2) {
+                const float e0 = (ok0 && a2 < act) ? 1.0f : 0.f, e1 = (ok1 && a2 < act) ? 1.0f : 0.f;
+                am[0][a2] *= e0; al[0][a2] *= e0; am[1][a2] *= e1; al[1][a2] *= e1;
+            }
+            wm4[0] = make_float4(am[0][0], am[0][1], am[0][2], am[0][3]); wl4[0] = make_float4(al[0][0], al[0][1], al[0][2], al[0][3]);
+            wm4[1] = make_float4(am[1][0], am[1][1], am[1][2], am[1][3]); wl4[1] = make_float4(al[1][0], al[1][1], al[1][2], al[1][3]);
+        }
+        float ga[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < jb.nparts) { ga[0] += dp[q].x; ga[1] += dp[q].y; ga[2] += dp[q].z; ga[3] += dp[q].w; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float av = sv[c].x, std = sv[c].y, tt = sv[c].z, e = sv[c].w;
+            const float glp = row < Bv ? jb.alpha / (float)Bv : 0.f;  // d pi_loss / d logp_pi (padding rows carry no loss)
+            const float om = 1.0f - av * av;
+            const float cl = fminf(fmaxf(om, 0.f), 1.f);
+            const float du = (ga[c] * jb.scale) * om + glp * ((2.0f * av * om) / (cl + 1e-6f));
+            const float sd = std + STD_EPS;
+            const float z = (e * std) / sd;
+            const float dzdl = ((e * std) * STD_EPS) / (sd * sd);
+            const float dl = du * (e * std) + glp * (-(z * dzdl) - 1.0f);
+            pdm[c] = c < act ? du : 0.f;
+            pdl[c] = c < act ? dl * (11.0f * (1.0f - tt * tt)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = tid + 256 * u;
+            if (k < 8 * G) { *reinterpret_cast<float4 *>(&s_w8[k * 8]) = wm4[u]; *reinterpret_cast<float4 *>(&s_w8[k * 8 + 4]) = wl4[u]; }
+        }
+    }
     ktouch(kl);
     DST(kid, 1);
     // ---- epilogue operands: requested from inside the K loop (behind the MFMAs of the first groups), so that the first
@@ -1106,7 +1189,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
     };
     // ---- DGRAD_Q prologue: q1, q2, q1(x,pi), the target backup, the per-row loss terms and dq = dLoss/dq (actor_learner.py:58-69)
     float dqr = m0 + l31 < Bv ? jb.gconst : 0.f;
-    if (has_gen) { s_gw[tid] = gv0; s_gw[tid + 256] = gv1; }
+    if (has_gen && !agen) { s_gw[tid] = gv0; s_gw[tid + 256] = gv1; }
     if (has_gen && !need_q) __syncthreads();
     if (type == DG_DGRAD_Q) {
         if (need_q) {
@@ -1187,6 +1270,19 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int ts1, int ts2, i
             if (type == DG_DGRAD_Q) {
                 const float4 w3 = *reinterpret_cast<const float4 *>(&s_gw[8 * (g0 + g) + 4 * h]);
                 av4 = make_float4(av4.x > 0.f ? dqr * w3.x : 0.f, av4.y > 0.f ? dqr * w3.y : 0.f, av4.z > 0.f ? dqr * w3.z : 0.f, av4.w > 0.f ? dqr * w3.w : 0.f);
+            } else if (agen) {
+                const float *wk = &s_w8[(8 * (g0 + g) + 4 * h) * 8];
+                float z4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 m4 = *reinterpret_cast<const float4 *>(wk + 8 * e), l4 = *reinterpret_cast<const float4 *>(wk + 8 * e + 4);
+                    float acc = fmaf(pdl[0], l4.x, pdm[0] * m4.x);     // (the summation order of the DG_ROWS_C tiles)
+                    acc = fmaf(pdm[1], m4.y, acc); acc = fmaf(pdl[1], l4.y, acc);
+                    acc = fmaf(pdm[2], m4.z, acc); acc = fmaf(pdl[2], l4.z, acc);
+                    acc = fmaf(pdm[3], m4.w, acc); acc = fmaf(pdl[3], l4.w, acc);
+                    z4[e] = acc;
+                }
+                av4 = make_float4(av4.x > 0.f ? z4[0] : 0.f, av4.y > 0.f ? z4[1] : 0.f, av4.z > 0.f ? z4[2] : 0.f, av4.w > 0.f ? z4[3] : 0.f);
             } else if (jb.bgen) {
                 const float4 d4 = *reinterpret_cast<const float4 *>(&s_gw[8 * (g0 + g) + 4 * h]);
                 bv4 = make_float4(bv4.x > 0.f ? d4.x * gwn : 0.f, bv4.y > 0.f ? d4.y * gwn : 0.f, bv4.z > 0.f ? d4.z * gwn : 0.f, bv4.w > 0.f ? d4.w * gwn : 0.f);
@@ -1368,7 +1464,7 @@ static void dg_add(DGJobs &js, DGJob j) {
     j.ntiles = j.type == DG_LOSS ? 1 : j.tiles_m * ((j.N + 31) / 32);
     j.tile_start = js.total_tiles;
     js.total_tiles += j.ntiles;
-    for (int i = js.njobs; i < MAX_DG_JOBS; ++i) js.tile_start[i] = 0x7fffffff;
+    for (int i = js.njobs; i < MAX_DG_JOBS; ++i) js.tile_start[i] = 0xffff;   // (k_dg compares 16-bit starts)
     js.tile_start[js.njobs] = j.tile_start;
     js.job[js.njobs++] = j;
 }
@@ -1387,8 +1483,10 @@ static void launch_dg(const DGJobs &J_, hipStream_t s, int kid = 0) {
         const int G = (j.K + 7) / 8, pw = (G + 3) / 4;
         if (pw > per_wave) per_wave = pw;
     }
-    if (per_wave <= 10) k_dg<10><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], kid, J);
-    else k_dg<DGMAX><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], ts[7], kid, J);
+    int pk[8];
+    for (int i = 0; i < 8; ++i) pk[i] = (ts[2 * i] & 0xffff) | (int)((unsigned)(ts[2 * i + 1] & 0xffff) << 16);   // pk[0]'s low half (job 0 starts at 0) is unused
+    if (per_wave <= 10) k_dg<10><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], pk[6], pk[7], kid, J);
+    else k_dg<DGMAX><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], pk[6], pk[7], kid, J);
 }
 
 // The dgrad image [N/4][ld][4] of a k4-interleaved kernel [K/4][Np][4] (after a set_weights / import / flat Adam step)
