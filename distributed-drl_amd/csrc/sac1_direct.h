@@ -1097,9 +1097,13 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = tid + 256 * u;
-            if (k < 8 * G) { *reinterpret_cast<float4 *>(&s_w8[k * 8]) = wm4[u]; *reinterpret_cast<float4 *>(&s_w8[k * 8 + 4]) = wl4[u]; }
+            if (k < 8 * G) {
+                if (act <= 2) *reinterpret_cast<float4 *>(&s_w8[k * 4]) = make_float4(wm4[u].x, wm4[u].y, wl4[u].x, wl4[u].y);   // packed rows: half the LDS reads
+                else { *reinterpret_cast<float4 *>(&s_w8[k * 8]) = wm4[u]; *reinterpret_cast<float4 *>(&s_w8[k * 8 + 4]) = wl4[u]; }
+            }
         }
     }
+    const bool agen2 = agen && jb.nact <= 2;   // block-uniform
     ktouch(kl);
     DST(kid, 1);
     // ---- epilogue operands: requested from inside the K loop (behind the MFMAs of the first groups), so that the first
@@ -1270,6 +1274,18 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
             if (type == DG_DGRAD_Q) {
                 const float4 w3 = *reinterpret_cast<const float4 *>(&s_gw[8 * (g0 + g) + 4 * h]);
                 av4 = make_float4(av4.x > 0.f ? dqr * w3.x : 0.f, av4.y > 0.f ? dqr * w3.y : 0.f, av4.z > 0.f ? dqr * w3.z : 0.f, av4.w > 0.f ? dqr * w3.w : 0.f);
+            } else if (agen2) {
+                // act <= 2: rows [Wmu0 Wmu1 Wls0 Wls1]; the terms of the action slots 2, 3 are exact zeros and add nothing (fma(0, 0, acc) == acc)
+                const float *wk = &s_w8[(8 * (g0 + g) + 4 * h) * 4];
+                float z4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wk + 4 * e);
+                    float acc = fmaf(pdl[0], w4.z, pdm[0] * w4.x);
+                    acc = fmaf(pdm[1], w4.y, acc); acc = fmaf(pdl[1], w4.w, acc);
+                    z4[e] = acc;
+                }
+                av4 = make_float4(av4.x > 0.f ? z4[0] : 0.f, av4.y > 0.f ? z4[1] : 0.f, av4.z > 0.f ? z4[2] : 0.f, av4.w > 0.f ? z4[3] : 0.f);
             } else if (agen) {
                 const float *wk = &s_w8[(8 * (g0 + g) + 4 * h) * 8];
                 float z4[4];
