@@ -745,11 +745,6 @@ struct alignas(64) DGJob {
     int wa_d0;
     float *da_part;          // ... dQ/da partials [tiles_n][B][4]
     int nact;
-    const float *part_x;     // DGRAD: fused layer-1 wgrad partials (see gemm_core.h)
-    float *part;
-    int part_nk, part_ldx;
-    int *part_cnt;           // ... arrival counters, one per column tile (zero between launches)
-    long long part_adam_off; // ... the layer-1 block array (w1y_index(k, j); the bias is input column part_nk - 1) in the flat buffers
     // wgrad epilogue (optimizer): offsets into the flat parameter-shaped buffers
     long long adam_off;      // J4: the W2 image;  RM: element (0, 0)
     long long bias_off;      // J4: b2
@@ -796,11 +791,9 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ float s_q[8][32];
     __shared__ float s_g[32];
-    __shared__ float s_px[32][13];
     __shared__ float s_wa[4][32];
     __shared__ __attribute__((aligned(16))) float s_gw[512];
     __shared__ __attribute__((aligned(16))) float s_w8[512 * 8];   // agen: the policy's head kernels, [k][Wmu 0..3 | Wls 0..3]
-    __shared__ int s_last;
     int t, ji;
 #ifdef DDRL_STAMPS
     unsigned long long *const st_ = jobs.st;
@@ -824,7 +817,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
     // ONE round trip to the kernarg segment: the hot line of the job record into SGPRs + one touch per other line of the record and
     // of the launch header (so that every later field load hits the scalar cache), one wait
     typedef int v16i __attribute__((ext_vector_type(16)));
-    static_assert(sizeof(DGJob) == 6 * 64 && offsetof(DGJob, M) == 64, "DGJob: hot line = the first 64 bytes, at most 6 lines");
+    static_assert(sizeof(DGJob) == 5 * 64 && offsetof(DGJob, M) == 64, "DGJob: hot line = the first 64 bytes, 5 lines in all");
     static_assert(offsetof(DGJobs, job) == 6 * 64, "DGJobs: header of 6 lines, records 64-byte aligned");
     v16i hot;
     int kl;
@@ -836,24 +829,23 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
         const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
         const int jboff = __builtin_amdgcn_readfirstlane(JOBS_OFF + (int)offsetof(DGJobs, job) + ji * (int)sizeof(DGJob));  // (wave-uniform: an SGPR address)
         const void *hdp = ka + JOBS_OFF, *jbp = ka + jboff;
-        int k1, k2, k3, k4, k5, k6, k7, k8, k9, k10, k11;
-        asm volatile("s_load_dwordx16 %0, %12, 0x0\n\t"
-                     "s_load_dword %1, %12, 0x40\n\t"
-                     "s_load_dword %2, %12, 0x80\n\t"
-                     "s_load_dword %3, %12, 0xc0\n\t"
-                     "s_load_dword %4, %12, 0x100\n\t"
-                     "s_load_dword %5, %12, 0x140\n\t"
-                     "s_load_dword %6, %13, 0x0\n\t"
-                     "s_load_dword %7, %13, 0x40\n\t"
-                     "s_load_dword %8, %13, 0x80\n\t"
-                     "s_load_dword %9, %13, 0xc0\n\t"
-                     "s_load_dword %10, %13, 0x100\n\t"
-                     "s_load_dword %11, %13, 0x140\n\t"
+        int k1, k2, k3, k4, k5, k6, k7, k8, k9, k10;
+        asm volatile("s_load_dwordx16 %0, %11, 0x0\n\t"
+                     "s_load_dword %1, %11, 0x40\n\t"
+                     "s_load_dword %2, %11, 0x80\n\t"
+                     "s_load_dword %3, %11, 0xc0\n\t"
+                     "s_load_dword %4, %11, 0x100\n\t"
+                     "s_load_dword %5, %12, 0x0\n\t"
+                     "s_load_dword %6, %12, 0x40\n\t"
+                     "s_load_dword %7, %12, 0x80\n\t"
+                     "s_load_dword %8, %12, 0xc0\n\t"
+                     "s_load_dword %9, %12, 0x100\n\t"
+                     "s_load_dword %10, %12, 0x140\n\t"
                      "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(hot), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7), "=&s"(k8), "=&s"(k9), "=&s"(k10), "=&s"(k11)
+                     : "=&s"(hot), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7), "=&s"(k8), "=&s"(k9), "=&s"(k10)
                      : "s"(jbp), "s"(hdp)
                      : "memory");
-        kl = k1 | k2 | k3 | k4 | k5 | k6 | k7 | k8 | k9 | k10 | k11;
+        kl = k1 | k2 | k3 | k4 | k5 | k6 | k7 | k8 | k9 | k10;
     }
     // (the pointers are rebuilt from SGPR halves: the cast goes through the GLOBAL address space, or every load through them
     // would be a flat_load — counted out of order, the compiler then waits for vmcnt(0) in front of every MFMA group)
@@ -1114,8 +1106,8 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
     // per CU at 131 VGPRs (59.5 us per update), and capping the kernel at 128 VGPRs spills (55.7 us) against 52.5 us.)
     const bool is_dgrad = type == DG_DGRAD_Q || type == DG_DGRAD;
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-    float wa_v = 0.f, px_v[2] = {0.f, 0.f};  // staged into LDS after the K loop
-    const bool has_da = is_dgrad && jb.da_part, has_part = type == DG_DGRAD && jb.part;  // block-uniform
+    float wa_v = 0.f;  // staged into LDS after the K loop
+    const bool has_da = is_dgrad && jb.da_part;  // block-uniform
     const bool rm_like = type == DG_WGRAD_RM || type == DG_WGRAD_W1Y;  // element-addressed gradient: row-major, or the layer-1 block layout
     const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || rm_like) && jb.adam_off >= 0;
     float al_pi = 0.f, al_q = 0.f;
@@ -1127,10 +1119,6 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
     bool okv[4];
     long long j_idx = 0, b_idx = 0;
     bool j_ok = false, b_ok = false;
-    // DGRAD with fused layer-1 partials: the optimizer state of this column tile's layer-1 parameters (two elements per thread)
-    long long off2[2] = {0, 0}, e2[2] = {0, 0};
-    bool ok2[2] = {false, false};
-    float am2[2] = {0.f, 0.f}, av2[2] = {0.f, 0.f}, ap2[2] = {0.f, 0.f}, at2[2] = {0.f, 0.f};
     auto epilogue_operands = [&]() {
         if (is_dgrad) mk = *reinterpret_cast<const float4 *>(jb.mask + ((long long)(m0 / 4 + cg) * jb.ldmask + n0 + r) * 4);  // mapping C: (col r, row group cg)
         if (has_da) {
@@ -1138,28 +1126,6 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
             const bool ok = c < jb.nact && col < jb.N;
             const float v = jb.wa[ok ? w1y_index(jb.wa_d0 + c, col) : 0];
             wa_v = ok ? v : 0.f;
-        }
-        if (has_part) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + 256 * u;  // 32 * 12 = 384 slots
-                const int rr = idx / 12, k = idx - rr * 12;
-                const bool ok = idx < 32 * 12 && k < jb.part_nk;
-                const float v = jb.part_x[ok ? (long long)(m0 + rr) * jb.part_ldx + k : 0];
-                px_v[u] = ok ? v : 0.f;
-            }
-        }
-        if (has_part && jobs.ad.on && jb.part_cnt != nullptr) {
-            // requested from inside the K loop: by the hand-off (whose drain waits for vmcnt(0)) they have long arrived, and the row tile
-            // that turns out to be last has them without a round trip of its own
-#pragma unroll
-            for (int u2 = 0; u2 < 2; ++u2) {
-                const int idx = tid + 256 * u2, k = idx >> 5, col = idx & 31;
-                ok2[u2] = idx < jb.part_nk * 32 && n0 + col < jb.N;
-                e2[u2] = ok2[u2] ? (long long)k * jb.N + n0 + col : 0;
-                off2[u2] = jb.part_adam_off + (ok2[u2] ? w1y_index(k, n0 + col) : 0);
-                am2[u2] = jobs.ad.m[off2[u2]]; av2[u2] = jobs.ad.v[off2[u2]]; ap2[u2] = jobs.ad.p[off2[u2]]; at2[u2] = jobs.ad.t[off2[u2]];
-            }
         }
         if (jobs.ad.on) {
             const float b1p_pi = jobs.ad.opt->b1p_pi, b2p_pi = jobs.ad.opt->b2p_pi, b1p_q = jobs.ad.opt->b1p_q, b2p_q = jobs.ad.opt->b2p_q;
@@ -1312,13 +1278,6 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
     // ---- split-K combine.  D layout: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
     DST(kid, 3);
     if (has_da && tid < 128) s_wa[tid >> 5][tid & 31] = wa_v;
-    if (has_part) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < 32 * 12) s_px[idx / 12][idx % 12] = px_v[u];
-        }
-    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[w][(q & 3) + 8 * (q >> 2) + 4 * h][l31] = acc[q];
     __syncthreads();
@@ -1334,81 +1293,17 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
         }
         const bool colok = n0 + r < jb.N;
         if (jb.C && colok) st_dg(jb.C + ((long long)(m0 / 4 + cg) * jb.ldc + n0 + r) * 4, make_float4(o4[0], o4[1], o4[2], o4[3]));
-        if (has_da || has_part) {  // block-uniform
+        if (has_da) {  // block-uniform: dQ/da partial of this column tile (rows x action dims)
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[0][4 * cg + i][r] = colok ? o4[i] : 0.f;
             __syncthreads();
-            if (has_da) {  // dQ/da partial of this column tile: rows x action dims
-                const int c = tid >> 5;
-                if (c < 4) {
-                    float s = 0.f;
+            const int c = tid >> 5;
+            if (c < 4) {
+                float s = 0.f;
 #pragma unroll
-                    for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wa[c][col], s);
-                    jb.da_part[((long long)nt * Bn + m0 + r) * 4 + c] = s;
-                }
-            } else {
-                // Layer-1 wgrad of the same network from this tile's rows, as a per-row-tile partial.  With the optimizer
-                // in this launch the LAST of the row tiles of a column tile to arrive sums the partials in tile order and
-                // steps those parameters (no spinning: the arrival order only decides who does the work, not the result).
-                // Hand-off per MI355X guide "Valid forms": every partial leaves as a write-through (sc1) store, each storing
-                // wave drains, the workgroup's barrier, ONE agent-scope add; the workgroup whose add returned last reads
-                // the partials with sc1 loads behind a barrier that its adding wave joined.
-                const bool la = jobs.ad.on && jb.part_cnt != nullptr;  // block-uniform
-                for (int idx = tid; idx < jb.part_nk * 32; idx += 256) {
-                    const int k = idx >> 5, col = idx & 31;
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int rr = 0; rr < 32; ++rr) sacc = fmaf(s_px[rr][k], red[0][rr][col], sacc);
-                    if (n0 + col < jb.N) {
-                        float *dst = jb.part + ((long long)mt * jb.part_nk + k) * jb.N + n0 + col;
-                        if (la) __hip_atomic_store(dst, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else *dst = sacc;
-                    }
-                }
-                if (la) {
-                    // (the optimizer state of this column tile's layer-1 parameters was requested from inside the K loop: epilogue_operands)
-                    const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) s_last = __hip_atomic_fetch_add(jb.part_cnt + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __syncthreads();
-                    if (s_last == tiles_m - 1) {
-                        float g2[2] = {0.f, 0.f};
-                        for (int q0 = 0; q0 < tiles_m; q0 += 8) {  // 8 partials per element and round trip, summed in tile order (as k_adam_polyak)
-                            float u[2][8];
-#pragma unroll
-                            for (int u2 = 0; u2 < 2; ++u2)
-#pragma unroll
-                                for (int q = 0; q < 8; ++q)
-                                    u[u2][q] = __hip_atomic_load(jb.part + (long long)(q0 + q < tiles_m ? q0 + q : 0) * jb.part_nk * jb.N + e2[u2], __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                            for (int u2 = 0; u2 < 2; ++u2)
-#pragma unroll
-                                for (int q = 0; q < 8; ++q)
-                                    if (q0 + q < tiles_m) g2[u2] += u[u2][q];
-                        }
-#pragma unroll
-                        for (int u2 = 0; u2 < 2; ++u2) {
-                            if (ok2[u2]) {
-                                adam1(g2[u2], am2[u2], av2[u2], ap2[u2], at2[u2], omb1, omb2, al_pi, jobs.ad.eps, jobs.ad.pk, jobs.ad.pk1);
-                                jobs.ad.g[off2[u2]] = g2[u2];
-                                jobs.ad.m[off2[u2]] = am2[u2]; jobs.ad.v[off2[u2]] = av2[u2]; jobs.ad.p[off2[u2]] = ap2[u2]; jobs.ad.t[off2[u2]] = at2[u2];
-                            }
-                        }
-                        if (tid == 0) {
-                            jb.part_cnt[nt] = 0;  // for the next launch
-                            if (nt == 0) {        // optimizer bookkeeping of the whole step (running beta powers, step counts, noise counter)
-                                OptState nx = *jobs.ad.opt;
-                                nx.b1p_pi *= jobs.ad.b1; nx.b2p_pi *= jobs.ad.b2; nx.b1p_q *= jobs.ad.b1; nx.b2p_q *= jobs.ad.b2;
-                                nx.t_pi += 1; nx.t_q += 1;
-                                nx.noise_ctr += jobs.ad.noise_adv;
-                                *jobs.ad.opt_next = nx;
-                            }
-                        }
-                    }
-                }
+                for (int col = 0; col < 32; ++col) s = fmaf(red[0][r][col], s_wa[c][col], s);
+                jb.da_part[((long long)nt * Bn + m0 + r) * 4 + c] = s;
             }
         }
         DST(kid, 5); DRT(kid, 15);
