@@ -1110,6 +1110,7 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
     const bool has_da = is_dgrad && jb.da_part;  // block-uniform
     const bool rm_like = type == DG_WGRAD_RM || type == DG_WGRAD_W1Y;  // element-addressed gradient: row-major, or the layer-1 block layout
     const bool do_adam = jobs.ad.on && (type == DG_WGRAD_J4 || rm_like) && jb.adam_off >= 0;
+    const bool narrow = rm_like && hot_N <= 8;   // block-uniform
     float al_pi = 0.f, al_q = 0.f;
     // optimizer state of this tile: J4 — thread (col r, row group cg) owns rows 4cg..4cg+3 of column r as one float4;
     // RM — thread owns elements (o >> 5, o & 31), o = tid + 256 q
@@ -1145,10 +1146,13 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
                 bm = jobs.ad.m[bc]; bv = jobs.ad.v[bc]; bp = jobs.ad.p[bc]; bt = jobs.ad.t[bc];
             }
         } else if (rm_like) {
+            // narrow outputs (the head kernels: N = act or 1 column): 32 rows x 8 columns = one element per thread instead of four —
+            // a quarter of the optimizer-state loads queued in front of the operand groups that follow them
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (narrow && q > 0) { okv[q] = false; continue; }   // block-uniform
                 const int o = tid + 256 * q;
-                const int gi = m0 + (o >> 5), gj = n0 + (o & 31);
+                const int gi = m0 + (narrow ? (o >> 3) : (o >> 5)), gj = n0 + (narrow ? (o & 7) : (o & 31));
                 okv[q] = gi < jb.M && gj < jb.N;
                 if (do_adam) {
                     const long long idx = !okv[q] ? jb.adam_off : jb.adam_off + (type == DG_WGRAD_W1Y ? w1y_index(gi, gj) : (long long)gi * jb.ldc + gj);
@@ -1352,8 +1356,9 @@ __global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, i
         const float omb1 = 1.0f - jobs.ad.b1, omb2 = 1.0f - jobs.ad.b2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (narrow && q > 0) continue;   // block-uniform
             const int o = tid + 256 * q;
-            const int row = o >> 5, col = o & 31;
+            const int row = narrow ? (o >> 3) : (o >> 5), col = narrow ? (o & 7) : (o & 31);
             const float gv = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
             if (okv[q]) {
                 const long long idx = jb.adam_off + (type == DG_WGRAD_W1Y ? w1y_index(m0 + row, n0 + col) : (long long)(m0 + row) * jb.ldc + n0 + col);
