@@ -23,9 +23,9 @@ def rows(name):
 
 
 fetch, write, sq = rows("pmc_FETCH_SIZE.txt"), rows("pmc_WRITE_SIZE.txt"), rows("pmc_sq.txt")
-# the update's five launches, identified by kernel + grid (config 2: 400 / 240 forward tiles; 312 / 361 / 280 backward tiles)
+# the update's five launches, identified by kernel + grid (config 2: 400 / 240 forward tiles; 312 / 464 / 190 backward tiles)
 want = [("k_dfwd<0>", "k_dfwd<0,", 400 * 256), ("k_dfwd<1>", "k_dfwd<1,", 240 * 256), ("k_dg bq", "k_dg<10>", 312 * 256),
-        ("k_dg mid", "k_dg<10>", 361 * 256), ("k_dg pi", "k_dg<10>", 280 * 256)]
+        ("k_dg mid", "k_dg<10>", 464 * 256), ("k_dg pi", "k_dg<10>", 190 * 256)]
 per, lines = {}, []
 for label, kname, grid in want:
     key = next((k for k in fetch if k[0].startswith(kname.rstrip(",")) and k[1] == grid), None)
@@ -52,8 +52,8 @@ json.dump({"source": srcnote,
            "what": "L2 <-> fabric traffic (Infinity Cache + HBM behind it), mean per dispatch",
            "per_kernel": per, "bytes_per_launch_mean": mean,
            "algorithmic_bytes_per_launch": "operands read once + outputs written once, per launch: k_dfwd<0> ~6.0 MB, k_dfwd<1> ~3.5 MB, k_dg bq ~6.5 MB, "
-                                           "k_dg mid ~11 MB (two Q layer-2 optimizer tiles: m, v, main, target read + written = 9.6 MB), k_dg pi ~7.6 MB: "
-                                           "mean ~6.9 MB (DESIGN.md section 4)"},
+                                           "k_dg mid ~12 MB (the two Q layer-2 optimizer jobs: m, v, main, target read + written = 9.6 MB), k_dg pi ~7 MB (the policy's: 4.8 MB): "
+                                           "mean ~7 MB (DESIGN.md section 4)"},
           open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 with open(os.path.join(ROOT, "profiles", "%s_pmc_summary.txt" % tag), "w") as fo:
     fo.write("PMC passes (separate rocprofv3 runs, eager launches, 40 dispatches per kernel): %s\n" % srcnote)
