@@ -297,9 +297,10 @@ int ddrl_sac1_fill_noise(ddrl_sac1_t *h, uint32_t seed, void *stream);
  * ddrl_sac1_step and are idempotent.  Stage ids:
  *   direct-operand path (ddrl_sac1_is_fused == 1), the five launches of one update in launch order:
  *     2 k_dfwd<0> (evaluations 0-4: layer 1 + layer 2 + head partials)   5 k_dfwd<1> (evaluations 5-7; + the next
- *     batch's sampler when one is armed)   7 k_dg "bq" (Q heads / losses / the three Q dgrads)   8 k_dg "mid" (policy-head
- *     backward + Q layer-2 / head wgrads)   9 k_dg "pi" (policy dgrad + policy wgrads + Q layer-1 wgrads); 8 and 9 run with
- *     their optimizer epilogues exactly as the last step left them armed; 1, 3, 4, 6, 10 are no-ops there;
+ *     batch's sampler when one is armed)   7 k_dg "bq" (Q heads / losses / the three Q dgrads)   8 k_dg "mid" (policy dgrad with
+ *     its A operand generated in the tile + policy-head backward tiles + Q layer-2 / head wgrads)   9 k_dg "pi" (policy wgrads of
+ *     all three layers + Q layer-1 wgrads + loss means / optimizer bookkeeping); 8 and 9 run with their optimizer epilogues exactly
+ *     as the last step left them armed; 1, 3, 4, 6, 10 are no-ops there;
  *   generic path: 1 layer 1 (8 nets; + noise) 2 gemm fwd (A: 5 nets) 3 heads (A) + 2nd-phase layer 1 5 gemm fwd (B: 3
  *     nets) 6 heads (B) + losses 7 gemm bwd (Q: 3 dgrad + 4 wgrad) 8 policy-head bwd 9 gemm bwd (pi: 1 dgrad + 5 wgrad)
  *     10 pi layer-1 wgrad.
