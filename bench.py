@@ -234,6 +234,21 @@ def stage_measurements(args, opt, rb, roll, d):
                            "flop_per_env_step": pf, "achieved_TFLOPs": n_env * pf / t / 1e12,
                            "frac_of_f32_mfma_peak": n_env * pf / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
                            "what": "policy forward + env.step + store of %d envs per launch sequence (no learner)" % n_env}
+    try:   # config 4's rollout ranks step 8192 envs: both launches of a vector step are latency chains at 4096 (one workgroup round), so the
+        # rate grows with the envs per step (profiles/r03_rollout_sweep.txt)
+        from distributed_drl_amd.agent import HyperParameters
+        from distributed_drl_amd.workers import RolloutDevice
+        o8 = HyperParameters(num_workers=1)
+        o8.__dict__.update(opt.__dict__)
+        o8.num_envs = 8192
+        rb8 = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 1 << 20, seed=1)
+        roll8 = RolloutDevice(None, rb8, o8, worker_index=1)
+        t8 = timed(lambda: roll8.step(20), 20) / 20.0
+        out["rollout_only_8192_envs"] = {"env_steps_per_s": 8192 / t8, "us_per_vector_step": t8 * 1e6, "num_envs": 8192,
+                                         "achieved_TFLOPs": 8192 * pf / t8 / 1e12, "frac_of_f32_mfma_peak": 8192 * pf / t8 / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        del roll8, rb8
+    except Exception as e:  # noqa
+        out["rollout_only_8192_envs"] = {"error": repr(e)[:200]}
     o, o2 = torch.randn(n_env, 8, device="cuda"), torch.randn(n_env, 8, device="cuda")
     a, r, dn = torch.rand(n_env, 2, device="cuda"), torch.randn(n_env, device="cuda"), torch.zeros(n_env, device="cuda")
     t = timed(lambda: rb.store_batch(o, a, r, o2, dn), 200)

@@ -1989,10 +1989,17 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
     const int D1 = c.obs_dim + 1, ns = D1 <= 8 ? 4 : 4 + (D1 - 8 + 1) / 2;
     const unsigned grid = (unsigned)(n / 32) * A.ngroups;
     hipStream_t s = ddrl::as_stream(stream);
-    if (ns == 4) k_actor_fwd<4><<<grid, 256, 0, s>>>(A);
-    else if (ns == 5) k_actor_fwd<5><<<grid, 256, 0, s>>>(A);
-    else if (ns == 6) k_actor_fwd<6><<<grid, 256, 0, s>>>(A);
-    else k_actor_fwd<7><<<grid, 256, 0, s>>>(A);
+    if (grid > 256) {   // more than one workgroup per CU: the two-per-CU register budget
+        if (ns == 4) k_actor_fwd<4, 2><<<grid, 256, 0, s>>>(A);
+        else if (ns == 5) k_actor_fwd<5, 2><<<grid, 256, 0, s>>>(A);
+        else if (ns == 6) k_actor_fwd<6, 2><<<grid, 256, 0, s>>>(A);
+        else k_actor_fwd<7, 2><<<grid, 256, 0, s>>>(A);
+    } else {
+        if (ns == 4) k_actor_fwd<4, 1><<<grid, 256, 0, s>>>(A);
+        else if (ns == 5) k_actor_fwd<5, 1><<<grid, 256, 0, s>>>(A);
+        else if (ns == 6) k_actor_fwd<6, 1><<<grid, 256, 0, s>>>(A);
+        else k_actor_fwd<7, 1><<<grid, 256, 0, s>>>(A);
+    }
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }

@@ -545,8 +545,12 @@ struct ActFwdArgs {
 #else
 #define AST(i) do { } while (0)
 #endif
-template <int NS>
-__global__ void __launch_bounds__(256) k_actor_fwd(ActFwdArgs a) {
+// OCC = workgroups per CU the register budget is cut for: 1 -> 268 registers, one wave per SIMD: the fastest single round (<= 256
+// workgroups: 4096 rows, 16.4 us); 2 -> 256 registers with 64 spilled to scratch, two workgroups per CU: +1.8 us on a single round, but
+// 8192 rows (config 4's rollout ranks: 512 workgroups) take one round instead of two (rollout-only 195 -> 208 M env-steps/s, 16 384
+// rows 227 -> 253 M).
+template <int NS, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     // rows of 36 floats: 16-byte aligned (b128 LDS reads) and conflict-free for 16 lanes reading 4 words each
     __shared__ __attribute__((aligned(16))) float red[2][4][32][36];
     __shared__ __attribute__((aligned(16))) float red2[2][32][36];
