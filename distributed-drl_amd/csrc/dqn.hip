@@ -1,12 +1,15 @@
 // Discrete-action learners on the shared GEMM core: Double-DQN (algos/dqn) and soft-Q (algos/sqn).
 #include "gemm_core.h"
+#include "wide_l1.h"
 
 // ==========================================================================================
 // Double-DQN learner (algos/dqn/actor_learner.py:19-107 on algos/dqn/core.py:40-50):
 // q = mlp(obs -> h1 -> h2 -> n_actions), q_x2 = the same variables at obs2, q_next = target(obs2);
 // q_target = q_next[argmax q_x2]; q_loss = 0.5 mean((r + gamma (1-d) q_target - q[a])^2);
 // one Adam over main/q1, polyak over all.  Every layer (also layer 1: obs_dim is arbitrary here) is a
-// job of the generic MFMA GEMM kernel; 8 launches per update.
+// job of the generic MFMA GEMM kernel; 8 launches per update.  Wide observations (obs_dim >= 1024, config 5's 28 224) take
+// layer 1 through the tiled kernels of wide_l1.h instead (forward split over K + reduce; wgrad), reading the caller's
+// observation rows in place.
 // variant DDRL_SQN = the soft-Q learner of algos/sqn/actor_learner.py:19-78 on algos/sqn/core.py:30-79:
 // twin networks main/q1, main/q2; evaluations q1(x), q1(x2) (its softmax policy's sum p log p at x2),
 // q2(x) and the targets q1_(x2), q2_(x2); v_backup = min(max q1_, max q2_) - alpha * sum p log p;
@@ -138,6 +141,10 @@ struct ddrl_dqn {
     DqnRows rows;
     SqnRows srows;
     AdamArgs ad;
+    bool wide;            // layer 1 on wide_l1.h
+    WideArgs wf, ww[2];   // forward (all evaluations), wgrad per network
+    int wf_x2[WD_MAXEV];  // which input an evaluation reads: 0 obs1, 1 obs2
+    float *wpart, *wconsts;
 };
 
 extern "C" {
@@ -195,6 +202,12 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     ALLOC(x1, (size_t)B * h->ldx); ALLOC(x2, (size_t)B * h->ldx); ALLOC(acts, B); ALLOC(rew, B); ALLOC(done, B);
     ALLOC(H1, (size_t)5 * B * h->ldh1); ALLOC(H2, (size_t)5 * B * h->ldh2); ALLOC(Q, (size_t)5 * B * h->ldq); ALLOC(dQ, (size_t)2 * B * h->ldq);
     ALLOC(dZ2, (size_t)2 * B * h2); ALLOC(dZ1, (size_t)2 * B * h1); ALLOC(loss, 4); ALLOC(qsel, B);
+    h->wide = wide_applies(o, h1);
+    const int nev_all = cfg->variant == DDRL_SQN ? 5 : 3;
+    if (h->wide) {
+        wide_plan(h->wf, nev_all, B, h1, o, true, 4, 512);
+        ALLOC(wpart, wide_part_floats(h->wf)); ALLOC(wconsts, 8);
+    }
 #undef ALLOC
     const size_t opt_off = reserve((2 * sizeof(OptState) + 3) / 4);
     const size_t segs_off = reserve((h->segs.size() * sizeof(Seg) + 3) / 4);
@@ -217,6 +230,11 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         DDRL_HIP_CHECK(hipMemcpy(h->opt, &os, sizeof(os), hipMemcpyHostToDevice));
         h->opt_cur = 0;
     }
+    if (h->wide) {
+        const float c8[8] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        DDRL_HIP_CHECK(hipMemcpy(h->wconsts, c8, sizeof(c8), hipMemcpyHostToDevice));
+        DDRL_HIP_CHECK(wide_prepare());
+    }
     k_fill_col<<<(B + 255) / 256, 256>>>(h->x1, B, h->ldx, o, 1.0f);
     k_fill_col<<<(B + 255) / 256, 256>>>(h->x2, B, h->ldx, o, 1.0f);
     k_fill_col<<<(5 * B + 255) / 256, 256>>>(h->H1, 5ll * B, h->ldh1, h1, 1.0f);
@@ -233,6 +251,10 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     const int net[5] = {0, 0, sqn ? 1 : 0, 0, 1};
     for (int ev = 0; ev < nev; ++ev) {
         const int n = net[ev];
+        if (h->wide) {
+            h->wf.ev[ev] = WideEval{xin[ev], par[ev] + h->W1[n], par[ev] + h->b1[n], h->H1 + ev * BH1, h->ldx};
+            h->wf_x2[ev] = xin[ev] == h->x2;
+        }
         gemm_add(h->g_f1, gemm_fwd(xin[ev], h->ldx, par[ev] + h->W1[n], par[ev] + h->b1[n], h->H1 + ev * BH1, h->ldh1, B, o, h1));
         gemm_add(h->g_f2, gemm_fwd(h->H1 + ev * BH1, h->ldh1, par[ev] + h->W2[n], par[ev] + h->b2[n], h->H2 + ev * BH2, h->ldh2, B, h1, h2));
         GemmJob j = gemm_fwd(h->H2 + ev * BH2, h->ldh2, par[ev] + h->W3[n], par[ev] + h->b3[n], h->Q + ev * BQ, h->ldq, B, h2, A);
@@ -256,7 +278,13 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         gemm_add(h->g_b2, gemm_dgrad(dZ2, Pm + h->W2[n], h->H1 + ev * BH1, h->ldh1, dZ1, B, h1, h2));
         gemm_add(h->g_b2, gemm_wgrad(h->H1 + ev * BH1, h->ldh1, h1, dZ2, h2, h2, G + h->W2[n], h2, B));
         gemm_add(h->g_b1, gemm_wgrad(h->x1, h->ldx, o, dZ1, h1, h1, G + h->W1[n], h1, B));
+        if (h->wide) {   // [dW1 ; db1] = [x | 1]^T dZ1: the bias row follows the kernel in the flat gradient
+            wide_plan(h->ww[n], 1, o + 1, h1, B, false, 4, 0);
+            h->ww[n].ev[0] = WideEval{h->x1, dZ1, nullptr, G + h->W1[n], h->ldx};
+            h->ww[n].a_rows = o; h->ww[n].consts = h->wconsts;
+        }
     }
+    if (h->wide) { h->wf.part = h->wpart; h->wf.consts = h->wconsts; h->wf.a_rows = B; h->wf.ldo = h->ldh1; }
     h->srows = SqnRows{h->Q, h->acts, h->rew, h->done, h->dQ, h->loss, B, A, h->ldq, (float)cfg->gamma, (float)cfg->alpha};
     h->rows = DqnRows{h->Q, h->acts, h->rew, h->done, h->dQ, h->loss, h->qsel, B, A, h->ldq, (float)cfg->gamma};
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, h->total_int, 0, 0,
@@ -292,16 +320,37 @@ int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const
     ddrl::DeviceGuard g(h->device);
     hipStream_t s = ddrl::as_stream(stream);
     const int B = h->cfg.batch, o = h->cfg.obs_dim;
-    const int n = B * o > B ? B * o : B;
-    k_dqn_stage<<<(n + 255) / 256, 256, 0, s>>>(obs1_d, obs2_d, acts_d, rews_d, done_d, h->x1, h->x2, h->acts, h->rew, h->done, B, o, h->ldx);
-    launch_gemm(h->g_f1, s);
+    // wide layer 1 reads the caller's observation rows in place (16-byte aligned rows: obs_dim % 4 == 0 there); otherwise
+    // they are staged into the padded images with the ones column
+    const bool in_place = h->wide && al16(obs1_d) && al16(obs2_d);
+    const int n = in_place ? B : (B * o > B ? B * o : B);
+    k_dqn_stage<<<(n + 255) / 256, 256, 0, s>>>(obs1_d, obs2_d, acts_d, rews_d, done_d, h->x1, h->x2, h->acts, h->rew, h->done, B, in_place ? 0 : o, h->ldx);
+    if (h->wide) {
+        WideArgs f = h->wf;
+        for (int ev = 0; ev < f.nev; ++ev) {
+            f.ev[ev].A = in_place ? (h->wf_x2[ev] ? obs2_d : obs1_d) : (h->wf_x2[ev] ? h->x2 : h->x1);
+            f.ev[ev].lda = in_place ? o : h->ldx;
+        }
+        launch_wide_fwd(f, s);
+    } else {
+        launch_gemm(h->g_f1, s);
+    }
     launch_gemm(h->g_f2, s);
     launch_gemm(h->g_f3, s);
     if (h->cfg.variant == DDRL_SQN) k_sqn_rows<<<1, 256, 0, s>>>(h->srows);
     else k_dqn_rows<<<1, 256, 0, s>>>(h->rows);
     launch_gemm(h->g_b3, s);
     launch_gemm(h->g_b2, s);
-    launch_gemm(h->g_b1, s);
+    if (h->wide) {
+        for (int nn = 0; nn < h->nnet; ++nn) {
+            WideArgs g = h->ww[nn];
+            g.ev[0].A = in_place ? obs1_d : h->x1;
+            g.ev[0].lda = in_place ? o : h->ldx;
+            launch_wide_wgrad(g, s);
+        }
+    } else {
+        launch_gemm(h->g_b1, s);
+    }
     {
         const long long blocks = (h->total_int / 4 + 255) / 256;
         h->ad.adam_blocks = (int)blocks;
@@ -325,7 +374,8 @@ int ddrl_dqn_q(ddrl_dqn_t *h, const float *obs_d, int64_t n, float *q_d, void *s
     const int o = h->cfg.obs_dim;
     DDRL_HIP_CHECK(hipMemcpy2DAsync(h->x1, (size_t)h->ldx * sizeof(float), obs_d, (size_t)o * sizeof(float), (size_t)o * sizeof(float), (size_t)n,
                                     hipMemcpyDeviceToDevice, s));
-    launch_gemm(h->g_f1, s);   // all three evaluations run (rows beyond n hold the previous batch): simple, off the hot path
+    if (h->wide) launch_wide_fwd(h->wf, s);   // (evaluations read the staged images here)
+    else launch_gemm(h->g_f1, s);   // all three evaluations run (rows beyond n hold the previous batch): simple, off the hot path
     launch_gemm(h->g_f2, s);
     launch_gemm(h->g_f3, s);
     DDRL_LAUNCH_CHECK();

@@ -1,0 +1,305 @@
+// Layer 1 of the discrete-action learners when the observation is WIDE (config 5: flat 84x84x4 = 28 224 floats,
+// algos/dqn/train.py:43-52 feeding algos/dqn/core.py:40-50's first dense layer).  The generic k_gemm (one 32x32 tile per
+// workgroup: 8 FLOP per operand byte) was built for the SAC shapes; at K = 28 224 it pulls 1.2 GB through the fabric for
+// 206 MB of operands and runs at a third of the fp32 MFMA rate (profiles/r03_ddqn_cfg5_summary.txt).  One tiled kernel
+// replaces it for both GEMMs of the layer:
+//
+//   k_wide<true>   forward, split K: partial pre-activations P[ev][s] = X[ev][:, Ks] * W1[ev][Ks, :]
+//   k_wide_reduce  H1[ev] = relu(sum_s P[ev][s] + b1) in split order (deterministic)
+//   k_wide<false>  [dW1 ; db1] = [X | 1]^T dZ1, the whole batch as K
+//
+// One workgroup = 128 output rows x NU <= 4 column units of 32 (32 FLOP per operand byte): 4 waves x (32 rows x NU units),
+// both operands staged through LDS 32 k at a time (double-buffered 2 x 32 KB, so two workgroups share a CU; whole 128-byte
+// lines per row and stage); per 8-deep k group a wave reads 1 + 4 NU operands and issues 4 NU v_mfma_f32_32x32x2_f32.
+// hidden = 400 is 13 units: column tiles of 4, 3, 3, 3 units; a tile's number of K ranges is proportional to its units so
+// that every workgroup carries the same MFMA work, and the total is chosen so that all workgroups are resident at once.
+// Workgroups are dealt to the XCDs in contiguous runs of the order (evaluation, K range, row tile, column tile): the
+// tiles that read the same X rows / W1 rows at the same time share an L2.
+// Exact fp32 like the rest of the learner; the k order inside an 8-deep group differs from k_gemm's (lane half h takes
+// k = 8g + 4h + {0..3}), which only reorders the fp32 sums.
+#pragma once
+#include "gemm_core.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int WD_MAXEV = 5;
+
+struct WideEval {
+    const float *A;     // forward: X [M][lda] (k contiguous)     wgrad: X [K][lda] (output row i = input column i contiguous)
+    const float *B;     // forward: W1 [K][N]                      wgrad: dZ1 [K][N]
+    const float *bias;  // forward only
+    float *out;         // forward: H1 [M][ldo] (written by k_wide_reduce)   wgrad: G [(a_rows + 1)][N]
+    long long lda;
+};
+struct WideArgs {
+    WideEval ev[WD_MAXEV];
+    float *part;        // forward: [nev][Smax][Mp][Np]
+    const float *consts; // {1, 0, 0, 0, 0, 0, 0, 0}: sources of what lies outside the matrices
+    int nev, M, N, K;   // M: output rows (wgrad: a_rows + 1, the last one contracts the constant 1)
+    int a_rows;         // rows of A that exist in memory (forward: M; wgrad: obs_dim)
+    int m_tiles, rows, kb;  // rows per tile = 32 x waves of the kernel instance; kb = its k per stage
+    // column tiles come in two classes: cnt[0] tiles of nu[0] units, then cnt[1] tiles of nu[1] units; S[c] K ranges each
+    int nu[2], cnt[2], S[2], wg0[3];
+    int Smax, Mp, Np, ldo, total;
+#ifdef WD_STAMPS
+    long long *stamps;  // diagnostic builds (tools/wide_bench.hip): [workgroup][wave][8] accumulated phase cycles
+#endif
+};
+
+// 16 bytes per lane, global -> LDS without a register stop: lane l's bytes land at LDS byte address lds + 16 l (lds wave-uniform).
+// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin hipcc waits vmcnt(0) before the first ds_read that follows
+// (it cannot tell the two LDS buffers apart), which serialises the stage being loaded with the stage being computed.  The
+// compiler does not count these loads: the kernel waits for them by hand (wide_dma_wait) before the barrier that publishes them.
+// M0 (the LDS-DMA base) is compiler-reserved: saved, set and restored inside the one statement.
+__device__ __forceinline__ void glds16(const float *src, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void wide_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const float *)p;
+}
+
+template <bool FWD, int WV, int WD_KB>   // WD_KB: k per LDS stage (32; 16 halves the LDS image: four workgroups of 4 waves per CU)
+__global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
+    static_assert(WD_KB == 32 || !FWD, "the forward A image is cut for 128-byte rows");
+    constexpr int ROWS = 32 * WV, AOP = ROWS * WD_KB, WD_BOP = WD_KB * 128, NG = WD_KB / 8;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *sA = wsm;             // [2][AOP]  forward: [rows][8 float4 slots], chunk q of row r in slot q ^ ((r >> 1) & 7)   wgrad: [32 k][rows]
+    float *sB = wsm + 2 * AOP;   // [2][32 k][128 columns]
+    int L;
+    {   // contiguous run of the workgroup order per XCD (block b runs on XCD b % 8)
+        const int b = blockIdx.x, q = a.total >> 3, r = a.total & 7, x = b & 7;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int c = L >= a.wg0[1] ? 1 : 0;
+    L -= a.wg0[c];
+    const int NU = a.nu[c], S = a.S[c];
+    const int ct = L % a.cnt[c]; L /= a.cnt[c];
+    const int mt = L % a.m_tiles; L /= a.m_tiles;
+    const int s = L % S, e = L / S;
+    const WideEval E = a.ev[e];
+    const int unit0 = c ? a.cnt[0] * a.nu[0] + ct * NU : ct * NU;
+    const int m0 = mt * ROWS, n0 = unit0 * 32;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = (a.K + WD_KB - 1) / WD_KB;
+    const int st0 = (int)((long long)s * T / S), st1 = (int)((long long)(s + 1) * T / S);
+    // global -> LDS staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  One wave-instruction
+    // fills 1 KB of LDS in lane order from per-lane source addresses, so the images are cut into 1 KB pieces of 64 float4:
+    //   forward A   piece I = rows 8I..8I+7 x 8 slots; the lane that fills slot p of row r loads chunk p ^ ((r >> 1) & 7) (the
+    //               swizzle sits on the SOURCE address and on the read; the destination is linear)
+    //   wgrad A     piece I = 1 KB of the [32 k][rows] image (8 waves: k row I; 4 waves: k rows 2I, 2I + 1)
+    //   B           piece I = k rows 2I, 2I + 1 of the [32 k][128 columns] image
+    // What lies outside the matrices comes from a 16-byte block of zeros, the gradient's bias row from {1, 0, 0, 0}.
+    constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;   // pieces per wave and stage: one A piece per k group, B: WD_KB / (2 WV)
+    const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
+    const float *pa[APW], *pb[BPW];
+    int ak[APW], bk[BPW];   // k offset inside a stage of what this lane loads (forward A: of its chunk; else of its k row)
+    int amode = 1;          // wgrad: 1 data, 2 the bias row's constant, 0 beyond it
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int I = APW * w + i;
+        if (FWD) {
+            const int row = 8 * I + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
+            ak[i] = 4 * q;
+            pa[i] = m0 + row < a.a_rows ? E.A + (long long)(m0 + row) * E.lda + 4 * q : nullptr;
+        } else {
+            const int kk = WV == 8 ? I : 2 * I + (lane >> 5), i0 = m0 + 4 * (WV == 8 ? lane : lane & 31);
+            ak[i] = kk;
+            amode = i0 < a.a_rows ? 1 : i0 == a.a_rows ? 2 : 0;   // a_rows % 4 == 0: four input columns exist or not as a whole
+            pa[i] = E.A + (long long)kk * E.lda + (amode == 1 ? i0 : 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int kk = 2 * (BPW * w + j) + (lane >> 5), c4 = lane & 31;
+        bk[j] = kk;
+        pb[j] = (c4 < NU * 8 && n0 + 4 * c4 < a.N) ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;   // N % 4 == 0
+    }
+    // a stage's pieces, all issued at the top of the stage before (dealing them between that stage's MFMA groups instead measured
+    // the same: 359 vs 345 us at config 5 — the texture path takes ~1 k cycles per CU and stage either way)
+    auto issue = [&](int st, int buf) {
+        const int k = st * WD_KB;
+        const unsigned dA = lds_addr(sA + buf * AOP + 256 * APW * w), dB = lds_addr(sB + buf * WD_BOP + 256 * BPW * w);
+#pragma unroll
+        for (int g = 0; g < APW; ++g) {
+            const float *src;
+            if (FWD) src = (pa[g] && k + ak[g] < a.K) ? pa[g] + k : zero_blk;   // K % 4 == 0
+            else src = amode == 2 ? ones_blk : (amode == 1 && k + ak[g] < a.K) ? pa[g] + (long long)k * E.lda : zero_blk;
+            glds16(src, dA + 1024 * g);
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
+    };
+    floatx16 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const bool active = m0 + 32 * w < a.M;   // wave-uniform: this wave's 32 rows hold output
+    const int sw = (l31 >> 1) & 7;
+    auto compute = [&](const float *cA, const float *cB, auto nu_c) {
+        constexpr int NUC = decltype(nu_c)::value;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float av[4], bv[NUC][4];
+            if (FWD) {
+                const float4 t = *reinterpret_cast<const float4 *>(cA + (32 * w + l31) * WD_KB + (((2 * g + h) ^ sw) << 2));
+                av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = cA[(8 * g + 4 * h + j) * ROWS + 32 * w + l31];
+            }
+#pragma unroll
+            for (int u = 0; u < NUC; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * 128 + 32 * u + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < NUC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[u][j], acc[u], 0, 0, 0);
+        }
+    };
+    // the stage loop, one instance per NU (dispatching inside the loop made the compiler shuffle the accumulators between variants)
+    auto run = [&](auto nu_c) {
+        issue(st0, 0);
+        wide_dma_wait();
+        __syncthreads();
+#ifdef WD_STAMPS
+        long long ph[6] = {0, 0, 0, 0, 0, 0}, t_prev = (long long)__builtin_readcyclecounter();
+#define WD_PHN(i) do { const long long t_now = (long long)__builtin_readcyclecounter(); ph[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define WD_PHN(i) do { } while (0)
+#endif
+        for (int st = st0; st < st1; ++st) {
+            const int cur = (st - st0) & 1;
+            WD_PHN(0);
+            if (st + 1 < st1) issue(st + 1, cur ^ 1);   // that buffer's last reads ended before the previous barrier
+            WD_PHN(1);   // issue of the next stage's loads
+            if (active) compute(sA + cur * AOP, sB + cur * WD_BOP, nu_c);
+            WD_PHN(2);   // compute
+            wide_dma_wait();   // the next stage has landed (this wave's share; the barrier covers the others')
+            WD_PHN(3);
+            __syncthreads();
+            WD_PHN(4);   // barrier
+        }
+#ifdef WD_STAMPS
+        if (a.stamps && lane == 0) {
+            long long *o = a.stamps + ((long long)blockIdx.x * WV + w) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = ph[i];
+            o[6] = st1 - st0; o[7] = NU;
+        }
+#endif
+    };
+    if (st0 < st1) {
+        if (NU == 4) run(std::integral_constant<int, 4>{});
+        else if (NU == 3) run(std::integral_constant<int, 3>{});
+        else if (NU == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+    // D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h
+    if (FWD) {
+        float *P = a.part + (((long long)e * a.Smax + s) * a.Mp + m0 + 32 * w) * a.Np + n0 + l31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < NU)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) P[(long long)((r & 3) + 8 * (r >> 2) + 4 * h) * a.Np + 32 * u] = acc[u][r];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < NU) {
+                const int col = n0 + 32 * u + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < a.M && col < a.N) E.out[(long long)row * a.N + col] = acc[u][r];
+                }
+            }
+    }
+}
+
+// H1 = relu(sum of the column's partials + b1); one thread per four columns
+__global__ void __launch_bounds__(256) k_wide_reduce(WideArgs a) {
+    const int n4s = a.N >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)a.M * n4s;
+    if (i >= per * a.nev) return;
+    const int e = (int)(i / per);
+    const long long rc = i - e * per;
+    const int row = (int)(rc / n4s), c4 = (int)(rc - (long long)row * n4s) * 4;
+    const WideEval E = a.ev[e];
+    const int S = (c4 >> 5) < a.cnt[0] * a.nu[0] ? a.S[0] : a.S[1];
+    const float4 *P = reinterpret_cast<const float4 *>(a.part + (((long long)e * a.Smax) * a.Mp + row) * a.Np + c4);
+    const long long sstride = (long long)a.Mp * a.Np / 4;
+    float4 acc = P[0];
+    for (int s = 1; s < S; ++s) {
+        const float4 v = P[s * sstride];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 bz = *reinterpret_cast<const float4 *>(E.bias + c4);
+    acc.x = fmaxf(acc.x + bz.x, 0.f); acc.y = fmaxf(acc.y + bz.y, 0.f); acc.z = fmaxf(acc.z + bz.z, 0.f); acc.w = fmaxf(acc.w + bz.w, 0.f);
+    *reinterpret_cast<float4 *>(E.out + (long long)row * a.ldo + c4) = acc;
+}
+
+// the wide path takes layer 1 when the observation is wide enough for the split-K forward to fill the chip
+static bool wide_applies(int obs, int h1) { return obs >= 1024 && obs % 4 == 0 && h1 % 4 == 0; }
+
+// Tiling of an [M x N] output over K: column tiles in two classes, K ranges per class proportional to the class's units,
+// at most `slots` workgroups (forward: all resident, 2 per CU; split = false: one K range, any number of workgroups).
+static void wide_plan(WideArgs &a, int nev, int M, int N, int K, bool split, int waves, int slots, int kb = 32, int max_nu = 4) {
+    a.nev = nev; a.M = M; a.N = N; a.K = K; a.rows = 32 * waves; a.kb = kb;
+    const int units = (N + 31) / 32, ntiles = (units + max_nu - 1) / max_nu, base = units / ntiles, rem = units % ntiles;
+    a.nu[0] = base + 1; a.cnt[0] = rem; a.nu[1] = base; a.cnt[1] = ntiles - rem;
+    a.m_tiles = (M + a.rows - 1) / a.rows;
+    a.Mp = a.m_tiles * a.rows; a.Np = units * 32;
+    const int T = (K + kb - 1) / kb;
+    for (int c = 0; c < 2; ++c) {
+        int S = 1;
+        if (split) {
+            S = (int)((long long)a.nu[c] * slots / ((long long)nev * a.m_tiles * units));
+            if (S < 1) S = 1;
+            if (S > T) S = T;
+        }
+        a.S[c] = a.cnt[c] ? S : 1;
+    }
+    a.Smax = a.S[0] > a.S[1] ? a.S[0] : a.S[1];
+    a.wg0[0] = 0;
+    a.wg0[1] = nev * a.m_tiles * a.S[0] * a.cnt[0];
+    a.wg0[2] = a.wg0[1] + nev * a.m_tiles * a.S[1] * a.cnt[1];
+    a.total = a.wg0[2];
+}
+static size_t wide_part_floats(const WideArgs &a) { return (size_t)a.nev * a.Smax * a.Mp * a.Np; }
+template <bool FWD, int WV, int KB>
+static hipError_t wide_launch(const WideArgs &a, hipStream_t s, bool prepare_only) {
+    constexpr size_t lds = (size_t)2 * (32 * WV * KB + KB * 128) * sizeof(float);   // 4 waves: 64 KB (KB 32) or 32 KB (KB 16), 8 waves: 96 KB
+    if (prepare_only) return hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide<FWD, WV, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_wide<FWD, WV, KB><<<a.total, 64 * WV, lds, s>>>(a);
+    return hipSuccess;
+}
+// once per device, outside any stream capture (ddrl_dqn_create)
+static hipError_t wide_prepare() {
+    WideArgs z{};
+    hipError_t e = wide_launch<true, 4, 32>(z, nullptr, true);
+    if (e == hipSuccess) e = wide_launch<true, 8, 32>(z, nullptr, true);
+    if (e == hipSuccess) e = wide_launch<false, 4, 32>(z, nullptr, true);
+    if (e == hipSuccess) e = wide_launch<false, 4, 16>(z, nullptr, true);
+    if (e == hipSuccess) e = wide_launch<false, 8, 32>(z, nullptr, true);
+    return e;
+}
+static void launch_wide_fwd(const WideArgs &a, hipStream_t s) {
+    if (a.rows == 256) (void)wide_launch<true, 8, 32>(a, s, false);
+    else (void)wide_launch<true, 4, 32>(a, s, false);
+    const long long n = (long long)a.nev * a.M * (a.N >> 2);
+    k_wide_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a);
+}
+static void launch_wide_wgrad(const WideArgs &a, hipStream_t s) {
+    if (a.rows == 256) (void)wide_launch<false, 8, 32>(a, s, false);
+    else if (a.kb == 16) (void)wide_launch<false, 4, 16>(a, s, false);
+    else (void)wide_launch<false, 4, 32>(a, s, false);
+}
+
+}  // namespace

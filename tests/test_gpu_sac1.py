@@ -422,9 +422,58 @@ def test_fused_envelope_shapes(ddrl, obs, act, hid, batch):
     assert learner.opt_steps() == (2, 2)
 
 
+@pytest.mark.parametrize("variant,obs,acts,hid,batch,misalign", [("ddqn", 1024, 4, (400, 300), 32, False), ("ddqn", 1028, 3, (72, 40), 50, False),
+                                                                 ("sqn", 1040, 5, (100, 60), 130, False), ("ddqn", 2048, 2, (32, 32), 64, True)])
+def test_wide_layer1_shapes(ddrl, variant, obs, acts, hid, batch, misalign):
+    """Wide observations (obs_dim >= 1024) take layer 1 through csrc/wide_l1.h — split-K tiled forward + reduce, tiled wgrad with
+    the bias row, the caller's observation rows read in place by LDS-DMA.  Shapes off the headline one: K not a multiple of the
+    32-deep stage, a last column unit of 8 of 32 hidden units, batches that are not whole 32-row units / 128-row tiles (the wgrad's K),
+    five evaluations and two networks (SQN), and observation pointers that are not 16-byte aligned (staged copy instead of in
+    place).  Two updates vs the float64 oracle."""
+    from distributed_drl_amd import _lib, dqn
+    from oracle import dqn_oracle as do
+
+    class Opt:
+        obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed, alpha = obs, acts, list(hid), 0.99, 1e-3, 0.995, batch, 2, 0.1
+    sqn = variant == "sqn"
+    learner = (dqn.LearnerSQN if sqn else dqn.Learner)(Opt, "learner")
+    cfg = do.Config(obs_dim=obs, n_actions=acts, hidden1=hid[0], hidden2=hid[1], batch=batch)
+    params = (do.sqn_init_params if sqn else do.init_params)(cfg, 2)
+    rs = np.random.RandomState(3)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.1, 0.1, params[k].shape).astype(np.float32)
+    learner.set_weights(list(params.keys()), list(params.values()))
+    o64 = do.SqnOracle(cfg, params, 0.1, torch.float64) if sqn else do.DqnOracle(cfg, params, torch.float64)
+    for it in range(2):
+        b = do.synthetic_batch(cfg, 30 + it)
+        w = o64.step(b)
+        fed = dict(b)
+        if misalign:
+            for k in ("obs1", "obs2"):
+                flat = torch.zeros(batch * obs + 1, dtype=torch.float32, device="cuda")
+                flat[1:] = torch.from_numpy(b[k]).reshape(-1).cuda()
+                fed[k] = flat[1:].view(batch, obs)
+                assert fed[k].data_ptr() % 16 == 4
+        loss, q = learner.train(fed, it, return_outputs=True)
+        tol = 2e-5 if it == 0 else 1e-4
+        assert _rel(loss.item(), w["q_loss"]) <= tol, (it, loss.item(), float(w["q_loss"]))
+        np.testing.assert_allclose(q.cpu().numpy(), w["q"].numpy(), rtol=10 * tol, atol=10 * tol)
+        if it == 0:
+            g, g64 = learner.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
+            assert np.abs(g - g64).max() <= 3e-4 * np.abs(g64).max()
+    for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target")):
+        assert np.abs(learner.export(which).cpu().numpy() - o64.flat(name)).max() <= 2 * 2e-2 * cfg.lr
+    # the q output for fewer rows than the batch goes through the staged image
+    x = b["obs1"][:3]
+    qn = (do.q_net(o64.main, "main", torch.as_tensor(x.astype(np.float64))) if not sqn else None)
+    if qn is not None:
+        np.testing.assert_allclose(learner.q_values(x).cpu().numpy(), qn.numpy(), rtol=1e-3, atol=1e-4)
+
+
 def test_ddqn_learner_at_the_config5_observation_width(ddrl):
     """BASELINE config 5's learner input: flat 84x84x4 = 28 224-wide observations (algos/dqn/train.py:43-52) through the
-    Double-DQN learner — layer 1 is a K = 28 224 GEMM (streaming K loop of k_gemm).  One update vs the float64 oracle; the
+    Double-DQN learner — layer 1 is a K = 28 224 GEMM (csrc/wide_l1.h).  One update vs the float64 oracle; the
     tolerances are wider than at K = 8 because 28 224 float32 products are summed per pre-activation (~sqrt(K) * 6e-8)."""
     from distributed_drl_amd import _lib, dqn
     from oracle import dqn_oracle as do

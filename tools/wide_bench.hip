@@ -1,0 +1,142 @@
+// Dev harness for csrc/wide_l1.h: the wide layer-1 forward (split K + reduce) and wgrad kernels against a double-precision
+// host loop at small ragged shapes, then timed at config 5's shape (batch 512, obs 28 224, hidden 400, three evaluations).
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function tools/wide_bench.hip -o tools/wide_bench.bin
+#include "../distributed-drl_amd/csrc/wide_l1.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+static float *dev(const std::vector<float> &v) {
+    float *p; hipMalloc(&p, v.size() * 4); hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice); return p;
+}
+static std::vector<float> rnd(size_t n, float sc) {
+    std::vector<float> v(n);
+    for (auto &x : v) x = ((float)(rand() & 0xffff) / 32768.f - 1.f) * sc;
+    return v;
+}
+
+static int WVF = 4, WVG = 4, KBG = 32, MNU = 4;
+static const float *g_consts;
+static int check(int nev, int M, int N, int K) {
+    const int ldh = (N + 1 + 3) & ~3;
+    std::vector<std::vector<float>> X(nev), W(nev), Bz(nev);
+    WideArgs a{};
+    wide_plan(a, nev, M, N, K, true, WVF, WVF == 8 ? 256 : 512);
+    float *part; hipMalloc(&part, wide_part_floats(a) * 4);
+    std::vector<float *> H(nev);
+    for (int e = 0; e < nev; ++e) {
+        X[e] = rnd((size_t)M * K, 1.f); W[e] = rnd((size_t)K * N, 0.05f); Bz[e] = rnd(N, 0.5f);
+        hipMalloc(&H[e], (size_t)M * ldh * 4); hipMemset(H[e], 0, (size_t)M * ldh * 4);
+        a.ev[e] = WideEval{dev(X[e]), dev(W[e]), dev(Bz[e]), H[e], K};
+    }
+    a.part = part; a.a_rows = M; a.ldo = ldh; a.consts = g_consts;
+    launch_wide_fwd(a, 0);
+    hipDeviceSynchronize();
+    double worst = 0;
+    for (int e = 0; e < nev; ++e) {
+        std::vector<float> h((size_t)M * ldh);
+        hipMemcpy(h.data(), H[e], h.size() * 4, hipMemcpyDeviceToHost);
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < N; ++j) {
+                double s = Bz[e][j];
+                for (int k = 0; k < K; ++k) s += (double)X[e][(size_t)i * K + k] * W[e][(size_t)k * N + j];
+                s = s > 0 ? s : 0;
+                worst = std::max(worst, std::fabs(s - h[(size_t)i * ldh + j]) / (1.0 + std::fabs(s)));
+            }
+    }
+    // wgrad: G = [X0 | 1]^T dZ
+    std::vector<float> dZ = rnd((size_t)M * N, 0.1f);
+    float *G; hipMalloc(&G, (size_t)(K + 1) * N * 4); hipMemset(G, 0xff, (size_t)(K + 1) * N * 4);
+    WideArgs g{};
+    wide_plan(g, 1, K + 1, N, M, false, WVG, 0, KBG, MNU);
+    g.ev[0] = WideEval{a.ev[0].A, dev(dZ), nullptr, G, K}; g.a_rows = K; g.consts = g_consts;
+    launch_wide_wgrad(g, 0);
+    hipDeviceSynchronize();
+    std::vector<float> hg((size_t)(K + 1) * N);
+    hipMemcpy(hg.data(), G, hg.size() * 4, hipMemcpyDeviceToHost);
+    double worst_g = 0;
+    for (int i = 0; i <= K; i += (K > 4096 ? 97 : 1))
+        for (int j = 0; j < N; ++j) {
+            double s = 0;
+            for (int k = 0; k < M; ++k) s += (double)(i < K ? X[0][(size_t)k * K + i] : 1.f) * dZ[(size_t)k * N + j];
+            worst_g = std::max(worst_g, std::fabs(s - hg[(size_t)i * N + j]) / (1.0 + std::fabs(s)));
+        }
+    const bool ok = worst < 2e-5 && worst_g < 2e-5;
+    printf("nev %d M %4d N %4d K %6d  S %2d/%2d: fwd err %.2e  wgrad err %.2e  %s (%s)\n", nev, M, N, K, a.S[0], a.S[1], worst, worst_g, ok ? "ok" : "MISMATCH",
+           hipGetErrorString(hipGetLastError()));
+    return ok ? 0 : 1;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) WVF = atoi(argv[1]);
+    if (argc > 2) WVG = atoi(argv[2]);
+    if (argc > 3) KBG = atoi(argv[3]);
+    if (argc > 4) MNU = atoi(argv[4]);
+    if (wide_prepare() != hipSuccess) { printf("wide_prepare failed\n"); return 1; }
+    g_consts = dev(std::vector<float>{1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+    int bad = 0;
+    bad += check(3, 32, 400, 1024);
+    bad += check(3, 50, 72, 1028);
+    bad += check(5, 600, 100, 1040);
+    bad += check(1, 512, 32, 2048);
+    bad += check(3, 37, 400, 28224);
+    if (bad) return 1;
+    // timing at config 5's shape
+    const int nev = 3, M = 512, N = 400, K = 28224, ldh = 404;
+    WideArgs a{};
+    wide_plan(a, nev, M, N, K, true, WVF, WVF == 8 ? 256 : 512);
+    float *x1, *x2, *w, *wt, *bz, *h, *part, *dz, *G;
+    hipMalloc(&x1, (size_t)M * K * 4); hipMalloc(&x2, (size_t)M * K * 4); hipMalloc(&w, (size_t)K * N * 4); hipMalloc(&wt, (size_t)K * N * 4);
+    hipMalloc(&bz, N * 4); hipMalloc(&h, (size_t)3 * M * ldh * 4); hipMalloc(&part, wide_part_floats(a) * 4); hipMalloc(&dz, (size_t)M * N * 4);
+    hipMalloc(&G, (size_t)(K + 1) * N * 4);
+    {   // random operands: zero-filled ones flatter the matrix pipes
+        std::vector<float> t = rnd((size_t)M * K, 1.f);
+        hipMemcpy(x1, t.data(), t.size() * 4, hipMemcpyHostToDevice); hipMemcpy(x2, t.data() + 1000, (t.size() - 1000) * 4, hipMemcpyHostToDevice);
+        t = rnd((size_t)K * N, 0.05f);
+        hipMemcpy(w, t.data(), t.size() * 4, hipMemcpyHostToDevice); hipMemcpy(wt, t.data() + 1000, (t.size() - 1000) * 4, hipMemcpyHostToDevice);
+        t = rnd((size_t)M * N, 0.1f);
+        hipMemcpy(dz, t.data(), t.size() * 4, hipMemcpyHostToDevice); hipMemset(bz, 0, N * 4);
+    }
+    a.ev[0] = WideEval{x1, w, bz, h, K}; a.ev[1] = WideEval{x2, w, bz, h + (size_t)M * ldh, K}; a.ev[2] = WideEval{x2, wt, bz, h + (size_t)2 * M * ldh, K};
+    a.part = part; a.a_rows = M; a.ldo = ldh; a.consts = g_consts;
+    WideArgs g{};
+    wide_plan(g, 1, K + 1, N, M, false, WVG, 0, KBG, MNU);
+    g.ev[0] = WideEval{x1, dz, nullptr, G, K}; g.a_rows = K; g.consts = g_consts;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 10; ++i) launch_wide_fwd(a, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("forward (3 evaluations, S = %d/%d, %d workgroups) + reduce: %.1f us  = %.1f TFLOP/s\n", a.S[0], a.S[1], a.total, ms * 100.f,
+               2.0 * nev * M * N * (double)K / (ms * 1e-4) / 1e12);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 10; ++i) launch_wide_wgrad(g, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("wgrad (%d workgroups): %.1f us  = %.1f TFLOP/s\n", g.total, ms * 100.f, 2.0 * M * N * (double)(K + 1) / (ms * 1e-4) / 1e12);
+    }
+#ifdef WD_STAMPS
+    {
+        long long *st; hipMalloc(&st, (size_t)a.total * 8 * 8 * 8); hipMemset(st, 0, (size_t)a.total * 8 * 8 * 8);
+        a.stamps = st;
+        launch_wide_fwd(a, 0); hipDeviceSynchronize();
+        std::vector<long long> hs((size_t)a.total * 8 * 8);
+        hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+        for (int nu = 3; nu <= 4; ++nu) {
+            double ph[6] = {0}; long long n = 0, stages = 0;
+            for (int wg = 0; wg < a.total; ++wg)
+                for (int w = 0; w < WVF; ++w) {
+                    const long long *o = &hs[((size_t)wg * WVF + w) * 8];
+                    if (o[7] != nu) continue;
+                    ++n; stages += o[6];
+                    for (int i = 0; i < 6; ++i) ph[i] += (double)o[i];
+                }
+            if (n) printf("forward NU %d: %lld waves, %.1f stages each; cycles per stage: top %.0f issue %.0f compute %.0f landed %.0f barrier %.0f\n", nu, n,
+                          (double)stages / n, ph[0] / stages, ph[1] / stages, ph[2] / stages, ph[3] / stages, ph[4] / stages);
+        }
+    }
+#endif
+    printf("%s\n", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
