@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 static float *dev(const std::vector<float> &v) {
     float *p; hipMalloc(&p, v.size() * 4); hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice); return p;
@@ -115,6 +116,23 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 10; ++i) launch_wide_wgrad(g, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("wgrad (%d workgroups): %.1f us  = %.1f TFLOP/s\n", g.total, ms * 100.f, 2.0 * M * N * (double)(K + 1) / (ms * 1e-4) / 1e12);
+    }
+    {   // race screen: the same launches 100 times, every output bit-identical to the first (LDS-DMA ordering is by vmcnt + barrier only)
+        std::vector<float> h0((size_t)3 * M * ldh), h1(h0.size()), g0((size_t)(K + 1) * N), g1(g0.size());
+        launch_wide_fwd(a, 0); launch_wide_wgrad(g, 0); hipDeviceSynchronize();
+        hipMemcpy(h0.data(), h, h0.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(g0.data(), G, g0.size() * 4, hipMemcpyDeviceToHost);
+        int diff = 0;
+        for (int it = 0; it < 100 && !diff; ++it) {
+            hipMemsetAsync(h, 0xff, h0.size() * 4, 0); hipMemsetAsync(G, 0xff, g0.size() * 4, 0);
+            launch_wide_fwd(a, 0); launch_wide_wgrad(g, 0); hipDeviceSynchronize();
+            hipMemcpy(h1.data(), h, h1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(g1.data(), G, g1.size() * 4, hipMemcpyDeviceToHost);
+            for (int e = 0; e < 3; ++e)
+                for (int i = 0; i < M; ++i)
+                    if (memcmp(&h0[((size_t)e * M + i) * ldh], &h1[((size_t)e * M + i) * ldh], N * 4)) { diff = 1 + it; break; }
+            if (memcmp(g0.data(), g1.data(), g0.size() * 4)) diff = -(1 + it);
+        }
+        printf("race screen, 100 repeats of forward + wgrad at config 5's shape: %s (%d)\n", diff ? "OUTPUTS DIFFER" : "bit-identical", diff);
+        if (diff) return 1;
     }
 #ifdef WD_STAMPS
     {
