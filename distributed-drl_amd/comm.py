@@ -16,6 +16,7 @@ Mapping of the reference's cross-process traffic:
         (example/dsac.py:59-62,233), so this is a documented new synchronous semantics.
 The path shards by independent units (envs, replay shards): bench.py reports weak scaling.
 """
+import datetime
 import os
 
 import numpy as np
@@ -38,9 +39,15 @@ def init_from_env(backend=None, force=None):
             # DDRL_DIST_BACKEND=gloo lets several ranks share ONE GPU for functional checks
             # (RCCL refuses duplicate devices); production = "nccl" (RCCL over xGMI)
             backend = os.environ.get("DDRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # a collective that never completes (a peer died, a mismatched send / recv) aborts after DDRL_DIST_TIMEOUT_S instead of
+        # the backend's 10-minute default; binding the group to its device makes RCCL build the communicator now, so the first
+        # isend / irecv of a run does not create two-rank communicators lazily in an order the peers may not share
+        kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("DDRL_DIST_TIMEOUT_S", "300")))}
         if backend == "nccl":
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
