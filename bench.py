@@ -354,8 +354,8 @@ def stage_measurements(args, opt, rb, roll, d):
             fl = 2.0 * 512 * (4 * O5L.obs_dim * 400 + 5 * (400 * 300 + 300 * 4))
             out["ddqn_update_cfg5"] = {"batch": 512, "obs_dim": O5L.obs_dim, "ms": t_u * 1e3, "updates_per_s": 1.0 / t_u,
                                        "approx_TFLOPs": fl / t_u / 1e12, "frac_of_f32_mfma_peak": fl / t_u / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                       "what": "one Double-DQN update at config 5's observation width (generic k_gemm path: layer 1 is a "
-                                               "K = 28 224 GEMM), eager"}
+                                       "what": "one Double-DQN update at config 5's observation width, eager: layer 1 (K = 28 224) on the "
+                                               "128-row x 4-unit LDS-DMA tiles of csrc/wide_l1.h, layers 2 / 3 on the generic k_gemm"}
 
             def iteration():   # worker_train's loop body on config 5: sample_batch(512) -> train (algos/dqn/train.py:66-76, actor_learner.py)
                 bb = rb5.sample_batch_device(B5)
