@@ -430,7 +430,10 @@ int ddrl_dqn_set_weights(ddrl_dqn_t *h, const float *flat_main_d, void *stream);
 int ddrl_dqn_export(ddrl_dqn_t *h, int which, float *flat_d, void *stream);
 /* Learner.train(batch, cnt) == sess.run([q_loss, q, train_value_op, target_update]) (actor_learner.py:110-119):
  * acts_d holds the action indices as float32 (the buffer's acts_buf), loss_d[1] and q_d[batch, n_actions]
- * (either may be NULL) receive q_loss and self.q from the pre-update variables. */
+ * (either may be NULL) receive q_loss and self.q from the pre-update variables.
+ * Wide observations (obs_dim >= 1024, a multiple of 4; config 5's 28 224) whose obs1_d / obs2_d are 16-byte aligned are read IN PLACE by the
+ * layer-1 kernels, obs1_d until the last GEMM of the step (its layer-1 weight gradient): the rows must stay unchanged until `stream`
+ * has passed the step (the ordinary stream-order contract of every borrowed input here); other inputs are copied by the first launch. */
 int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
                   const float *done_d, float *loss_d, float *q_d, void *stream);
 /* self.q of the main network (SQN: q1) for n <= batch observations (Actor.get_action, actor_learner.py:193-198). */
