@@ -1257,19 +1257,27 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             const int ns_pi = steps(o) - 4, ns_q = steps(o + a) - 4;
             DFHead &HA = h->fh_a[st], &HB = h->fh_b[st];
             DFArgs &FA = h->f_a[st], &FB = h->f_b[st];
-            head(HA); args(FA, 5);
+            // Q1(x, a), Q2(x, a) need nothing from the policy: they run in phase 1 beside the policy-dependent evaluations (k_dfwd:
+            // "stored") when the tile counts allow the per-XCD split, else in phase 0 as before.  DDRL_QXA_PHASE=0 forces phase 0.
+            const int tpj_f = (B / 32) * nt2;
+            static const int qxa_phase = getenv("DDRL_QXA_PHASE") ? atoi(getenv("DDRL_QXA_PHASE")) : 1;
+            const bool q_late = qxa_phase == 1 && (3 * tpj_f) % 8 == 0 && (2 * tpj_f) % 8 == 0;
+            head(HA); args(FA, q_late ? 3 : 5);
             FA.job[0] = pij(Pm, 0); FA.job[0].H2c4 = h->H2c4; FA.job[0].H2r4 = h->H2r4; FA.job[0].H1r4 = h->H1r4;
             FA.job[0].xr4 = h->xp_r4;   // [x | 1] as an x4 image: A operand of the policy's layer-1 wgrad
             FA.job[1] = pij(Pm, 1);
             FA.job[2] = pij(Pt, 2);
-            FA.job[3] = qj(Pm, 0, 3); FA.job[3].H2c4 = h->H2c4 + 1 * H2C; FA.job[3].H2r4 = h->H2r4 + 1 * H2R; FA.job[3].H1r4 = h->H1r4 + 1 * H1I;
-            FA.job[3].xr4 = h->xa_r4;
-            FA.job[4] = qj(Pm, 1, 4); FA.job[4].H2c4 = h->H2c4 + 2 * H2C; FA.job[4].H2r4 = h->H2r4 + 2 * H2R; FA.job[4].H1r4 = h->H1r4 + 2 * H1I;
-            head(HB); args(FB, 3);
+            DFJob qa1 = qj(Pm, 0, 3); qa1.H2c4 = h->H2c4 + 1 * H2C; qa1.H2r4 = h->H2r4 + 1 * H2R; qa1.H1r4 = h->H1r4 + 1 * H1I;
+            qa1.xr4 = h->xa_r4;
+            DFJob qa2 = qj(Pm, 1, 4); qa2.H2c4 = h->H2c4 + 2 * H2C; qa2.H2r4 = h->H2r4 + 2 * H2R; qa2.H1r4 = h->H1r4 + 2 * H1I;
+            if (!q_late) { FA.job[3] = qa1; FA.job[4] = qa2; }
+            head(HB); args(FB, q_late ? 5 : 3);
+            if (q_late) { FB.job[3] = qa1; FB.job[4] = qa2; }
             {   // pack field of a job: steps | obs2 << 2 | target << 3 | network << 4
                 auto pk = [](int ns, int x2, int targ, int net) { return ns | (x2 << 2) | (targ << 3) | (net << 4); };
-                HA.pack = pk(ns_pi, 0, 0, 0) | (pk(ns_pi, 1, 0, 0) << 6) | (pk(ns_pi, 1, 1, 0) << 12) | (pk(ns_q, 0, 0, 1) << 18) | (pk(ns_q, 0, 0, 2) << 24);
-                HB.pack = pk(ns_q, 0, 0, 1) | (pk(ns_q, 1, 1, 1) << 6) | (pk(ns_q, 1, 1, 2) << 12);
+                const int qxa = (pk(ns_q, 0, 0, 1) << 18) | (pk(ns_q, 0, 0, 2) << 24);
+                HA.pack = pk(ns_pi, 0, 0, 0) | (pk(ns_pi, 1, 0, 0) << 6) | (pk(ns_pi, 1, 1, 0) << 12) | (q_late ? 0 : qxa);
+                HB.pack = pk(ns_q, 0, 0, 1) | (pk(ns_q, 1, 1, 1) << 6) | (pk(ns_q, 1, 1, 2) << 12) | (q_late ? (qxa | (1 << 30)) : 0);
             }
             auto from_pi = [&](DFJob &j, int pev, const float *Ppi, const float *eps, int side) {
                 j.php = h->hp + pev * HP; j.pbmu = Ppi + L.pi_bmu; j.pbls = Ppi + L.pi_bls; j.peps = eps; j.side = side;

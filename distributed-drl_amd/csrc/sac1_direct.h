@@ -19,13 +19,14 @@
 //     written by the optimizer epilogue; H1 / H2 / dZ: written in the layouts their consumers need
 //     by the epilogue that has the tile in LDS anyway).
 //
-// Launches of one update (all captured in the learner's hipGraph):
-//   k_dfwd<0>  evaluations 0-4 (layer 1 + layer 2 + head partials)            400 tiles
-//   k_dfwd<1>  evaluations 5-7, action from the policy-head partials (+ sampler workgroup)
-//   k_dg "bq"  the three Q dgrads, dZ2 generated from H2 on the fly; dQ/da partials
-//   k_dg "mid" policy-head backward as 32x32 tiles + the Q layer-2 / head wgrads with Adam + polyak
-//   k_dg "pi"  policy dgrad (+ layer-1 wgrad partials; the last row tile of a column tile to arrive sums them and steps the
-//              policy's layer 1), policy wgrads, Q layer-1 wgrads, Adam + polyak, optimizer bookkeeping
+// Launches of one update (all captured in the learner's hipGraph; tiles at config 2):
+//   k_dfwd<0>  evaluations 0-2: pi(x), pi(x2), pi_targ(x2) (layer 1 + layer 2 + head partials)                         240 tiles
+//   k_dfwd<1>  evaluations 5-7, action from the policy-head partials, + the stored-action evaluations 3-4 (q1(x,a),
+//              q2(x,a)) beside them (+ the next update's sampler workgroup)                                       240 + 160 + 1
+//   k_dg "bq"  the three Q dgrads, dZ2 generated from H2 on the fly; losses, dq; dQ/da partials; W3 snapshot              312
+//   k_dg "mid" the policy dgrad with its A operand generated in the tile, the policy-head backward tiles (images for the
+//              wgrads), the Q layer-2 / head wgrads with Adam + polyak                                                      464
+//   k_dg "pi"  policy layer-2 / head / layer-1 wgrads, Q layer-1 wgrads, Adam + polyak, loss means + optimizer bookkeeping  190
 
 #ifdef DDRL_STAMPS  // diagnostic builds only (tools/upd_bench.hip): per-workgroup cycle stamps of thread 0
 // the stamp buffer travels in the kernel arguments ([kernel id][1024 workgroups][16]): a __device__ pointer variable would
@@ -131,7 +132,7 @@ struct DFHead {
     int npi, perq;           // inside a buffer: the policy, then q1 at npi, q2 at npi + perq
     int hp_off;              // head-partial buffer (phase 1 reads the policy evaluations' partials)
     int x_off;               // input set: obs1; obs2 and acts follow as consecutive 256-byte aligned items
-    int pack;                // 6 bits per job: [1:0] layer-1 MFMA steps - 4 (input columns + the bias column, in pairs), [2] input is obs2, [3] target copy, [5:4] network
+    int pack;                // 6 bits per job: [1:0] layer-1 MFMA steps - 4 (input columns + the bias column, in pairs), [2] input is obs2, [3] target copy, [5:4] network; bit 30 (phase 1): jobs 3, 4 take the stored action
 };
 
 // One 32-unit block of the K loop: layer 1 (NS MFMA steps) -> relu -> 4 * nrq layer-2 MFMA steps.
@@ -258,7 +259,16 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         return;
     }
     int t;
-    {   // XCD-aware, panel-major tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s); give each XCD a
+    // Phase 1 with pack bit 30: jobs 3, 4 are STORED-action evaluations (Q1(x, a), Q2(x, a)) moved here from phase 0 — they need no
+    // policy output, so their K loops run while the three policy-dependent jobs of the same CUs still wait for head partials ->
+    // action -> layer-1 input (4.4 k cycles), and phase 0 drops to 240 tiles, one per CU.  Each XCD gets a run of dependent tiles
+    // first (dispatched first: one per CU) and then a run of stored ones (the second workgroup of a CU); host: 3 tpj % 8 == 0 == 2 tpj % 8.
+    bool stored = false;
+    if (PH == 1 && ((pack >> 30) & 1)) {
+        const int nd = 3 * tpj, b = blockIdx.x, x = b & 7, slot = b >> 3, qd = nd >> 3, qs = (2 * tpj) >> 3;
+        stored = slot >= qd;
+        t = stored ? nd + x * qs + (slot - qd) : x * qd + slot;
+    } else {   // XCD-aware, panel-major tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s); give each XCD a
         // contiguous run of tiles so that a W2 panel is fetched by one or two L2s instead of all eight (speed only)
         const int nwg = njobs * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int q = 0; q < DNT / 4; ++q) hv[e][c][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PH == 1) {
+    if (PH == 1 && !stored) {   // block-uniform
         const long long HPq = (long long)DFH * B * DNT;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -332,7 +342,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     #pragma unroll
                 for (int s = 0; s < 7; ++s) {
                     const int d = d_slot(s, h);
-                    const bool f0 = d < d0, f1 = PH == 0 && !f0 && d < D;
+                    const bool f0 = d < d0, f1 = (PH == 0 || stored) && !f0 && d < D;
                     const float *p = f1 ? in1 + row * d1 + (d - d0) : in0 + row * d0 + (f0 ? d : 0);
                     // (no select on the loaded value: the compiler would sink the load into a branch.)  Column D: the bias row
                     const float v = *p;   // (masking by multiplication instead of the select: +1.5 us per update)
@@ -357,7 +367,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
             const int cc = c < jb.hsplit ? c : c - jb.hsplit;
             whv = p[ok ? (long long)col * jb.hstride + cc : 0] * (ok ? 1.0f : 0.f);
         };
-        if (PH == 1) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
+        if (PH == 1 && !stored) {  // the sampled action of this tile's rows, in every lane of every wave (no LDS, no barrier)
             float hs[2][4];
     #pragma unroll
             for (int e = 0; e < 2; ++e)
