@@ -23,8 +23,8 @@ def rows(name):
 
 
 fetch, write, sq = rows("pmc_FETCH_SIZE.txt"), rows("pmc_WRITE_SIZE.txt"), rows("pmc_sq.txt")
-# the update's five launches, identified by kernel + grid (config 2: 400 / 240 forward tiles; 312 / 464 / 190 backward tiles)
-want = [("k_dfwd<0>", "k_dfwd<0,", 400 * 256), ("k_dfwd<1>", "k_dfwd<1,", 240 * 256), ("k_dg bq", "k_dg<10>", 312 * 256),
+# the update's five launches, identified by kernel + grid (config 2: 240 / 400 forward tiles; 312 / 464 / 190 backward tiles)
+want = [("k_dfwd<0>", "k_dfwd<0,", 240 * 256), ("k_dfwd<1>", "k_dfwd<1,", 400 * 256), ("k_dg bq", "k_dg<10>", 312 * 256),
         ("k_dg mid", "k_dg<10>", 464 * 256), ("k_dg pi", "k_dg<10>", 190 * 256)]
 per, lines = {}, []
 for label, kname, grid in want:
