@@ -8,11 +8,12 @@
 //   k_wide_reduce  H1[ev] = relu(sum_s P[ev][s] + b1) in split order (deterministic)
 //   k_wide<false>  [dW1 ; db1] = [X | 1]^T dZ1, the whole batch as K
 //
-// One workgroup = 128 output rows x NU <= 4 column units of 32 (32 FLOP per operand byte): 4 waves x (32 rows x NU units),
-// both operands staged through LDS 32 k at a time (double-buffered 2 x 32 KB, so two workgroups share a CU; whole 128-byte
+// One workgroup = 128 output rows x NU <= 5 column units of 32 (32-36 FLOP per operand byte): 4 waves x (32 rows x NU units),
+// both operands staged through LDS 32 k at a time (double-buffered 2 x 36 KB, so two workgroups share a CU; whole 128-byte
 // lines per row and stage); per 8-deep k group a wave reads 1 + 4 NU operands and issues 4 NU v_mfma_f32_32x32x2_f32.
-// hidden = 400 is 13 units: column tiles of 4, 3, 3, 3 units; a tile's number of K ranges is proportional to its units so
-// that every workgroup carries the same MFMA work, and the total is chosen so that all workgroups are resident at once.
+// hidden = 400 is 13 units: column tiles of 5, 4, 4 units (with 4, 3, 3, 3 the 3-unit tiles needed 9.8 K ranges for the
+// 4-unit tiles' 13: 9 % imbalance); a tile's number of K ranges is proportional to its units (16 / 13) so that every
+// workgroup carries the same MFMA work, and the total is chosen so that all workgroups are resident at once.
 // Workgroups are dealt to the XCDs in contiguous runs of the order (evaluation, K range, row tile, column tile): the
 // tiles that read the same X rows / W1 rows at the same time share an L2.
 // Exact fp32 like the rest of the learner; the k order inside an 8-deep group differs from k_gemm's (lane half h takes
@@ -24,6 +25,8 @@
 namespace {
 
 constexpr int WD_MAXEV = 5;
+constexpr int WD_NB = 5;        // column units of the B image (160 columns)
+constexpr int WD_BW = 32 * WD_NB;
 
 struct WideEval {
     const float *A;     // forward: X [M][lda] (k contiguous)     wgrad: X [K][lda] (output row i = input column i contiguous)
@@ -65,10 +68,10 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) {
 template <bool FWD, int WV, int WD_KB>   // WD_KB: k per LDS stage (32; 16 halves the LDS image: four workgroups of 4 waves per CU)
 __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     static_assert(WD_KB == 32 || !FWD, "the forward A image is cut for 128-byte rows");
-    constexpr int ROWS = 32 * WV, AOP = ROWS * WD_KB, WD_BOP = WD_KB * 128, NG = WD_KB / 8;
+    constexpr int ROWS = 32 * WV, AOP = ROWS * WD_KB, WD_BOP = WD_KB * WD_BW, NG = WD_KB / 8;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *sA = wsm;             // [2][AOP]  forward: [rows][8 float4 slots], chunk q of row r in slot q ^ ((r >> 1) & 7)   wgrad: [32 k][rows]
-    float *sB = wsm + 2 * AOP;   // [2][32 k][128 columns]
+    float *sB = wsm + 2 * AOP;   // [2][32 k][160 columns]
     int L;
     {   // contiguous run of the workgroup order per XCD (block b runs on XCD b % 8)
         const int b = blockIdx.x, q = a.total >> 3, r = a.total & 7, x = b & 7;
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     //   forward A   piece I = rows 8I..8I+7 x 8 slots; the lane that fills slot p of row r loads chunk p ^ ((r >> 1) & 7) (the
     //               swizzle sits on the SOURCE address and on the read; the destination is linear)
     //   wgrad A     piece I = 1 KB of the [32 k][rows] image (8 waves: k row I; 4 waves: k rows 2I, 2I + 1)
-    //   B           piece I = k rows 2I, 2I + 1 of the [32 k][128 columns] image
+    //   B           piece I = float4 64 I .. 64 I + 63 of the [32 k][160 columns] image (1.6 k rows)
     // What lies outside the matrices comes from a 16-byte block of zeros, the gradient's bias row from {1, 0, 0, 0}.
     constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;   // pieces per wave and stage: one A piece per k group, B: WD_KB / (2 WV)
     const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
-        const int kk = 2 * (BPW * w + j) + (lane >> 5), c4 = lane & 31;
+        const int f4 = 64 * (BPW * w + j) + lane, kk = f4 / (WD_BW / 4), c4 = f4 - kk * (WD_BW / 4);
         bk[j] = kk;
         pb[j] = (c4 < NU * 8 && n0 + 4 * c4 < a.N) ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;   // N % 4 == 0
     }
@@ -134,9 +137,9 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
     };
-    floatx16 acc[4];
+    floatx16 acc[WD_NB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < WD_NB; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
     const bool active = m0 + 32 * w < a.M;   // wave-uniform: this wave's 32 rows hold output
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
 #pragma unroll
             for (int u = 0; u < NUC; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * 128 + 32 * u + l31];
+                for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * WD_BW + 32 * u + l31];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -195,7 +198,8 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
 #endif
     };
     if (st0 < st1) {
-        if (NU == 4) run(std::integral_constant<int, 4>{});
+        if (NU == 5) run(std::integral_constant<int, 5>{});
+        else if (NU == 4) run(std::integral_constant<int, 4>{});
         else if (NU == 3) run(std::integral_constant<int, 3>{});
         else if (NU == 2) run(std::integral_constant<int, 2>{});
         else run(std::integral_constant<int, 1>{});
@@ -204,13 +208,13 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     if (FWD) {
         float *P = a.part + (((long long)e * a.Smax + s) * a.Mp + m0 + 32 * w) * a.Np + n0 + l31;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < WD_NB; ++u)
             if (u < NU)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P[(long long)((r & 3) + 8 * (r >> 2) + 4 * h) * a.Np + 32 * u] = acc[u][r];
     } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < WD_NB; ++u)
             if (u < NU) {
                 const int col = n0 + 32 * u + l31;
 #pragma unroll
@@ -250,7 +254,7 @@ static bool wide_applies(int obs, int h1) { return obs >= 1024 && obs % 4 == 0 &
 
 // Tiling of an [M x N] output over K: column tiles in two classes, K ranges per class proportional to the class's units,
 // at most `slots` workgroups (forward: all resident, 2 per CU; split = false: one K range, any number of workgroups).
-static void wide_plan(WideArgs &a, int nev, int M, int N, int K, bool split, int waves, int slots, int kb = 32, int max_nu = 4) {
+static void wide_plan(WideArgs &a, int nev, int M, int N, int K, bool split, int waves, int slots, int kb = 32, int max_nu = WD_NB) {
     a.nev = nev; a.M = M; a.N = N; a.K = K; a.rows = 32 * waves; a.kb = kb;
     const int units = (N + 31) / 32, ntiles = (units + max_nu - 1) / max_nu, base = units / ntiles, rem = units % ntiles;
     a.nu[0] = base + 1; a.cnt[0] = rem; a.nu[1] = base; a.cnt[1] = ntiles - rem;
@@ -275,7 +279,7 @@ static void wide_plan(WideArgs &a, int nev, int M, int N, int K, bool split, int
 static size_t wide_part_floats(const WideArgs &a) { return (size_t)a.nev * a.Smax * a.Mp * a.Np; }
 template <bool FWD, int WV, int KB>
 static hipError_t wide_launch(const WideArgs &a, hipStream_t s, bool prepare_only) {
-    constexpr size_t lds = (size_t)2 * (32 * WV * KB + KB * 128) * sizeof(float);   // 4 waves: 64 KB (KB 32) or 32 KB (KB 16), 8 waves: 96 KB
+    constexpr size_t lds = (size_t)2 * (32 * WV * KB + KB * WD_BW) * sizeof(float);   // 4 waves, 32-k stages: 72 KB (two workgroups per CU)
     if (prepare_only) return hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide<FWD, WV, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     k_wide<FWD, WV, KB><<<a.total, 64 * WV, lds, s>>>(a);
     return hipSuccess;
@@ -284,22 +288,14 @@ static hipError_t wide_launch(const WideArgs &a, hipStream_t s, bool prepare_onl
 static hipError_t wide_prepare() {
     WideArgs z{};
     hipError_t e = wide_launch<true, 4, 32>(z, nullptr, true);
-    if (e == hipSuccess) e = wide_launch<true, 8, 32>(z, nullptr, true);
     if (e == hipSuccess) e = wide_launch<false, 4, 32>(z, nullptr, true);
-    if (e == hipSuccess) e = wide_launch<false, 4, 16>(z, nullptr, true);
-    if (e == hipSuccess) e = wide_launch<false, 8, 32>(z, nullptr, true);
     return e;
 }
 static void launch_wide_fwd(const WideArgs &a, hipStream_t s) {
-    if (a.rows == 256) (void)wide_launch<true, 8, 32>(a, s, false);
-    else (void)wide_launch<true, 4, 32>(a, s, false);
+    (void)wide_launch<true, 4, 32>(a, s, false);
     const long long n = (long long)a.nev * a.M * (a.N >> 2);
     k_wide_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a);
 }
-static void launch_wide_wgrad(const WideArgs &a, hipStream_t s) {
-    if (a.rows == 256) (void)wide_launch<false, 8, 32>(a, s, false);
-    else if (a.kb == 16) (void)wide_launch<false, 4, 16>(a, s, false);
-    else (void)wide_launch<false, 4, 32>(a, s, false);
-}
+static void launch_wide_wgrad(const WideArgs &a, hipStream_t s) { (void)wide_launch<false, 4, 32>(a, s, false); }
 
 }  // namespace

@@ -17,13 +17,13 @@ static std::vector<float> rnd(size_t n, float sc) {
     return v;
 }
 
-static int WVF = 4, WVG = 4, KBG = 32, MNU = 4;
+static int WVF = 4, MNU = WD_NB;   // column units per tile (argv[1])
 static const float *g_consts;
 static int check(int nev, int M, int N, int K) {
     const int ldh = (N + 1 + 3) & ~3;
     std::vector<std::vector<float>> X(nev), W(nev), Bz(nev);
     WideArgs a{};
-    wide_plan(a, nev, M, N, K, true, WVF, WVF == 8 ? 256 : 512);
+    wide_plan(a, nev, M, N, K, true, 4, 512, 32, MNU);
     float *part; hipMalloc(&part, wide_part_floats(a) * 4);
     std::vector<float *> H(nev);
     for (int e = 0; e < nev; ++e) {
@@ -50,7 +50,7 @@ static int check(int nev, int M, int N, int K) {
     std::vector<float> dZ = rnd((size_t)M * N, 0.1f);
     float *G; hipMalloc(&G, (size_t)(K + 1) * N * 4); hipMemset(G, 0xff, (size_t)(K + 1) * N * 4);
     WideArgs g{};
-    wide_plan(g, 1, K + 1, N, M, false, WVG, 0, KBG, MNU);
+    wide_plan(g, 1, K + 1, N, M, false, 4, 0, 32, MNU);
     g.ev[0] = WideEval{a.ev[0].A, dev(dZ), nullptr, G, K}; g.a_rows = K; g.consts = g_consts;
     launch_wide_wgrad(g, 0);
     hipDeviceSynchronize();
@@ -70,10 +70,7 @@ static int check(int nev, int M, int N, int K) {
 }
 
 int main(int argc, char **argv) {
-    if (argc > 1) WVF = atoi(argv[1]);
-    if (argc > 2) WVG = atoi(argv[2]);
-    if (argc > 3) KBG = atoi(argv[3]);
-    if (argc > 4) MNU = atoi(argv[4]);
+    if (argc > 1) MNU = atoi(argv[1]);
     if (wide_prepare() != hipSuccess) { printf("wide_prepare failed\n"); return 1; }
     g_consts = dev(std::vector<float>{1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
     int bad = 0;
@@ -86,7 +83,7 @@ int main(int argc, char **argv) {
     // timing at config 5's shape
     const int nev = 3, M = 512, N = 400, K = 28224, ldh = 404;
     WideArgs a{};
-    wide_plan(a, nev, M, N, K, true, WVF, WVF == 8 ? 256 : 512);
+    wide_plan(a, nev, M, N, K, true, 4, 512, 32, MNU);
     float *x1, *x2, *w, *wt, *bz, *h, *part, *dz, *G;
     hipMalloc(&x1, (size_t)M * K * 4); hipMalloc(&x2, (size_t)M * K * 4); hipMalloc(&w, (size_t)K * N * 4); hipMalloc(&wt, (size_t)K * N * 4);
     hipMalloc(&bz, N * 4); hipMalloc(&h, (size_t)3 * M * ldh * 4); hipMalloc(&part, wide_part_floats(a) * 4); hipMalloc(&dz, (size_t)M * N * 4);
@@ -102,7 +99,7 @@ int main(int argc, char **argv) {
     a.ev[0] = WideEval{x1, w, bz, h, K}; a.ev[1] = WideEval{x2, w, bz, h + (size_t)M * ldh, K}; a.ev[2] = WideEval{x2, wt, bz, h + (size_t)2 * M * ldh, K};
     a.part = part; a.a_rows = M; a.ldo = ldh; a.consts = g_consts;
     WideArgs g{};
-    wide_plan(g, 1, K + 1, N, M, false, WVG, 0, KBG, MNU);
+    wide_plan(g, 1, K + 1, N, M, false, 4, 0, 32, MNU);
     g.ev[0] = WideEval{x1, dz, nullptr, G, K}; g.a_rows = K; g.consts = g_consts;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms;
