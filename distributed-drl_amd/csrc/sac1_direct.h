@@ -172,7 +172,13 @@ struct DOps {
 // Measured at config 2 (us per update): DPRE 1 / 2 / 3 / 4 (= everything up front) 54.1 / 54.5 / 55.2 / 55.3; the input rows
 // requested in front of the operand blocks 54.0, the epilogue operands from inside the loop 53.7; DGP 1 / 2 / 4 / 8 / 16
 // 52.4 / 52.35 / 52.6 / 53.2 / 53.7; DGMID 1 / 2 / 4 / 6 / 8 52.3 / 52.3 / 52.0 / 52.1 / 52.3.
-constexpr int DPRE = 1;    // operand blocks of k_dfwd requested before its K loop
+#ifndef DDRL_DPRE0
+#define DDRL_DPRE0 1
+#endif
+#ifndef DDRL_DPRE1
+#define DDRL_DPRE1 1
+#endif
+constexpr int DPRE = 1;    // operand blocks of k_dfwd requested before its K loop (per phase: DDRL_DPRE0 / DDRL_DPRE1)
 #ifndef DDRL_DGP0
 #define DDRL_DGP0 2
 #endif
@@ -330,7 +336,7 @@ __global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int
     }
     DOps ops;
     const DSrc src{W1, W2p, Np, b0, nb, n0};
-    constexpr int PRE = DPRE;
+    constexpr int PRE = PH == 0 ? DDRL_DPRE0 : DDRL_DPRE1;
     {
         // ---- the observation part of the layer-1 input: lane (row, h) holds input column d_slot(s, h) for step s
         float xin[MT][7];
