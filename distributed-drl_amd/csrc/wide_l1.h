@@ -1,7 +1,7 @@
 // Layer 1 of the discrete-action learners when the observation is WIDE (config 5: flat 84x84x4 = 28 224 floats,
 // algos/dqn/train.py:43-52 feeding algos/dqn/core.py:40-50's first dense layer).  The generic k_gemm (one 32x32 tile per
 // workgroup: 8 FLOP per operand byte) was built for the SAC shapes; at K = 28 224 it pulls 1.2 GB through the fabric for
-// 206 MB of operands and runs at a third of the fp32 MFMA rate (profiles/r03_ddqn_cfg5_summary.txt).  One tiled kernel
+// 206 MB of operands and runs at a third of the fp32 MFMA rate (profiles/r03_ddqn_cfg5_before_summary.txt).  One tiled kernel
 // replaces it for both GEMMs of the layer:
 //
 //   k_wide<true>   forward, split K: partial pre-activations P[ev][s] = X[ev][:, Ks] * W1[ev][Ks, :]
@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) {
     return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const float *)p;
 }
 
-template <bool FWD, int WV, int WD_KB>   // WD_KB: k per LDS stage (32; 16 halves the LDS image: four workgroups of 4 waves per CU)
+template <bool FWD, int WV, int WD_KB>   // the product instance is <., 4, 32>: 4 waves, 32 k per LDS stage (8-wave 256-row tiles and 16-k stages measured no better)
 __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     static_assert(WD_KB == 32 || !FWD, "the forward A image is cut for 128-byte rows");
     constexpr int ROWS = 32 * WV, AOP = ROWS * WD_KB, WD_BOP = WD_KB * WD_BW, NG = WD_KB / 8;
@@ -94,10 +94,10 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     // fills 1 KB of LDS in lane order from per-lane source addresses, so the images are cut into 1 KB pieces of 64 float4:
     //   forward A   piece I = rows 8I..8I+7 x 8 slots; the lane that fills slot p of row r loads chunk p ^ ((r >> 1) & 7) (the
     //               swizzle sits on the SOURCE address and on the read; the destination is linear)
-    //   wgrad A     piece I = 1 KB of the [32 k][rows] image (8 waves: k row I; 4 waves: k rows 2I, 2I + 1)
+    //   wgrad A     piece I = 1 KB of the [32 k][rows] image (4 waves: k rows 2I, 2I + 1)
     //   B           piece I = float4 64 I .. 64 I + 63 of the [32 k][160 columns] image (1.6 k rows)
     // What lies outside the matrices comes from a 16-byte block of zeros, the gradient's bias row from {1, 0, 0, 0}.
-    constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;   // pieces per wave and stage: one A piece per k group, B: WD_KB / (2 WV)
+    constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;   // pieces per wave and stage: 4 of A, 5 of B
     const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
     const float *pa[APW], *pb[BPW];
     int ak[APW], bk[BPW];   // k offset inside a stage of what this lane loads (forward A: of its chunk; else of its k row)
