@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     //   B           piece I = float4 64 I .. 64 I + 63 of the [32 k][160 columns] image (1.6 k rows)
     // What lies outside the matrices comes from a 16-byte block of zeros, the gradient's bias row from {1, 0, 0, 0}.
     constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;   // pieces per wave and stage: 4 of A, 5 of B
+    static_assert(APW * WV * 256 == AOP && BPW * WV * 256 == WD_BOP, "the LDS images are dealt to the waves in whole 1 KB pieces");
     const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
     const float *pa[APW], *pb[BPW];
     int ak[APW], bk[BPW];   // k offset inside a stage of what this lane loads (forward A: of its chunk; else of its k row)
