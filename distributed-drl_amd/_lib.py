@@ -126,6 +126,7 @@ SIGNATURES = {
     "ddrl_dqn_destroy": (c_int, [_P]),
     "ddrl_dqn_set_weights": (c_int, [_P, _P, _P]),
     "ddrl_dqn_export": (c_int, [_P, c_int, _P, _P]),
+    "ddrl_dqn_import": (c_int, [_P, c_int, _P, _P]),
     "ddrl_dqn_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ddrl_dqn_q": (c_int, [_P, _P, c_int64, _P, _P]),
     "ddrl_winq_create": (c_int, [POINTER(_P), c_int, c_int64, c_int32, c_int32, c_int32, c_int32]),

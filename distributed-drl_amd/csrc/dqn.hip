@@ -314,6 +314,18 @@ int ddrl_dqn_export(ddrl_dqn_t *h, int which, float *flat_d, void *stream) {
     return DDRL_OK;
 }
 
+int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && flat_d != nullptr, "NULL pointer");
+    // MAIN alone (no target_init), TARGET, or an Adam slot: what a resumed learner / a test with its own targets sets
+    float *buf = which == DDRL_SAC1_MAIN ? h->main_p : which == DDRL_SAC1_TARGET ? h->target_p : which == DDRL_SAC1_ADAM_M ? h->m :
+                 which == DDRL_SAC1_ADAM_V ? h->v : nullptr;
+    DDRL_REQUIRE(buf != nullptr, "unknown or read-only buffer id");
+    ddrl::DeviceGuard g(h->device);
+    k_pack<<<dim3(64, (unsigned)h->segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_d, buf, nullptr, 1);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
 int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,
                   float *loss_d, float *q_d, void *stream) {
     DDRL_REQUIRE(h != nullptr && obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL pointer");

@@ -77,6 +77,11 @@ class Learner:
         _lib.check(self._lib.ddrl_dqn_export(self._h, which, _lib.dptr(flat), _lib.stream_ptr()))
         return flat
 
+    def import_(self, which, flat):
+        flat = flat.to(device=self.device, dtype=torch.float32).contiguous()
+        assert flat.numel() == self.n_params
+        _lib.check(self._lib.ddrl_dqn_import(self._h, which, _lib.dptr(flat), _lib.stream_ptr()))
+
     def get_weights(self):
         flat = self.export().cpu().numpy()
         return list(self.keys), [flat[o:o + n].reshape(s).copy() for (o, n, s) in (self.table[k] for k in self.keys)]

@@ -428,6 +428,9 @@ int ddrl_dqn_destroy(ddrl_dqn_t *h);
 int ddrl_dqn_set_weights(ddrl_dqn_t *h, const float *flat_main_d, void *stream);
 /* Flat copies of the learner's buffers; `which` = DDRL_SAC1_MAIN / TARGET / ADAM_M / ADAM_V / GRAD. */
 int ddrl_dqn_export(ddrl_dqn_t *h, int which, float *flat_d, void *stream);
+/* The inverse for MAIN (without target_init), TARGET, ADAM_M, ADAM_V: a learner resumed from its own state, or one whose
+ * target network differs from main (any state after the first update: actor_learner.py:62-66). GRAD is read-only. */
+int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream);
 /* Learner.train(batch, cnt) == sess.run([q_loss, q, train_value_op, target_update]) (actor_learner.py:110-119):
  * acts_d holds the action indices as float32 (the buffer's acts_buf), loss_d[1] and q_d[batch, n_actions]
  * (either may be NULL) receive q_loss and self.q from the pre-update variables.
