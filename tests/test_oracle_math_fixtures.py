@@ -146,3 +146,22 @@ def test_discrete_oracles_equal_reference_text(family):
             if family == "sqn":
                 assert close(out["q2"].numpy(), z[tag + "_q2"]), tag
             check_state(o, z, tag, names)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="build container only: regenerates from the reference checkout")
+def test_fixtures_regenerate_identically_from_the_reference(tmp_path):
+    """The committed vectors are what the reference's text produces today: rerun the generator (small families) into a
+    scratch directory and compare every array bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from oracle import gen_golden_math as g; g.OUT = %r; g.main(['sac1', 'sacv'])"
+            % (root, str(tmp_path)))
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL)
+    for fam in ("sac1", "sacv"):
+        a, b = np.load(os.path.join(GOLD, fam + "_math.npz")), np.load(os.path.join(str(tmp_path), fam + "_math.npz"))
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (fam, k)
+        with open(os.path.join(GOLD, fam + "_math.json")) as f, open(os.path.join(str(tmp_path), fam + "_math.json")) as g2:
+            assert json.load(f) == json.load(g2)
