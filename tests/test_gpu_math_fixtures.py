@@ -186,3 +186,106 @@ def test_discrete_learners_vs_reference_text(ddrl, family, case):
         # wide: a pre-activation carries ~1e-5 relative rounding, so of 512 x 400 hidden units a few sit on the other side of
         # their relu in float32 — discrete changes in single gradient entries (seen: 1.05e-3 of a tensor's RMS on update 2)
         check_digests(learner, _lib, z, tag, shapes, s, c["lr"], (2e-3 if s == 0 else 4e-3) if wide else 3e-4)
+
+
+# ---- config 5's learner at the shape bench.py times: batch 512, obs 28 224, hidden (400, 300) -------------------------------
+class _Cfg5Opt:
+    obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed, alpha = 84 * 84 * 4, 4, [400, 300], 0.99, 1e-4, 0.995, 512, 2, 0.1
+    buffer_size, save_dir = 1536, "."
+
+
+def _cfg5_batches(n, seed=1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    o = _Cfg5Opt
+    return [{"obs1": torch.randint(0, 256, (512, o.obs_dim), device="cuda", generator=g).float() / 16,
+             "obs2": torch.randint(0, 256, (512, o.obs_dim), device="cuda", generator=g).float() / 16,
+             "acts": torch.randint(0, 4, (512,), device="cuda", generator=g).float(), "rews": torch.randn(512, device="cuda", generator=g),
+             "done": (torch.rand(512, device="cuda", generator=g) < 0.01).float()} for _ in range(n)]
+
+
+@pytest.mark.parametrize("variant", ["ddqn", "sqn"])
+def test_config5_learner_race_screen(ddrl, variant):
+    """60 repeats of the same update from the same parameters at the benched shape (csrc/wide_l1.h: 504-workgroup split-K
+    forward + reduce, 663-workgroup wgrad, LDS-DMA double buffers ordered by vmcnt + barrier only): loss, q output and the whole
+    11.4 M-element gradient must come back bit-identical every time.  (Round 3's intra-launch race passed every value test.)"""
+    from distributed_drl_amd import _lib, dqn
+    learner = (dqn.LearnerSQN if variant == "sqn" else dqn.Learner)(_Cfg5Opt, "learner")
+    main = learner.export(_lib.SAC1_MAIN).clone()
+    targ = torch.roll(main, 1)                                # any target != main
+    b = _cfg5_batches(1)[0]
+    first = None
+    for rep in range(60):
+        learner.import_(_lib.SAC1_MAIN, main)
+        learner.import_(_lib.SAC1_TARGET, targ)
+        loss, q = learner.train(b, rep, return_outputs=True)
+        got = (loss.clone(), q.clone(), learner.export(_lib.SAC1_GRAD))
+        if first is None:
+            first = got
+            assert torch.isfinite(got[2]).all() and float(got[2].abs().max()) > 0
+        else:
+            for a, w in zip(got, first):
+                assert torch.equal(a, w), rep
+
+
+@pytest.mark.parametrize("variant", ["ddqn", "sqn"])
+def test_config5_learner_soak(ddrl, variant):
+    """Two learners from the same seed, the same 100 updates over rotating batches at the benched shape: parameters, targets
+    and both Adam moments end bit-identical and finite (tools/dqn_soak.py as a test)."""
+    from distributed_drl_amd import _lib, dqn
+    batches = _cfg5_batches(3, seed=7)
+    res = []
+    for run in range(2):
+        learner = (dqn.LearnerSQN if variant == "sqn" else dqn.Learner)(_Cfg5Opt, "learner")
+        for it in range(100):
+            learner.train(batches[it % 3], it)
+        torch.cuda.synchronize()
+        res.append([learner.export(w).cpu() for w in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V)])
+        del learner
+    for a, b in zip(*res):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert not torch.equal(res[0][0], res[0][1])
+
+
+def test_config5_whole_iteration_vs_oracle(ddrl):
+    """One whole learner iteration of config 5 (algos/dqn/train.py:66-76 + actor_learner.py:110-119): sample_batch(512) out
+    of a DQN-shape ring of 28 224-wide pixel transitions (wrapped), straight into Learner.train on the device — against the
+    oracle ring (bit-exact indices and rows) feeding the float64 oracle learner (loss within the derived 4*sqrt(K)*2^-24).
+    Three iterations: the sampler's stream carries over, the learner's state too."""
+    from distributed_drl_amd import _lib, dqn
+    from oracle import dqn_oracle as do
+    from oracle.replay_oracle import ReplayBufferOracle
+    o = _Cfg5Opt
+    buf = ddrl.ReplayBufferDQN(o, 0, seed=9)
+    ora = ReplayBufferOracle(o.obs_dim, 1, o.buffer_size, acts_1d=True, seed=9)
+    rs = np.random.RandomState(4)
+    for n in (1000, 1000):                                    # 2000 stores into 1536 slots: the ring wraps
+        o1 = rs.randint(0, 256, (n, o.obs_dim)).astype(np.float32)
+        o2 = rs.randint(0, 256, (n, o.obs_dim)).astype(np.float32)
+        a, r = rs.randint(0, 4, n).astype(np.float32), rs.randn(n).astype(np.float32)
+        d = (rs.rand(n) < 0.05).astype(np.float32)
+        buf.store_batch(*(torch.from_numpy(x).cuda() for x in (o1, a, r, o2, d)))
+        ora.store_batch(o1, a, r, o2, d)
+    learner = dqn.Learner(o, "learner")
+    names, vals = learner.get_weights()
+    vals[0] = vals[0] * np.float32(1.0 / 64)                  # 0..255 pixels: keep layer 1 in range
+    learner.set_weights(names, vals)
+    cfg = do.Config(obs_dim=o.obs_dim, n_actions=o.act_dim, hidden1=400, hidden2=300, batch=512, gamma=o.gamma, lr=o.lr, polyak=o.polyak)
+    o64 = do.DqnOracle(cfg, dict(zip(names, vals)), torch.float64)
+    bar = 4 * math.sqrt(o.obs_dim) * 2.0 ** -24
+    for it in range(3):
+        g = buf.sample_batch_device(512, with_indices=True)
+        w = ora.sample_batch(512)
+        np.testing.assert_array_equal(g["idxs"].cpu().numpy(), ora.last_idxs)
+        for k in ("obs1", "obs2", "acts", "rews", "done"):
+            assert np.array_equal(g[k].cpu().numpy(), w[k]), k
+        loss, q = learner.train(g, it, return_outputs=True)
+        want = o64.step(w)
+        assert _rel(loss.item(), want["q_loss"]) <= (1 + it) * bar, (it, loss.item(), float(want["q_loss"]))
+        wq = want["q"].numpy()
+        assert np.abs(q.cpu().numpy() - wq).max() <= 5 * (1 + it) * bar * max(1.0, np.abs(wq).max())
+    assert buf.get_counts() == ora.get_counts()
+    a, b = learner.export(_lib.SAC1_MAIN).cpu().numpy(), o64.flat("main")
+    # Adam's first steps move a parameter by ~lr * g / (|g| + 1e-8): where |g| ~ 1e-8 (a weight whose pixel column is almost
+    # always multiplied by a dead unit) the float32 and float64 steps may differ by up to lr each; everywhere else by rounding
+    err = np.abs(a - b)
+    assert err.max() <= 3 * 1.01 * o.lr and (err > 3 * 2e-2 * o.lr + 1e-7).mean() <= 1e-5, (err.max(), (err > 3 * 2e-2 * o.lr + 1e-7).mean())
