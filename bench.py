@@ -52,6 +52,16 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec (6 290 measured streaming)
 
 
+def kernel_source_hash():
+    """sha256 over csrc/*.h, *.hip (sorted by name): profiles/traffic.json records the one its PMC passes were taken on."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "distributed-drl_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "distributed-drl_amd", "csrc", "*.hip"))):
+        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return hsh.hexdigest()
+
+
 def update_flops(B, obs, act, h1, h2):
     """1 853 800 MAC per sample -> 949 145 600 FLOP at B = 256."""
     pol = obs * h1 + h1 * h2 + 2 * h2 * act
@@ -85,7 +95,8 @@ def parse_args():
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds per CPU-baseline leg")
     ap.add_argument("--gpu-seconds", type=float, default=10.0, help="keep repeating the timed block until the GPU legs lasted this long")
     ap.add_argument("--stage-samples", type=int, default=200)
-    ap.add_argument("--cfg5-capacity", type=int, default=294912, help="transitions of the config-5 ring (225 804 B each; default 66.6 GB)")
+    ap.add_argument("--cfg5-capacity", type=int, default=-1,
+                    help="transitions of the config-5 ring (225 804 B each); -1: as many as 90 %% of the free HBM holds (at most 1.15 M = 260 GB); 0: skip config 5")
     return ap.parse_args()
 
 
@@ -104,6 +115,7 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if ndev < n:
             env.setdefault("DDRL_DIST_BACKEND", "gloo")  # several ranks per GPU: functional run only (RCCL refuses duplicate devices)
+            env["DDRL_BENCH_FUNCTIONAL_ONLY"] = "1"      # the line says so and carries no scaling point
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
@@ -319,44 +331,102 @@ def stage_measurements(args, opt, rb, roll, d):
         del lp, m, rbv
     except Exception as e:  # noqa
         out["sac_v_update"] = {"error": repr(e)[:200]}
-    if args.cfg5_capacity > 0:
-        try:   # config 5: DQN (algos/dqn) on 84x84x4 float32 observations, batch 512 — the ring, its sampler and its learner
-            from distributed_drl_amd import dqn
-            obs_dim, B5, cap = 84 * 84 * 4, 512, int(args.cfg5_capacity)
+    if args.cfg5_capacity != 0:
+        out.update(config5_stages(args, d))
+    return out
 
-            class O5:
-                pass
-            O5.obs_dim, O5.buffer_size, O5.batch_size, O5.save_dir = obs_dim, cap, B5, "."
-            rb5 = d.ReplayBufferDQN(O5, 0, seed=0)
-            g = torch.Generator(device="cuda").manual_seed(0)
-            z = torch.zeros(2048, device="cuda")
-            for s0 in range(0, cap, 2048):
-                n = min(2048, cap - s0)
-                x = torch.randint(0, 256, (n, obs_dim), device="cuda", generator=g).float()
-                rb5.store_batch(x, z[:n], z[:n], x, z[:n])
-            del x
-            T5 = 4 * (2 * obs_dim + 1 + 2)
-            t_g = timed(lambda: rb5.sample_batch_device(B5), 64)
-            out["config5_gather"] = {"batch": B5, "bytes_per_transition": T5, "ring_GB": cap * T5 / 1e9, "ring_transitions": cap,
-                                     "us": t_g * 1e6, "bytes_per_batch": B5 * (2 * T5 + 4), "GBps": B5 * (2 * T5 + 4) / t_g / 1e9,
-                                     "frac_of_hbm_peak": B5 * (2 * T5 + 4) / t_g / 1e9 / PEAK_HBM_GBPS,
-                                     "what": "sample_batch(512) of 84x84x4 float32 transitions (MT19937 indices + five gathers); the "
-                                             "observation arrays are %.1f GB each: byte offsets far beyond 2^32, a ring far beyond the 256 MiB "
-                                             "Infinity Cache" % (cap * obs_dim * 4 / 1e9)}
 
-            class O5L:
-                obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed = 84 * 84 * 4, 4, [400, 300], 0.99, 1e-3, 0.995, 512, 2
-            l5 = dqn.Learner(O5L, "learner")
-            b5 = rb5.sample_batch_device(B5)
-            b5["acts"].random_(0, 4)
-            t_u = timed(lambda: l5.train(b5, 0), 20, warm=3)
-            # three forwards (main @ x, main @ x2, target @ x2) + the wgrad of main @ x for every layer, + the dgrad of layers 2, 3
-            fl = 2.0 * 512 * (4 * O5L.obs_dim * 400 + 5 * (400 * 300 + 300 * 4))
-            out["ddqn_update_cfg5"] = {"batch": 512, "obs_dim": O5L.obs_dim, "ms": t_u * 1e3, "updates_per_s": 1.0 / t_u,
-                                       "approx_TFLOPs": fl / t_u / 1e12, "frac_of_f32_mfma_peak": fl / t_u / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                       "what": "one Double-DQN update at config 5's observation width, eager: layer 1 (K = 28 224) on the "
-                                               "128-row x 4-unit LDS-DMA tiles of csrc/wide_l1.h, layers 2 / 3 on the generic k_gemm"}
+def config5_stages(args, d):
+    """config 5: DQN (algos/dqn) on 84x84x4 float32 observations, batch 512 — the ring, its sampler and its learner at single-GPU scale.
+    The learner legs do not depend on the ring (a box that cannot hold it still reports them); the ring is as large as the free HBM
+    allows (--cfg5-capacity < 0: auto; the full 4 M transitions = 903 GB need shards)."""
+    import torch
+    from distributed_drl_amd import _lib, dqn
+    out = {}
+    obs_dim, B5 = 84 * 84 * 4, 512
+    T5 = 4 * (2 * obs_dim + 1 + 2)
 
+    class O5L:
+        obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed = 84 * 84 * 4, 4, [400, 300], 0.99, 1e-3, 0.995, 512, 2
+    g = torch.Generator(device="cuda").manual_seed(0)
+    l5 = None
+    try:
+        l5 = dqn.Learner(O5L, "learner")
+        names, vals = l5.get_weights()
+        l5.set_weights(names[:1], [vals[0] / 64.0])      # 0..255 pixel inputs: keep layer 1 in range
+        b5 = {"obs1": torch.randint(0, 256, (B5, obs_dim), device="cuda", generator=g).float(),
+              "obs2": torch.randint(0, 256, (B5, obs_dim), device="cuda", generator=g).float(),
+              "acts": torch.randint(0, 4, (B5,), device="cuda", generator=g).float(), "rews": torch.randn(B5, device="cuda", generator=g),
+              "done": torch.zeros(B5, device="cuda")}
+        t_u = timed(lambda: l5.train(b5, 0), 20, warm=3)
+        st = l5.stage_times(b5, reps=20)
+        h1, h2, A = 400, 300, 4
+        # algorithmic FLOPs per launch group: three forwards (main @ x, main @ x2, target @ x2); backward of main @ x
+        fl = {"layer1_forward": 2.0 * B5 * obs_dim * h1 * 3, "layer2_forward": 2.0 * B5 * h1 * h2 * 3, "head_forward": 2.0 * B5 * h2 * A * 3,
+              "head_backward": 2.0 * B5 * h2 * A * 2, "layer2_backward": 2.0 * B5 * h1 * h2 * 2, "layer1_wgrad": 2.0 * B5 * (obs_dim + 1) * h1}
+        n_par = obs_dim * h1 + h1 + h1 * h2 + h2 + h2 * A + A
+        adam_bytes = 40.0 * n_par                      # SURVEY 8(d): 28 B/param optimizer + 12 B/param target traffic
+        names_k = {"layer1_forward": "k_wide<true> (504 workgroups, split-K) + k_wide_reduce", "layer2_forward": "k_gemm", "head_forward": "k_gemm",
+                   "head_backward": "k_gemm (dgrad + wgrad jobs)", "layer2_backward": "k_gemm (dgrad + wgrad jobs)", "layer1_wgrad": "k_wide<false>"}
+        order = ("stage", "layer1_forward", "layer2_forward", "head_forward", "rows", "head_backward", "layer2_backward", "layer1_wgrad", "adam_polyak")
+        per = {}
+        for k, ms in zip(order, st):
+            e = {"us": ms * 1e3}
+            if k in fl:
+                e.update({"kernel": names_k[k], "flop": fl[k], "achieved_TFLOPs": fl[k] / (ms * 1e-3) / 1e12,
+                          "frac": fl[k] / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "bound": "mfma"})
+            elif k == "adam_polyak":
+                e.update({"kernel": "k_adam_polyak (flat, 11.4 M parameters)", "bytes": adam_bytes, "achieved_GBps": adam_bytes / (ms * 1e-3) / 1e9,
+                          "frac": adam_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "bound": "hbm"})
+            per[k] = e
+        tot_fl = sum(fl.values())
+        out["ddqn_update_cfg5"] = {
+            "batch": 512, "obs_dim": obs_dim, "ms": t_u * 1e3, "updates_per_s": 1.0 / t_u,
+            "what": "one Double-DQN update at config 5's learner shape on a device batch, eager: layer 1 (K = 28 224) on the LDS-DMA tiles of "
+                    "csrc/wide_l1.h, layers 2 / 3 on k_gemm, flat Adam + polyak",
+            "roofline": {"kernel": "layer-1 forward (dominant): " + names_k["layer1_forward"], "bound": "mfma",
+                         "achieved": per["layer1_forward"]["achieved_TFLOPs"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": per["layer1_forward"]["frac"], "traffic": None,
+                         "update_flops": tot_fl, "update_achieved_TFLOPs": tot_fl / t_u / 1e12,
+                         "update_frac": tot_fl / t_u / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "per_launch_group": per,
+                         "how": "HIP events between the launch groups of 20 eager updates on the launch stream (ddrl_dqn_step_timed); rocprofv3 "
+                                "summary of the same shape under profiles/"}}
+    except Exception as e:  # noqa
+        out["ddqn_update_cfg5"] = {"error": repr(e)[:300]}
+    rb5 = None
+    try:
+        free_b, _ = torch.cuda.mem_get_info()
+        cap = int(args.cfg5_capacity) if args.cfg5_capacity > 0 else int(min(1.15e6, 0.90 * free_b / T5))
+        cap = max(2048, cap // 2048 * 2048)
+
+        class O5:
+            pass
+        O5.obs_dim, O5.buffer_size, O5.batch_size, O5.save_dir = obs_dim, cap, B5, "."
+        while True:
+            try:
+                rb5 = d.ReplayBufferDQN(O5, 0, seed=0)
+                break
+            except Exception:  # noqa  (out of memory: halve and retry; the stage still reports what it ran on)
+                if cap <= 4096:
+                    raise
+                cap = max(4096, cap // 2 // 2048 * 2048)
+                O5.buffer_size = cap
+                torch.cuda.empty_cache()
+        z = torch.zeros(2048, device="cuda")
+        for s0 in range(0, cap, 2048):
+            n = min(2048, cap - s0)
+            x = torch.randint(0, 256, (n, obs_dim), device="cuda", generator=g).float()
+            rb5.store_batch(x, z[:n], z[:n], x, z[:n])
+        del x
+        t_g = timed(lambda: rb5.sample_batch_device(B5), 64)
+        out["config5_gather"] = {"batch": B5, "bytes_per_transition": T5, "ring_GB": cap * T5 / 1e9, "ring_transitions": cap,
+                                 "us": t_g * 1e6, "bytes_per_batch": B5 * (2 * T5 + 4), "GBps": B5 * (2 * T5 + 4) / t_g / 1e9,
+                                 "frac_of_hbm_peak": B5 * (2 * T5 + 4) / t_g / 1e9 / PEAK_HBM_GBPS,
+                                 "what": "sample_batch(512) of 84x84x4 float32 transitions (MT19937 indices + five gathers) out of the largest ring "
+                                         "the free HBM holds; the observation arrays are %.1f GB each: byte offsets far beyond 2^32, a ring far "
+                                         "beyond the 256 MiB Infinity Cache" % (cap * obs_dim * 4 / 1e9)}
+        if l5 is not None:
             def iteration():   # worker_train's loop body on config 5: sample_batch(512) -> train (algos/dqn/train.py:66-76, actor_learner.py)
                 bb = rb5.sample_batch_device(B5)
                 l5.train(bb, 0)
@@ -365,10 +435,10 @@ def stage_measurements(args, opt, rb, roll, d):
                                                 "sample_share": t_g / t_i,
                                                 "what": "sample_batch(512) from the %.0f GB ring + one Double-DQN update, back to back on one stream: the "
                                                         "K = 28 224 layer-1 GEMMs (MFMA-bound), not the 231 MB gather (HBM-bound), set the rate" % (cap * T5 / 1e9)}
-            del rb5, l5, b5
-            torch.cuda.empty_cache()
-        except Exception as e:  # noqa  (an out-of-memory box must not lose the headline line)
-            out["config5_gather"] = dict(out.get("config5_gather", {}), error=str(e)[:200])
+    except Exception as e:  # noqa  (an out-of-memory box must not lose the headline line)
+        out["config5_gather"] = dict(out.get("config5_gather", {}), error=str(e)[:200])
+    del rb5, l5
+    torch.cuda.empty_cache()
     return out
 
 
@@ -409,10 +479,13 @@ def main():
     opt.max_ep_len = 1000
     opt.seed = 0
     env_steps_per_step = num_envs * len(roles.rollouts)
-    if args.gate == "hold":   # batches the gate owes for one step's env steps, shared over the learner ranks
-        updates_per_step = max(1, int(round(env_steps_per_step / args.a_l_ratio / len(roles.learners))))
-    else:
-        updates_per_step = max(1, int(round(4096 / args.a_l_ratio)))   # per learner rank, the config-2 figure at every N
+    # per learner rank and step.  hold: the batches the reference's gate owes for one step's env steps, shared over the learner ranks
+    # (algos/sac1/sac1.py:203-207); free: the config-2 figure at every N — example/dsac.py's workers, which have no gate at all
+    # (example/dsac.py:76-150: rollouts and learners run unthrottled), with per-rank work fixed as N grows
+    upd_by_gate = {"hold": max(1, int(round(env_steps_per_step / args.a_l_ratio / len(roles.learners)))),
+                   "free": max(1, int(round(4096 / args.a_l_ratio)))}
+    updates_per_step = upd_by_gate[args.gate]
+    other_gate = "free" if args.gate == "hold" else "hold"
     shard_cap = args.capacity // len(roles.shard_owner)
     cfgd = dict(B=opt.batch_size, obs=opt.obs_dim, act=opt.act_dim, h1=opt.hidden_sizes[0], h2=opt.hidden_sizes[1])
 
@@ -426,9 +499,9 @@ def main():
         trainer.ps = ps
         roll = RolloutDevice(ps, rb, opt, worker_index=0)
 
-        def one_step():
+        def one_step(n_upd=updates_per_step):
             roll.step()
-            trainer.run(updates_per_step)
+            trainer.run(n_upd)
     else:
         def make_replay():
             r = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, shard_cap, seed=1000 + rank)
@@ -437,17 +510,17 @@ def main():
         run = partition.PartitionedRun(opt, roles, make_replay, lambda r_: RolloutDevice(None, r_, opt, worker_index=rank),
                                        lambda: Learner(opt, job="learner", index=rank), seed=opt.seed, updates_per_graph=args.updates_per_graph)
 
-        def one_step():
-            run.step(updates_per_step)
+        def one_step(n_upd=updates_per_step):
+            run.step(n_upd)
 
     busy = [0.0]
 
-    def block():
+    def block(n_upd=updates_per_step):
         torch.cuda.synchronize()
         comm.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            one_step()
+            one_step(n_upd)
         torch.cuda.synchronize()
         busy[0] = time.perf_counter() - t0             # this rank's own work (a rollout rank then waits for the learners)
         comm.barrier()
@@ -466,6 +539,20 @@ def main():
 
     env_steps = args.steps * num_envs * len(roles.rollouts)
     updates = args.steps * updates_per_step * len(roles.learners)
+    # the same timed block under the other gate setting (identical by construction when both owe the same updates per step: N = 1)
+    if upd_by_gate[other_gate] != updates_per_step:
+        one_step(upd_by_gate[other_gate])
+        dt_other = block(upd_by_gate[other_gate])
+    else:
+        dt_other = dt
+    # who ran where: (rank, device index, device UUID / PCI bus id, backend) gathered over the group
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": dev.index, "uuid": str(getattr(props, "uuid", "")) or None,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "name": props.name}
+    rank_devices = [me]
+    if world > 1:
+        rank_devices = [None] * world
+        torch.distributed.all_gather_object(rank_devices, me)
     rank_busy = role_times = None
     if run is not None:
         import torch.distributed as dist
@@ -518,16 +605,18 @@ def main():
                          "note": "from the timed region of learner rank 0: env step + block transfers + the learner loop (%s)" %
                                  ("graph-captured, the sampler following the step's feed plan" if len(roles.learners) == 1 else
                                   "eager: gradients, RCCL all-reduce, Adam per update")})
-    traffic, tsrc = None, None
+    traffic, tsrc, stale = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic, tsrc = tj.get("bytes_per_launch_mean"), tj.get("source")
+            stale = tj.get("kernel_source_sha256") != kernel_source_hash()
         except Exception:  # noqa
             pass
     roofline["traffic"] = traffic
-    roofline["traffic_source"] = ("static file profiles/traffic.json (%s) — regenerate with tools/pmc_summary.py whenever the kernels change" % tsrc) if traffic else None
+    roofline["traffic_stale"] = stale   # true: csrc/ changed since the PMC passes behind profiles/traffic.json (tools/prof_round.sh + tools/make_traffic.py)
+    roofline["traffic_source"] = ("static file profiles/traffic.json (%s); PMC counters cannot be collected inside this process" % tsrc) if traffic else None
 
     out = {
         "metric": "env-steps/s + learner updates/s, SAC1 LunarLanderContinuous-v2 @1/2/4/8 GPU",
@@ -543,14 +632,41 @@ def main():
                    "num_envs": num_envs, "replay_capacity": args.capacity, "batch": args.batch,
                    "updates_per_step": updates_per_step, "updates_per_graph": args.updates_per_graph if len(roles.learners) == 1 else 0,
                    "gate": args.gate, "a_l_ratio": args.a_l_ratio,
+                   "weak_scaling_read_against": "value_ungated",
+                   "weak_scaling_why": "`value` keeps the actor/learner gate of algos/sac1/sac1.py:25,203-207 (env steps / sampled batches <= a_l_ratio): "
+                                       "env-steps/s is then 2 x the learner group's updates/s at every N, and a learner group does not grow with the "
+                                       "rollout ranks (SURVEY 8(e): updates/s is per learner group) — with config 4's 2 learner ranks of 8 the gated "
+                                       "curve is bounded by 2/8 whatever the kernels do. `value_ungated` is the same run with example/dsac.py's "
+                                       "semantics (dsac.py:76-150 has no gate: rollout workers and learners free-run), per-rank work fixed as N grows "
+                                       "(one vector env step per rollout rank + 2048 updates per learner rank per step): the quantity SURVEY 8(e) "
+                                       "expects to scale with the rollout GPUs and the one the north star's >= 0.7 weak-scaling target can be read "
+                                       "against. At N = 1 both are the same step (4096 env steps + 2048 updates).",
                    "env_steps_per_sample": env_steps / max(1, updates), "learner_ranks": roles.learners, "rollout_ranks": roles.rollouts,
                    "backend": (torch.distributed.get_backend() if world > 1 else None), "devices": ndev,
+                   "world_size": world, "rank_devices": rank_devices,
+                   "distinct_devices": len({(r or {}).get("uuid") or (r or {}).get("pci_bus_id") or (r or {}).get("device") for r in rank_devices}),
                    "parallelism": roles.describe()},
         "repeat_blocks": {"n": len(blocks), "ms_per_step_median": float(np.median(blocks)) / args.steps * 1e3,
                           "ms_per_step_min": float(np.min(blocks)) / args.steps * 1e3, "ms_per_step_max": float(np.max(blocks)) / args.steps * 1e3,
                           "note": "`value` is block 0 (exactly --steps steps); the same block repeated to keep the GPU leg visible"},
         "roofline": roofline,
     }
+    g_env, g_upd = env_steps, args.steps * upd_by_gate[other_gate] * len(roles.learners)
+    other = {"value": g_env / dt_other, "updates_per_s": g_upd / dt_other, "ms_per_step": dt_other / args.steps * 1e3,
+             "updates_per_step": upd_by_gate[other_gate], "gate": other_gate,
+             "what": "the same timed block of --steps steps under --gate %s%s" % (other_gate, " (identical step at N = 1: not re-run)" if dt_other is dt else "")}
+    out["value_ungated" if other_gate == "free" else "value_gated"] = other["value"]
+    out["other_gate"] = other
+    if args.gate == "free":
+        out["value_ungated"] = out["value"]
+    functional = os.environ.get("DDRL_BENCH_FUNCTIONAL_ONLY") == "1" or (world > 1 and out["config"]["distinct_devices"] < world) \
+        or (world > 1 and out["config"]["backend"] != "nccl")
+    out["functional_only"] = bool(functional)
+    if functional:   # several ranks on one device (gloo, host-staged): the code path ran, the rate is not a scaling point
+        out["functional_value"] = {"value": out["value"], "updates_per_s": out["updates_per_s"], "value_ungated": out.get("value_ungated"),
+                                   "note": "ranks shared a GPU over gloo: host-staged transfers on one device — NOT an N-GPU measurement"}
+        out["value"], out["updates_per_s"] = 0.0, 0.0
+        out.pop("value_ungated", None)
     if run is not None:
         out["partition_stats"] = {k: v for k, v in run.stats.items() if not k.startswith("s_")}
         s_upd = [t.get("s_updates") for t in role_times if t and t.get("s_updates")]

@@ -18,6 +18,7 @@ DDRL_ERR_UNSUPPORTED = -5
 DDRL_REPLAY_ACTS_1D = 1
 DDRL_ENV_STATE_FIELDS = 32
 SAC1_STAGES = 12
+DQN_STAGES = 9   # include/ddrl.h: DDRL_DQN_STAGES
 SAC1_MAIN, SAC1_TARGET, SAC1_ADAM_M, SAC1_ADAM_V, SAC1_GRAD = range(5)
 SAC1, SAC_V = 0, 1  # ddrl_sac1_config_t.variant
 
@@ -128,6 +129,7 @@ SIGNATURES = {
     "ddrl_dqn_export": (c_int, [_P, c_int, _P, _P]),
     "ddrl_dqn_import": (c_int, [_P, c_int, _P, _P]),
     "ddrl_dqn_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ddrl_dqn_step_timed": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P]),
     "ddrl_dqn_q": (c_int, [_P, _P, c_int64, _P, _P]),
     "ddrl_winq_create": (c_int, [POINTER(_P), c_int, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "ddrl_winq_destroy": (c_int, [_P]),

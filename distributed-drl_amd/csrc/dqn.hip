@@ -326,33 +326,44 @@ int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream)
     return DDRL_OK;
 }
 
-int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,
-                  float *loss_d, float *q_d, void *stream) {
-    DDRL_REQUIRE(h != nullptr && obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL pointer");
-    ddrl::DeviceGuard g(h->device);
-    hipStream_t s = ddrl::as_stream(stream);
+}  // extern "C"
+
+// The launches of one update.  ev != nullptr: an event after every stage (DDRL_DQN_STAGES + 1 events, ev[0] first) for
+// ddrl_dqn_step_timed; the update itself is the same either way.
+static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,
+                           float *loss_d, float *q_d, hipStream_t s, hipEvent_t *ev) {
     const int B = h->cfg.batch, o = h->cfg.obs_dim;
+    int e = 0;
+#define STAGE_MARK() do { if (ev) DDRL_HIP_CHECK(hipEventRecord(ev[e++], s)); } while (0)
+    STAGE_MARK();
     // wide layer 1 reads the caller's observation rows in place (16-byte aligned rows: obs_dim % 4 == 0 there); otherwise
     // they are staged into the padded images with the ones column
     const bool in_place = h->wide && al16(obs1_d) && al16(obs2_d);
     const int n = in_place ? B : (B * o > B ? B * o : B);
     k_dqn_stage<<<(n + 255) / 256, 256, 0, s>>>(obs1_d, obs2_d, acts_d, rews_d, done_d, h->x1, h->x2, h->acts, h->rew, h->done, B, in_place ? 0 : o, h->ldx);
+    STAGE_MARK();   // 0 stage
     if (h->wide) {
         WideArgs f = h->wf;
-        for (int ev = 0; ev < f.nev; ++ev) {
-            f.ev[ev].A = in_place ? (h->wf_x2[ev] ? obs2_d : obs1_d) : (h->wf_x2[ev] ? h->x2 : h->x1);
-            f.ev[ev].lda = in_place ? o : h->ldx;
+        for (int k = 0; k < f.nev; ++k) {
+            f.ev[k].A = in_place ? (h->wf_x2[k] ? obs2_d : obs1_d) : (h->wf_x2[k] ? h->x2 : h->x1);
+            f.ev[k].lda = in_place ? o : h->ldx;
         }
         launch_wide_fwd(f, s);
     } else {
         launch_gemm(h->g_f1, s);
     }
+    STAGE_MARK();   // 1 layer-1 forward (+ split-K reduce)
     launch_gemm(h->g_f2, s);
+    STAGE_MARK();   // 2 layer-2 forward
     launch_gemm(h->g_f3, s);
+    STAGE_MARK();   // 3 head forward
     if (h->cfg.variant == DDRL_SQN) k_sqn_rows<<<1, 256, 0, s>>>(h->srows);
     else k_dqn_rows<<<1, 256, 0, s>>>(h->rows);
+    STAGE_MARK();   // 4 rows: backup, loss, dQ
     launch_gemm(h->g_b3, s);
+    STAGE_MARK();   // 5 head dgrad + wgrad
     launch_gemm(h->g_b2, s);
+    STAGE_MARK();   // 6 layer-2 dgrad + wgrad
     if (h->wide) {
         for (int nn = 0; nn < h->nnet; ++nn) {
             WideArgs g = h->ww[nn];
@@ -363,6 +374,7 @@ int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const
     } else {
         launch_gemm(h->g_b1, s);
     }
+    STAGE_MARK();   // 7 layer-1 wgrad
     {
         const long long blocks = (h->total_int / 4 + 255) / 256;
         h->ad.adam_blocks = (int)blocks;
@@ -370,11 +382,47 @@ int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const
         h->opt_cur ^= 1;
         k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
     }
+    STAGE_MARK();   // 8 flat Adam + polyak
+#undef STAGE_MARK
     DDRL_LAUNCH_CHECK();
     if (loss_d) DDRL_HIP_CHECK(hipMemcpyAsync(loss_d, h->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (q_d) DDRL_HIP_CHECK(hipMemcpy2DAsync(q_d, (size_t)h->cfg.n_actions * sizeof(float), h->Q, (size_t)h->ldq * sizeof(float),
                                              (size_t)h->cfg.n_actions * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, s));
     return DDRL_OK;
+}
+
+extern "C" {
+
+int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,
+                  float *loss_d, float *q_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL pointer");
+    ddrl::DeviceGuard g(h->device);
+    return dqn_step_launch(h, obs1_d, obs2_d, acts_d, rews_d, done_d, loss_d, q_d, ddrl::as_stream(stream), nullptr);
+}
+
+int ddrl_dqn_step_timed(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,
+                        int reps, float *stage_ms_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr && obs1_d && obs2_d && acts_d && rews_d && done_d && stage_ms_h, "NULL pointer");
+    DDRL_REQUIRE(reps > 0 && reps <= 64, "reps outside [1, 64]");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    constexpr int NE = DDRL_DQN_STAGES + 1;
+    std::vector<hipEvent_t> ev((size_t)reps * NE);
+    for (auto &e : ev) DDRL_HIP_CHECK(hipEventCreate(&e));
+    int rc = DDRL_OK;
+    for (int r = 0; r < reps && rc == DDRL_OK; ++r) rc = dqn_step_launch(h, obs1_d, obs2_d, acts_d, rews_d, done_d, nullptr, nullptr, s, ev.data() + (size_t)r * NE);
+    if (rc == DDRL_OK) {
+        DDRL_HIP_CHECK(hipStreamSynchronize(s));
+        for (int k = 0; k < DDRL_DQN_STAGES; ++k) stage_ms_h[k] = 0.f;
+        for (int r = 0; r < reps; ++r)
+            for (int k = 0; k < DDRL_DQN_STAGES; ++k) {
+                float ms = 0.f;
+                DDRL_HIP_CHECK(hipEventElapsedTime(&ms, ev[(size_t)r * NE + k], ev[(size_t)r * NE + k + 1]));
+                stage_ms_h[k] += ms / (float)reps;
+            }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 // self.q for n <= batch observations (Actor.get_action / the learner's q output): rows of q(x) main

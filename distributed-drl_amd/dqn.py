@@ -112,6 +112,16 @@ class Learner:
             return self.loss, q
         return None
 
+    def stage_times(self, batch, reps=10):
+        """Mean milliseconds per launch group of `reps` updates on `batch` (ddrl_dqn_step_timed; bench.py's config-5 roofline)."""
+        B = self.cfg.batch
+        x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))
+        a, r, d = self._dev(batch["acts"], (B,)), self._dev(batch["rews"], (B,)), self._dev(batch["done"], (B,))
+        ms = (ctypes.c_float * _lib.DQN_STAGES)()
+        _lib.check(self._lib.ddrl_dqn_step_timed(self._h, _lib.dptr(x), _lib.dptr(x2), _lib.dptr(a), _lib.dptr(r), _lib.dptr(d), int(reps), ms,
+                                                 _lib.stream_ptr()))
+        return [float(v) for v in ms]
+
     def q_values(self, obs):
         obs = self._dev(obs, (-1, self.cfg.obs_dim))
         q = torch.empty(obs.shape[0], self.cfg.n_actions, dtype=torch.float32, device=self.device)

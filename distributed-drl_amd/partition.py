@@ -223,6 +223,11 @@ class PartitionedRun:
         self.plan_d, self.plan_stage, self.plan_turn = None, [], 0
         self.err_d = torch.zeros(1, dtype=torch.int32, device=self.device) if self.learner is not None else None
         self.err_stage = []                           # [(pinned int32[1], event)] of the steps in flight
+        # every rank, not only the learners, is held to PLAN_STAGES steps of run-ahead: a rollout / shard-owner rank never blocks
+        # its host otherwise (env step, block draw, isend, Work.wait and the broadcast are all stream-ordered under RCCL), and
+        # under the actor/learner gate it is ~4000x faster than the learner it serves — it would queue a whole run's sends and
+        # broadcasts at once and the ones at the back would sit in the queue past the process group's watchdog timeout
+        self.step_events = []
         self.sends = []
         self.stats = {"local_batches": 0, "remote_batches": 0, "sent_batches": 0, "sent_blocks": 0, "pushes": 0}
         self.last_plan = None
@@ -368,6 +373,8 @@ class PartitionedRun:
             self._poll_error(drain=True)
 
     def step(self, n_updates):
+        if len(self.step_events) >= PLAN_STAGES:
+            self.step_events.pop(0).synchronize()     # the step issued PLAN_STAGES steps ago has left the device
         if self.learner is not None:
             self._poll_error()
         t = self._tick(None, 0.0)
@@ -406,4 +413,7 @@ class PartitionedRun:
             ev = torch.cuda.Event()
             ev.record()
             self.err_stage.append((word, ev))
+        ev = torch.cuda.Event()
+        ev.record()
+        self.step_events.append(ev)
         self._tick("s_drain", t)

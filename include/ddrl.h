@@ -439,6 +439,13 @@ int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream)
  * has passed the step (the ordinary stream-order contract of every borrowed input here); other inputs are copied by the first launch. */
 int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
                   const float *done_d, float *loss_d, float *q_d, void *stream);
+/* `reps` updates (each exactly ddrl_dqn_step) with a HIP event between the launch groups on `stream`; stage_ms_h[DDRL_DQN_STAGES] receives
+ * the mean milliseconds of: 0 input staging, 1 layer-1 forward of all evaluations (+ split-K reduce), 2 layer-2 forward, 3 head forward,
+ * 4 rows (backup / loss / dQ), 5 head dgrad + wgrad, 6 layer-2 dgrad + wgrad, 7 layer-1 wgrad, 8 flat Adam + polyak.  Synchronises
+ * `stream`.  Measurement aid of bench.py's config-5 roofline block (the reference has no counterpart). */
+#define DDRL_DQN_STAGES 9
+int ddrl_dqn_step_timed(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
+                        const float *done_d, int reps, float *stage_ms_h, void *stream);
 /* self.q of the main network (SQN: q1) for n <= batch observations (Actor.get_action, actor_learner.py:193-198). */
 int ddrl_dqn_q(ddrl_dqn_t *h, const float *obs_d, int64_t n, float *q_d, void *stream);
 

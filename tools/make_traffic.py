@@ -9,6 +9,8 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402  (bench.py prints traffic_stale when csrc/ no longer matches)
 
 
 def rows(name):
@@ -46,7 +48,7 @@ srcnote = ("profiles/%s_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRIT
            "`python3 tools/insitu.py 40` (40 eager updates back to back: every dispatch in the update sequence; PMC collection does not "
            "survive hipGraph launches on this ROCm, and the profiler runs every dispatch in isolation), tools/prof_round.sh + "
            "tools/make_traffic.py" % tag)
-json.dump({"source": srcnote,
+json.dump({"source": srcnote, "kernel_source_sha256": kernel_source_hash(),
            "fetch_correction": "FETCH_SIZE x2 (MI355X guide: the counter tallies 64 B per 128-B request for 16 B/lane coalesced loads on gfx950)",
            "write_note": "WRITE_SIZE as reported (16-B/lane stores are calibrated; the 4-B/lane epilogue stores are not)",
            "what": "L2 <-> fabric traffic (Infinity Cache + HBM behind it), mean per dispatch",
