@@ -240,12 +240,27 @@ def stage_measurements(args, opt, rb, roll, d):
     import torch
     out = {}
     n_env = int(opt.num_envs)
+    t_live = None
+    if getattr(roll, "_versions", False):
+        # the version store (exact per-env weight adoption): right after a pull up to min(n_envs, max_ep_len) + 1 versions are live
+        # and the forward runs grouped by version; max_ep_len steps after the last pull every env has been through an episode end
+        # and the plain launch on the one version is the same computation
+        t_live = timed(lambda: roll.step(20), 10) / 20.0
+        _, vstate = roll.actor.version_state(with_slots=False)
+        for _ in range(int(opt.max_ep_len) // 50 + 2):
+            roll.step(50)
     t = timed(lambda: roll.step(20), 20) / 20.0   # 20 vector steps per call: two launches per step, no host work in between
     pf = policy_flops(opt.obs_dim, opt.act_dim, opt.hidden_sizes[0], opt.hidden_sizes[1])
     out["rollout_only"] = {"env_steps_per_s": n_env / t, "us_per_vector_step": t * 1e6, "num_envs": n_env,
                            "flop_per_env_step": pf, "achieved_TFLOPs": n_env * pf / t / 1e12,
                            "frac_of_f32_mfma_peak": n_env * pf / t / 1e12 / PEAK_F32_MFMA_TFLOPS,
                            "what": "policy forward + env.step + store of %d envs per launch sequence (no learner)" % n_env}
+    if t_live is not None:
+        out["rollout_only_versions_live"] = {"env_steps_per_s": n_env / t_live, "us_per_vector_step": t_live * 1e6, "num_envs": n_env,
+                                             "row_tiles": vstate["tiles"], "versions_in_use_at_last_pull": vstate["live"],
+                                             "what": "the same vector step right after the training loop's pushes: every env acts on the version "
+                                                     "it pulled at its own episode end (example/dsac.py:127-130), envs grouped by version on the "
+                                                     "device, one row tile per 32 envs of a version"}
     try:   # config 4's rollout ranks step 8192 envs: both launches of a vector step are latency chains at 4096 (one workgroup round), so the
         # rate grows with the envs per step (profiles/r03_rollout_sweep.txt)
         from distributed_drl_amd.agent import HyperParameters

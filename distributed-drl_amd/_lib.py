@@ -122,6 +122,9 @@ SIGNATURES = {
     "ddrl_env_stats": (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), _P]),
     "ddrl_env_get_state": (c_int, [_P, _P, _P]),
     "ddrl_env_set_state": (c_int, [_P, _P, _P]),
+    "ddrl_actor_versions_enable": (c_int, [_P, c_int32, _P]),
+    "ddrl_actor_versions_state": (c_int, [_P, _P, _P, _P]),
+    "ddrl_actor_versions_adopt": (c_int, [_P, _P, c_int64, _P]),
     "ddrl_dqn_param_count": (c_int, [_P, POINTER(c_int64)]),
     "ddrl_dqn_create": (c_int, [POINTER(_P), c_int, _P]),
     "ddrl_dqn_destroy": (c_int, [_P]),

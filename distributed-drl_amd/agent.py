@@ -429,6 +429,25 @@ class Actor(_Net):
     def _flat_set(self, flat):
         _lib.check(self._lib.ddrl_actor_set_weights(self._h, _lib.dptr(flat), _lib.stream_ptr()))
 
+    # -- version store: exact per-env weight adoption of a vectorised rollout worker (example/dsac.py:127-130) ------------------
+    def enable_versions(self, n_slots):
+        """Keep `n_slots` resident copies of the policy: set_weights then stores a NEW version (instead of replacing the one every
+        env acts on) and the fused rollout step moves an env to the newest version at that env's own episode end."""
+        _lib.check(self._lib.ddrl_actor_versions_enable(self._h, int(n_slots), _lib.stream_ptr()))
+        self.n_slots = int(n_slots)
+
+    def version_state(self, with_slots=True):
+        """-> (slot of every env [max_rows] int32 device tensor or None, dict(newest, live, tiles, out_of_slots))."""
+        slots = torch.empty(self.max_rows, dtype=torch.int32, device=self.device) if with_slots else None
+        st = (ctypes.c_int32 * 4)()
+        _lib.check(self._lib.ddrl_actor_versions_state(self._h, _lib.dptr(slots), st, _lib.stream_ptr()))
+        return slots, {"newest": int(st[0]), "live": int(st[1]), "tiles": int(st[2]), "out_of_slots": bool(st[3])}
+
+    def adopt_where_ended(self, ended):
+        """Episode ends of steps taken outside the fused rollout step (uint8 mask of env.step): those envs pull."""
+        ended = ended.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self._lib.ddrl_actor_versions_adopt(self._h, _lib.dptr(ended), int(ended.numel()), _lib.stream_ptr()))
+
     def get_actions(self, obs, deterministic=False, eps=None, out=None):
         """Batched get_action on device tensors: obs[n, obs_dim] -> act[n, act_dim]."""
         obs = self._dev(obs, (-1, self.cfg.obs_dim))

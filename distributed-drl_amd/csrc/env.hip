@@ -380,6 +380,11 @@ struct RolloutArgs {
     int deterministic;
     uint32_t noise_seed;
     unsigned long long noise_ctr;
+    // version store of the actor (nullable): env i acts on slot[i] (bmu / bls are slot 0's then, slot s is vstride floats further)
+    // and adopts the newest version where its episode ends — the reference worker's pull at episode end (example/dsac.py:127-130)
+    int *slot;
+    const int *newest;
+    long long vstride;
     // replay ring
     ddrl_replay_dev::RingState *rs;
     ddrl_replay_dev::RingPtrs ring;
@@ -432,8 +437,9 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
                 }
             }
             const int cc = c < a.act ? c : 0;
-            mu[c] = sm + a.bmu[cc];
-            ls[c] = sl + a.bls[cc];
+            const long long voff = a.slot ? (long long)a.slot[i] * a.vstride : 0;
+            mu[c] = sm + a.bmu[voff + cc];
+            ls[c] = sl + a.bls[voff + cc];
             ev[c] = (a.deterministic || c >= a.act) ? 0.f : ddrl_pol::normal_at(a.noise_seed, a.noise_ctr + (unsigned long long)(i * a.act + c));
         }
         const ddrl_pol::PolRow pr = ddrl_pol::policy_row(mu, ls, ev, a.act, a.scale);
@@ -464,6 +470,7 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
             n_end = 1; len_end = (long long)e.eplen; ret_end = (double)e.epret;
             e.epi = e.epi + 1.0f;
             e.reset(o);                                 // :127
+            if (a.slot) a.slot[i] = *a.newest;          // :129-130  weights = ps.pull(keys); agent.set_weights(keys, weights)
         }
         {
             float4 *p = reinterpret_cast<float4 *>(a.obs + i * 8);
@@ -616,8 +623,18 @@ int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay,
     a.obs = v.obs; a.hp = v.hp; a.bmu = v.bmu; a.bls = v.bls; a.act = v.act; a.nt2 = v.nt2; a.scale = v.scale;
     a.deterministic = deterministic; a.noise_seed = noise_seed;
     a.rs = rv.state; a.ring = rv.ring; a.act_out = act_out_d; a.next_obs_out = next_obs_out_d;
+    const bool store = v.n_slots > 0;
+    DDRL_REQUIRE(!store || h->n == v.max_rows, "an actor with a version store steps exactly max_rows envs");
     for (int k = 0; k < n_steps; ++k) {  // the loop body of worker_rollout, n_steps times with the weights the actor holds
-        const int rc = ddrl_actor_internal_forward(actor, h->n, stream);
+        // version store: once no install has happened for max_ep_len steps every env has been through an episode end and
+        // acts on the newest version — the plain launch on the actor's current weights is then the same computation
+        const bool versioned = store && *v.steps_since_install < (long long)h->max_ep_len;
+        a.slot = versioned ? v.slot : nullptr;
+        a.newest = versioned ? reinterpret_cast<const int *>(v.vs) : nullptr;   // VerState::newest is its first word
+        a.vstride = v.vstride;
+        a.bmu = versioned ? v.vbmu : v.bmu; a.bls = versioned ? v.vbls : v.bls;
+        if (store) *v.steps_since_install += 1;
+        const int rc = ddrl_actor_internal_forward(actor, h->n, stream, versioned ? 1 : 0);
         if (rc != DDRL_OK) return rc;
         a.noise_ctr = noise_ctr + (uint64_t)k * (uint64_t)h->n * (uint64_t)v.act;
         // one wave per workgroup: 4096 envs spread over 64 CUs instead of 16 (the kernel is a chain of dependent latencies)

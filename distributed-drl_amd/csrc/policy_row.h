@@ -60,6 +60,13 @@ struct ddrl_actor_rollout_view {
     int obs_dim, act, nt2;
     long long max_rows;
     float scale;
+    // version store (n_slots > 0): the slot every env acts on, the head biases of slot 0 (slot s: + s * vstride), device state
+    int n_slots;
+    int *slot;
+    const void *vs;     // VerState (sac1_direct.h): .newest is what an env adopts at its episode end
+    long long vstride;
+    const float *vbmu, *vbls;
+    long long *steps_since_install;
 };
-int ddrl_actor_internal_forward(ddrl_actor_t *h, long long n, void *stream);
+int ddrl_actor_internal_forward(ddrl_actor_t *h, long long n, void *stream, int versioned);
 ddrl_actor_rollout_view ddrl_actor_internal_view(ddrl_actor_t *h);

@@ -1872,7 +1872,100 @@ struct ddrl_actor {
     Layout Ld;
     float *dslab, *pi_d, *obs_d, *hp_d;
     Seg *segs_dd;
+    // version store (ddrl_actor_versions_enable): n_slots copies of the direct-layout policy, the slot every env acts on, the
+    // grouping of the envs by slot for the forward launch.  pi_d stays the newest weights.
+    int n_slots;
+    long long vstride;
+    float *vslab;
+    int *slot_d, *perm_d;
+    VerTile *vtiles_d;
+    VerState *vs_d;
+    long long steps_since_install;   // host-side: >= the envs' max_ep_len <=> every env has adopted the newest version
 };
+
+// ---- version store kernels -------------------------------------------------------------------------------------------
+// One workgroup.  Picks the slot the incoming weights go to: the newest slot itself when no env has adopted it yet (nobody
+// can ever act on it again once a newer version exists: a worker pulls whatever the server holds at ITS episode end), else
+// the lowest slot no env acts on.  n_slots >= min(n_envs, max_ep_len) + 2 always leaves one.
+constexpr int VER_MAX_SLOTS = 2048;
+__global__ void __launch_bounds__(1024) k_version_pick(const int *__restrict__ slot, long long n, int n_slots, VerState *vs) {
+    __shared__ int used[VER_MAX_SLOTS];
+    __shared__ int s_free, s_live;
+    for (int j = threadIdx.x; j < n_slots; j += 1024) used[j] = 0;
+    if (threadIdx.x == 0) { s_free = n_slots; s_live = 0; }
+    __syncthreads();
+    for (long long i = threadIdx.x; i < n; i += 1024) used[slot[i]] = 1;
+    __syncthreads();
+    const int newest = vs->newest;
+    for (int j = threadIdx.x; j < n_slots; j += 1024) {
+        if (used[j]) atomicAdd(&s_live, 1);
+        else if (j != newest) atomicMin(&s_free, j);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int target = newest;
+        if (used[newest]) {
+            if (s_free < n_slots) target = s_free;
+            else vs->err = 1;              // sticky: no free slot (the newest one is overwritten: its envs act on fresher weights)
+        }
+        vs->target = target;
+        vs->newest = target;
+        vs->live = s_live;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_version_copy(const float *__restrict__ src, float *__restrict__ vslab, long long vstride,
+                                                      const VerState *__restrict__ vs, long long n4) {
+    float4 *dst = reinterpret_cast<float4 *>(vslab + (long long)vs->target * vstride);
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = s4[i];
+}
+
+// One workgroup: envs grouped by slot (counting sort; the order inside a group is immaterial — rows are computed
+// independently), one VerTile per 32 envs of a group.
+__global__ void __launch_bounds__(1024) k_version_group(const int *__restrict__ slot, long long n, int n_slots, int *__restrict__ perm,
+                                                        VerTile *__restrict__ tiles, VerState *vs) {
+    __shared__ int cnt[VER_MAX_SLOTS], start[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
+    __shared__ int wsum_c[16], wsum_t[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int j = t; j < VER_MAX_SLOTS; j += 1024) cnt[j] = 0;
+    __syncthreads();
+    for (long long i = t; i < n; i += 1024) atomicAdd(&cnt[slot[i]], 1);
+    __syncthreads();
+    // exclusive scans of the group sizes and of the groups' tile counts: two slots per thread, wave scan, wave totals
+    const int c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
+    const int t0 = (c0 + 31) >> 5, t1 = (c1 + 31) >> 5;
+    int sc = c0 + c1, st = t0 + t1;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int uc = __shfl_up(sc, o), ut = __shfl_up(st, o);
+        if (lane >= o) { sc += uc; st += ut; }
+    }
+    if (lane == 63) { wsum_c[w] = sc; wsum_t[w] = st; }
+    __syncthreads();
+    int bc = 0, bt = 0;
+    for (int k = 0; k < w; ++k) { bc += wsum_c[k]; bt += wsum_t[k]; }
+    const int ec = bc + sc - (c0 + c1), et = bt + st - (t0 + t1);   // exclusive prefix of this thread's pair
+    start[2 * t] = ec; start[2 * t + 1] = ec + c0;
+    tstart[2 * t] = et; tstart[2 * t + 1] = et + t0;
+    if (t == 1023) vs->n_tiles = bt + st;
+    __syncthreads();
+    for (int j = t; j < n_slots; j += 1024) {
+        const int c = cnt[j];
+        for (int k = 0; k < ((c + 31) >> 5); ++k) tiles[tstart[j] + k] = VerTile{j, start[j] + 32 * k, c - 32 * k < 32 ? c - 32 * k : 32, 0};
+    }
+    __syncthreads();
+    for (int j = t; j < VER_MAX_SLOTS; j += 1024) cnt[j] = 0;   // reused as the groups' fill cursors
+    __syncthreads();
+    for (long long i = t; i < n; i += 1024) {
+        const int s = slot[i];
+        perm[start[s] + atomicAdd(&cnt[s], 1)] = (int)i;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_version_adopt(int *__restrict__ slot, const uint8_t *__restrict__ ended, long long n, const VerState *vs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && ended[i]) slot[i] = vs->newest;
+}
 
 extern "C" {
 
@@ -1903,6 +1996,8 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
         c2.batch = 32;
         h->direct = direct_ok(c2) && max_rows % 32 == 0 && max_rows <= 32 * 4095 && cfg->obs_dim + 1 <= 13;
         h->dslab = nullptr; h->segs_dd = nullptr;
+        h->n_slots = 0; h->vslab = nullptr; h->slot_d = h->perm_d = nullptr; h->vtiles_d = nullptr; h->vs_d = nullptr;
+        h->steps_since_install = 1ll << 40;
     }
     if (h->direct) {
         h->Ld = make_layout(*cfg, true, true);
@@ -1926,6 +2021,7 @@ int ddrl_actor_destroy(ddrl_actor_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
     (void)hipFree(h->dslab); (void)hipFree(h->segs_dd);
+    (void)hipFree(h->vslab); (void)hipFree(h->slot_d); (void)hipFree(h->perm_d); (void)hipFree(h->vtiles_d); (void)hipFree(h->vs_d);
     (void)hipFree(h->pi_p); (void)hipFree(h->H1); (void)hipFree(h->H2); (void)hipFree(h->segs_d);
     delete h;
     return DDRL_OK;
@@ -1936,6 +2032,61 @@ int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream
     ddrl::DeviceGuard g(h->device);
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_pi_d, h->pi_p, nullptr, 1);
     if (h->direct) k_pack<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_dd, flat_pi_d, h->pi_d, nullptr, 1);
+    if (h->n_slots > 0) {   // version store: the new weights become the newest version, in a slot no env acts on
+        hipStream_t s = ddrl::as_stream(stream);
+        k_version_pick<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->vs_d);
+        k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
+        h->steps_since_install = 0;
+    }
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(h->direct, "version store needs the direct-operand policy (shape outside the envelope)");
+    DDRL_REQUIRE(n_slots >= 2 && n_slots <= VER_MAX_SLOTS, "n_slots outside [2, 2048]");
+    DDRL_REQUIRE(h->n_slots == 0, "version store already enabled");
+    ddrl::DeviceGuard g(h->device);
+    const long long np = ((long long)h->Ld.total_int + 2048 + 63) & ~63ll;   // as the policy part of dslab (incl. the guard)
+    hipError_t e = dev_alloc(&h->vslab, (size_t)np * n_slots + 2048);
+    if (e == hipSuccess) e = dev_alloc(&h->slot_d, (size_t)h->max_rows + 64);
+    if (e == hipSuccess) e = dev_alloc(&h->perm_d, (size_t)h->max_rows + 64);
+    if (e == hipSuccess) e = dev_alloc(&h->vtiles_d, (size_t)(h->max_rows / 32 + n_slots) + 16);
+    if (e == hipSuccess) e = dev_alloc(&h->vs_d, 2);
+    if (e != hipSuccess) {
+        ddrl::set_error("hipMalloc failed in ddrl_actor_versions_enable (%d slots of %lld floats): %s", n_slots, np, hipGetErrorString(e));
+        return DDRL_ERR_NOMEM;
+    }
+    hipStream_t s = ddrl::as_stream(stream);
+    // (dev_alloc zero-fills: every env on slot 0, newest = 0) slot 0 = the weights the actor holds now
+    h->vstride = np;
+    h->n_slots = n_slots;
+    k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
+    h->steps_since_install = 1ll << 40;
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_actor_versions_state(ddrl_actor_t *h, int32_t *slot_of_env_d, int32_t *state_h, void *stream) {
+    DDRL_REQUIRE(h != nullptr && h->n_slots > 0, "version store not enabled");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    if (slot_of_env_d) DDRL_HIP_CHECK(hipMemcpyAsync(slot_of_env_d, h->slot_d, (size_t)h->max_rows * sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (state_h) {
+        VerState vs;
+        DDRL_HIP_CHECK(hipMemcpyAsync(&vs, h->vs_d, sizeof(vs), hipMemcpyDeviceToHost, s));
+        DDRL_HIP_CHECK(hipStreamSynchronize(s));
+        state_h[0] = vs.newest; state_h[1] = vs.live; state_h[2] = vs.n_tiles; state_h[3] = vs.err;
+    }
+    return DDRL_OK;
+}
+
+int ddrl_actor_versions_adopt(ddrl_actor_t *h, const uint8_t *ended_d, int64_t n, void *stream) {
+    DDRL_REQUIRE(h != nullptr && h->n_slots > 0 && ended_d != nullptr, "version store not enabled / NULL mask");
+    DDRL_REQUIRE(n > 0 && n <= h->max_rows, "n outside [1, max_rows]");
+    ddrl::DeviceGuard g(h->device);
+    k_version_adopt<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->slot_d, ended_d, n, h->vs_d);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
@@ -1979,7 +2130,7 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
 #ifdef DDRL_STAMPS
 unsigned long long *g_actor_st = nullptr;
 #endif
-int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
+int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream, int versioned) {
     DDRL_REQUIRE(h != nullptr && h->direct, "actor has no direct-operand policy (shape outside the envelope)");
     DDRL_REQUIRE(n > 0 && n % 32 == 0 && n <= h->max_rows, "n must be a positive multiple of 32 within max_rows");
     ddrl::DeviceGuard g(h->device);
@@ -1995,8 +2146,25 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream) {
     A.st = g_actor_st;
 #endif
     const int D1 = c.obs_dim + 1, ns = D1 <= 8 ? 4 : 4 + (D1 - 8 + 1) / 2;
-    const unsigned grid = (unsigned)(n / 32) * A.ngroups;
     hipStream_t s = ddrl::as_stream(stream);
+    if (versioned) {
+        // envs grouped by the policy version they act on; a row tile = up to 32 envs of one version.  The launch covers the worst
+        // case (every live version leaves one partial tile), surplus workgroups leave at once.
+        DDRL_REQUIRE(h->n_slots > 0 && n == h->max_rows, "versioned forward: store not enabled, or n != max_rows");
+        k_version_group<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d);
+        const long long vt = n / 32 + (h->n_slots < n ? h->n_slots : n);
+        A.W1 = h->vslab + L.pi_W1; A.W2p = A.W1 + ((c.hidden1 + 31) & ~31) * 16;
+        A.b2 = h->vslab + L.pi_b2; A.wmu = h->vslab + L.pi_Wmu; A.wls = h->vslab + L.pi_Wls;
+        A.vtiles = h->vtiles_d; A.perm = h->perm_d; A.vs = h->vs_d; A.vstride = h->vstride;
+        const unsigned vgrid = (unsigned)vt * A.ngroups;
+        if (ns == 4) k_actor_fwd<4, 2, true><<<vgrid, 256, 0, s>>>(A);
+        else if (ns == 5) k_actor_fwd<5, 2, true><<<vgrid, 256, 0, s>>>(A);
+        else if (ns == 6) k_actor_fwd<6, 2, true><<<vgrid, 256, 0, s>>>(A);
+        else k_actor_fwd<7, 2, true><<<vgrid, 256, 0, s>>>(A);
+        DDRL_LAUNCH_CHECK();
+        return DDRL_OK;
+    }
+    const unsigned grid = (unsigned)(n / 32) * A.ngroups;
     if (grid > 256) {   // more than one workgroup per CU: the two-per-CU register budget
         if (ns == 4) k_actor_fwd<4, 2><<<grid, 256, 0, s>>>(A);
         else if (ns == 5) k_actor_fwd<5, 2><<<grid, 256, 0, s>>>(A);
@@ -2016,6 +2184,9 @@ ddrl_actor_rollout_view ddrl_actor_internal_view(ddrl_actor *h) {
     ddrl_actor_rollout_view v{};
     if (!h || !h->direct) return v;
     v.ok = 1; v.obs = h->obs_d; v.hp = h->hp_d; v.bmu = h->pi_d + h->Ld.pi_bmu; v.bls = h->pi_d + h->Ld.pi_bls;
+    v.n_slots = h->n_slots; v.slot = h->slot_d; v.vs = h->vs_d; v.vstride = h->vstride;
+    v.vbmu = h->n_slots ? h->vslab + h->Ld.pi_bmu : nullptr; v.vbls = h->n_slots ? h->vslab + h->Ld.pi_bls : nullptr;
+    v.steps_since_install = &h->steps_since_install;
     v.obs_dim = h->cfg.obs_dim; v.act = h->cfg.act_dim; v.nt2 = (h->cfg.hidden2 + 31) / 32; v.max_rows = h->max_rows;
     v.scale = (float)h->cfg.act_scale; v.device = h->device;
     return v;

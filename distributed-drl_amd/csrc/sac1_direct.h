@@ -548,10 +548,19 @@ static void launch_dfwd(const DFHead &d, const DFArgs &F_, hipStream_t s) {
 // Same summation orders as k_dfwd (block order inside a wave, waves 0..3 in the combine, columns 0..31 in the head dot).
 // ==========================================================================================
 constexpr int ANT = 5;
+// A row tile of the versioned forward: `count` (<= 32) envs perm[base .. base + count) that all act on policy version `slot`.
+struct VerTile { int slot, base, count, pad; };
+// Device-side state of an actor's version store (exact per-env weight adoption, example/dsac.py:127-130).
+struct VerState { int newest, target, n_tiles, err, live, pad[3]; };
 struct ActFwdArgs {
     const float *W1, *W2p, *b2, *wmu, *wls, *obs;
     float *hp;
     int rows, K, Np, h2, d0, act, tiles_n, ngroups;
+    // VER: the weight pointers above are those of version slot 0; slot s lives vstride floats further per slot
+    const VerTile *vtiles;
+    const int *perm;
+    const VerState *vs;
+    long long vstride;
 #ifdef DDRL_STAMPS
     unsigned long long *st;  // dev harness (tools/actor_bench.hip): [workgroup][wave][32] cycle stamps
 #endif
@@ -565,7 +574,7 @@ struct ActFwdArgs {
 // workgroups: 4096 rows, 16.4 us); 2 -> 256 registers with 64 spilled to scratch, two workgroups per CU: +1.8 us on a single round, but
 // 8192 rows (config 4's rollout ranks: 512 workgroups) take one round instead of two (rollout-only 195 -> 208 M env-steps/s, 16 384
 // rows 227 -> 253 M).
-template <int NS, int OCC>
+template <int NS, int OCC, bool VER = false>
 __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     // rows of 36 floats: 16-byte aligned (b128 LDS reads) and conflict-free for 16 lanes reading 4 words each
     __shared__ __attribute__((aligned(16))) float red[2][4][32][36];
@@ -579,7 +588,17 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     const int rt = blockIdx.x / a.ngroups, grp = blockIdx.x - rt * a.ngroups;
     const int gbase = a.tiles_n / a.ngroups, gextra = a.tiles_n % a.ngroups;
     const int ntiles = gbase + (grp < gextra ? 1 : 0);
-    const int m0 = rt * 32, nt0 = grp * gbase + (grp < gextra ? grp : gextra);
+    int m0 = rt * 32;
+    const int nt0 = grp * gbase + (grp < gextra ? grp : gextra);
+    // VER: row tile rt of the grouping kernel's table — its envs (through perm) and its version's weights
+    int vcount = 32;
+    if (VER) {
+        if (rt >= a.vs->n_tiles) return;   // the launch covers the worst case (n / 32 + live versions); block-uniform
+        const VerTile vt = a.vtiles[rt];
+        const long long off = (long long)vt.slot * a.vstride;
+        a.W1 += off; a.W2p += off; a.b2 += off; a.wmu += off; a.wls += off;
+        m0 = vt.base; vcount = vt.count;
+    }
     const int K = a.K, Np = a.Np, d0 = a.d0;
     const int nblk = (K + 31) >> 5, bs = nblk >> 2, rem = nblk & 3;
     const int nb = bs + (w >= 4 - rem ? 1 : 0);
@@ -588,7 +607,8 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     // ---- loads in the order of need: the input rows, the layer-1 columns of this wave's blocks, the W2 groups of tile 0
     float xin[7];
     {
-        const long long row = m0 + l31 < a.rows ? m0 + l31 : a.rows - 1;
+        long long row = m0 + l31 < a.rows ? m0 + l31 : a.rows - 1;
+        if (VER) row = a.perm[m0 + (l31 < vcount ? l31 : vcount - 1)];
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
             const int d = d_slot(s, h);
@@ -721,7 +741,9 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
                     const float4 x = *reinterpret_cast<const float4 *>(&red2[t & 1][r][4 * c4]), y = *reinterpret_cast<const float4 *>(&s_wh[t][cg][4 * c4]);
                     sum = fmaf(x.x, y.x, sum); sum = fmaf(x.y, y.y, sum); sum = fmaf(x.z, y.z, sum); sum = fmaf(x.w, y.w, sum);
                 }
-                if (m0 + r < a.rows) a.hp[((long long)cg * a.rows + m0 + r) * DNT + nt0 + t] = sum;
+                if (VER) {
+                    if (r < vcount) a.hp[((long long)cg * a.rows + a.perm[m0 + r]) * DNT + nt0 + t] = sum;
+                } else if (m0 + r < a.rows) a.hp[((long long)cg * a.rows + m0 + r) * DNT + nt0 + t] = sum;
             }
             AST(7 + 5 * t);
         }

@@ -255,7 +255,14 @@ def worker_test_sac1(ps, replay_buffer, opt, make_env=None, make_agent=None, log
 # ------------------------------------------------------------------------------------------
 class RolloutDevice:
     """State of one vectorised rollout worker: `opt.num_envs` envs, one Actor, a local replay
-    shard and a ParameterServer (or a comm.ParamBroadcast on multi-GPU runs)."""
+    shard and a ParameterServer (or a comm.ParamBroadcast on multi-GPU runs).
+
+    Weight adoption (`opt.adopt`, default "episode"): the reference runs one worker per env and each pulls the server's weights at
+    ITS OWN episode end (example/dsac.py:127-130), so at any time the envs act on different versions.  "episode" reproduces that
+    exactly on the fused path: the actor keeps min(num_envs, max_ep_len) + 2 resident policy versions, pull() stores what the
+    server holds as the newest one, and the env-step kernel moves an env to it where that env's episode ends — the vector of envs
+    is then indistinguishable from num_envs reference workers stepped in lock step.  "step" (and shapes outside the fused
+    envelope) swaps the weights of every env at the next vector step: never staler than the reference, not identical to it."""
 
     def __init__(self, ps, replay_buffer, opt, worker_index=0):
         import torch
@@ -272,7 +279,12 @@ class RolloutDevice:
         self.act = torch.empty(opt.num_envs, 2, dtype=torch.float32, device=self.env.device)
         self._fused = None if getattr(opt, "fused_rollout", True) else False
         self._fused_live = False
+        self.adopt = getattr(opt, "adopt", "episode")
+        assert self.adopt in ("episode", "step"), self.adopt
+        self._versions = False
         self.pull()
+        if self.adopt == "episode" and self._fused is None:
+            self._fused_ready()   # the version store starts from the initial pull (dsac.py:88-90), before any step
 
     def pull(self):
         """ps.pull(keys) + agent.set_weights when the server has something newer."""
@@ -295,6 +307,10 @@ class RolloutDevice:
             if ok:
                 ok = self.actor._lib.ddrl_rollout_begin(self.env._h, self.actor._h, _lib.stream_ptr()) == 0
             self._fused, self._fused_live = ok, ok
+            if ok and self.adopt == "episode" and self.actor.max_rows == self.env.n:
+                # every env on the weights of the initial pull; later pulls become versions adopted at episode ends
+                self.actor.enable_versions(min(2048, min(self.env.n, int(self.opt.max_ep_len)) + 2))
+                self._versions = True
         return self._fused
 
     def step(self, n_steps=1):
@@ -304,6 +320,8 @@ class RolloutDevice:
         random-action phase (t <= start_steps) and shapes outside the envelope: get_action / env.step / store launches."""
         from . import _lib
         env = self.env
+        if self._versions:
+            self.pull()   # what the server holds NOW is what an env ending its episode in this step pulls (dsac.py:127-130)
         if self.t > self.opt.start_steps and self._fused_ready():
             if not self._fused_live:   # the unfused path has stepped the envs since: refresh the actor's observation rows
                 _lib.check(self.actor._lib.ddrl_rollout_begin(env._h, self.actor._h, _lib.stream_ptr()))
@@ -313,7 +331,8 @@ class RolloutDevice:
                                                 _lib.dptr(env.obs), _lib.stream_ptr()))
             a._noise_ctr += int(n_steps) * env.n * a.cfg.act_dim
             self.t += int(n_steps)
-            self.pull()
+            if not self._versions:
+                self.pull()
             return
         if n_steps > 1:
             for _ in range(int(n_steps)):
@@ -325,10 +344,13 @@ class RolloutDevice:
             self.actor.get_actions(self.o, out=self.act)
         else:
             env.sample_actions(out=self.act)
-        o2, r, d, _, _ = env.step(self.act)
+        o2, r, d, _, ended = env.step(self.act)
+        if self._versions:
+            self.actor.adopt_where_ended(ended)
         self.rb.store_batch(self.o, self.act, r, o2, d)
         self.t += 1
-        self.pull()
+        if not self._versions:
+            self.pull()
 
 
 class WindowQueue:

@@ -393,6 +393,22 @@ int ddrl_env_step_wrapped(ddrl_env_t *h, float *act_d, float act_noise, float ob
  * DDRL_ERR_BAD_ARG; the unfused sequence is ddrl_actor_act + ddrl_env_step + ddrl_replay_store.
  * n_steps >= 1 vector steps are issued back to back (step k draws noise elements noise_ctr + k*n*act ...).
  * act_out_d[n,2], next_obs_out_d[n,8]: optional mirrors of the LAST step (may be NULL). */
+/* Exact per-env weight adoption for a vectorised rollout worker.  A reference worker pulls the server's weights at ITS OWN episode end
+ * (example/dsac.py:127-130; algos/sac1/sac1.py:209-213) and acts on them until its next one, so n workers hold up to
+ * min(n, max_ep_len) + 1 different versions at a time.  ddrl_actor_versions_enable gives the actor `n_slots` resident copies of the
+ * policy (n_slots >= min(n_envs, max_ep_len) + 2 never runs out; [2, 2048]) and a slot word per env (all on slot 0 = the current
+ * weights).  From then on
+ *   ddrl_actor_set_weights  stores the incoming vector as the NEWEST version in a slot no env acts on (the newest slot itself while
+ *                           no env has adopted it) — a pull that some env's future episode end will see;
+ *   ddrl_rollout_step       evaluates every env against the version in its slot (envs grouped by slot on the device, one row tile
+ *                           per 32 envs of a version) and moves an env to the newest version where its episode ends;
+ *   ddrl_actor_versions_adopt  does that move for steps taken outside the fused path (ended_d[n]: uint8 mask of ddrl_env_step).
+ * ddrl_actor_act keeps evaluating the newest weights.  ddrl_actor_versions_state: slot_of_env_d[max_rows] (device, nullable) and
+ * state_h[4] = {newest slot, slots in use at the last install, row tiles of the last versioned launch, sticky out-of-slots flag}
+ * (host, nullable; synchronises `stream`). */
+int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream);
+int ddrl_actor_versions_state(ddrl_actor_t *h, int32_t *slot_of_env_d, int32_t *state_h, void *stream);
+int ddrl_actor_versions_adopt(ddrl_actor_t *h, const uint8_t *ended_d, int64_t n, void *stream);
 int ddrl_rollout_begin(ddrl_env_t *h, ddrl_actor_t *actor, void *stream);
 int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay, int32_t n_steps, uint32_t noise_seed,
                       uint64_t noise_ctr, int deterministic, float *act_out_d, float *next_obs_out_d, void *stream);

@@ -45,6 +45,20 @@ def main():
     assert torch.equal(g, g0)
     comm.barrier()
     assert comm.allreduce_max(3.5, device=dev) == 3.5 and comm.allreduce_sum(2.0, device=dev) == 2.0
+    # ---- the block transfer of configs 3/4 (partition._send / partition._Recv: RCCL send / recv) -----------------------------
+    # world size 1 has no remote owner; RCCL accepts a send to self when the matching receive sits in the same group call, so
+    # one block of 64 packed batches goes owner -> learner through the very functions PartitionedRun uses
+    from torch.distributed.distributed_c10d import _coalescing_manager
+    nf = partition.batch_floats(8, 2, 256)
+    blk = torch.randn(64 * nf, device=dev)
+    region = torch.zeros_like(blk)
+    with _coalescing_manager(device=dev, async_ops=True) as cm:
+        partition._send(blk, 0)
+        rcv = partition._Recv(region, 0)
+    cm.wait()
+    assert rcv.stage is None                                   # device buffers straight into RCCL: no host staging
+    torch.cuda.synchronize()
+    assert torch.equal(region, blk)
     print("rccl comm ok", flush=True)
     if what == "comm":
         return

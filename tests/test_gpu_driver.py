@@ -393,6 +393,7 @@ def test_vectorised_rollout_never_acts_on_weights_older_than_the_reference_worke
     n, steps = 64, 40
     opt = HyperParameters()
     opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, 7, 3   # time limit 7: every env ends episodes all the time
+    opt.adopt = "step"                                                    # the whole-vector swap; "episode" (default): the tests below
     keys, vals = Learner(opt).get_weights()
     code = lambda v: 0.08 * (v + 1)
 
@@ -431,3 +432,117 @@ def test_vectorised_rollout_never_acts_on_weights_older_than_the_reference_worke
         if s in push_after:
             ps.push(keys, weights(push_after[s]))
     assert (last_end >= steps - 8).all() and roll.env.stats()[0] >= n * (steps // 7 - 1)    # the episode ends the bound is about did happen
+
+
+def _coded_weights(keys, vals, v):
+    """Policy version v as a recognisable action: zero kernels, mu bias 0.08 (v + 1), log_std at its floor."""
+    out = []
+    for k, w in zip(keys, vals):
+        w = np.zeros_like(w)
+        if "pi" in k and k.endswith("dense_2/bias"):
+            w[:] = 0.08 * (v + 1)
+        if "pi" in k and k.endswith("dense_3/bias"):
+            w[:] = -40.0
+        out.append(w)
+    return out
+
+
+@pytest.mark.parametrize("n,limit,steps", [(64, 7, 60), (160, 23, 90)])
+def test_vectorised_rollout_equals_n_reference_workers_in_the_weights_each_env_acts_on(n, limit, steps):
+    """Bar (1) for the vectorised rollout: the reference runs one worker per env and each pulls the server's weights at ITS OWN
+    episode end (example/dsac.py:127-130: o = env.reset(); weights = ps.pull(keys); agent.set_weights(keys, weights)) and acts on
+    them until its next one.  RolloutDevice(adopt="episode") must act, for every env and every step, on EXACTLY the version that
+    env's own worker_rollout would hold: the one the server held when the env's last episode ended (the initial pull before its
+    first).  Bias-coded versions make the version behind every stored action readable; pushes land between vector steps, bursts
+    of them, long pauses (the single-version fast path), and up to min(n, limit) + 1 versions are live at once."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    from distributed_drl_amd.workers import RolloutDevice
+    opt = HyperParameters()
+    opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, limit, 3
+    keys, vals = Learner(opt).get_weights()
+    ps = ddrl.ParameterServer(keys, _coded_weights(keys, vals, 0))
+    rb = ddrl.ReplayBufferSAC1(8, 2, n * steps, seed=0)
+    roll = RolloutDevice(ps, rb, opt)
+    assert roll._versions and roll.actor.n_slots == min(n, limit) + 2
+    rs = np.random.RandomState(5)
+    # version pushed right after step s: a burst at the start, one every step for a while, then nothing for > limit steps, then more
+    push_after, v = {}, 0
+    for s in range(steps):
+        if s < 12 or (20 <= s < 20 + limit + 3) or (s >= 20 + 2 * limit + 12 and rs.rand() < 0.4):
+            v += 1
+            push_after[s] = v
+    EPLEN, EPI = 10, 13                                       # csrc/env.hip: per-env episode length / episode counter
+    st0 = roll.env.get_state()
+    st0[EPLEN] = torch.arange(n, device="cuda").float() % limit   # stagger the time limits: episode ends in every step, env by env
+    roll.env.set_state(st0)
+    epi_before = roll.env.get_state()[EPI].cpu().numpy().copy()
+    holds = np.zeros(n, int)                                  # the version env i's reference worker holds
+    newest, max_live = 0, 0
+    for s in range(steps):
+        roll.step()
+        acts = rb.rings()["acts_buf"][s * n:(s + 1) * n].cpu().numpy()
+        used = np.rint(np.arctanh(np.clip(acts[:, 0], -0.9999, 0.9999)) / 0.08 - 1).astype(int)
+        assert np.allclose(acts[:, 0], np.tanh(0.08 * (used + 1)), atol=1e-6)
+        np.testing.assert_array_equal(used, holds, err_msg="step %d" % s)
+        epi_after = roll.env.get_state()[EPI].cpu().numpy()
+        holds[epi_after > epi_before] = newest               # episode ended in step s: reset, pull what the server holds
+        epi_before = epi_after.copy()
+        max_live = max(max_live, len(set(holds)))
+        if s in push_after:
+            newest = push_after[s]
+            ps.push(keys, _coded_weights(keys, vals, newest))
+    slots, st = roll.actor.version_state()
+    assert not st["out_of_slots"] and max_live >= min(limit, 6)
+    assert roll.env.stats()[0] >= n * (steps // limit - 1)
+
+
+def test_versioned_rollout_actions_match_each_versions_own_policy():
+    """The same with real (random) policies: every env's stored action equals Actor.get_action of THAT env's version on the
+    observation it acted on, with the fused step's own noise element — within float32 of the row-major policy kernels."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import Actor, HyperParameters, Learner
+    from distributed_drl_amd.workers import RolloutDevice
+    n, limit, steps = 96, 9, 30
+    opt = HyperParameters()
+    opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, limit, 11
+    keys, vals = Learner(opt).get_weights()
+    rs = np.random.RandomState(2)
+
+    def version(v):
+        return [(w + (0.3 * rs.standard_normal(w.shape)).astype(np.float32) * (0.2 if w.ndim == 2 else 1.0)) for w in vals]
+    vers = {0: version(0)}
+    ps = ddrl.ParameterServer(keys, vers[0])
+    rb = ddrl.ReplayBufferSAC1(8, 2, n * steps, seed=0)
+    roll = RolloutDevice(ps, rb, opt)
+    assert roll._versions
+    scratch = Actor(opt, max_rows=n, index=99)
+    EPLEN, EPI = 10, 13
+    st0 = roll.env.get_state()
+    st0[EPLEN] = torch.arange(n, device="cuda").float() % limit
+    roll.env.set_state(st0)
+    epi_before = roll.env.get_state()[EPI].cpu().numpy().copy()
+    holds, newest = np.zeros(n, int), 0
+    lib = _lib.load()
+    for s in range(steps):
+        obs = roll.env.obs.clone()
+        ctr = roll.actor._noise_ctr
+        roll.step()
+        eps = torch.empty(n, 2, dtype=torch.float32, device="cuda")
+        _lib.check(lib.ddrl_normal_fill(_lib.dptr(eps), n * 2, roll.actor._noise_seed, ctr, _lib.stream_ptr()))
+        acts = rb.rings()["acts_buf"][s * n:(s + 1) * n]
+        np.testing.assert_array_equal(rb.rings()["obs1_buf"][s * n:(s + 1) * n].cpu().numpy(), obs.cpu().numpy())
+        for v in sorted(set(holds)):
+            rows = torch.from_numpy(np.nonzero(holds == v)[0]).cuda()
+            scratch.set_weights(keys, vers[v])
+            want = scratch.get_actions(obs[rows], eps=eps[rows])
+            np.testing.assert_allclose(acts[rows].cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5, err_msg="step %d version %d" % (s, v))
+        epi_after = roll.env.get_state()[EPI].cpu().numpy()
+        holds[epi_after > epi_before] = newest
+        epi_before = epi_after.copy()
+        if s % 2 == 0:
+            newest += 1
+            vers[newest] = version(newest)
+            ps.push(keys, vers[newest])
+    assert len(set(holds)) >= 3
