@@ -452,7 +452,48 @@ def config5_stages(args, d):
                                                         "K = 28 224 layer-1 GEMMs (MFMA-bound), not the 231 MB gather (HBM-bound), set the rate" % (cap * T5 / 1e9)}
     except Exception as e:  # noqa  (an out-of-memory box must not lose the headline line)
         out["config5_gather"] = dict(out.get("config5_gather", {}), error=str(e)[:200])
-    del rb5, l5
+    del rb5
+    torch.cuda.empty_cache()
+    # config 5 at its STATED capacity: 4 M transitions on the one GPU as the opt-in compact ring (uint8 observations behind the float32
+    # surface, lossless for integer-valued pixels; algos/dqn/train.py:43-52 x 4 M = 903 GB as float32, 226 GB compact)
+    rbc = None
+    try:
+        free_b, _ = torch.cuda.mem_get_info()
+        capc = 4 * 10 ** 6
+        if args.cfg5_capacity > 0 or free_b < 2 * capc * obs_dim + 12 * capc + (4 << 30):
+            capc = max(4096, min(capc, int(args.cfg5_capacity) if args.cfg5_capacity > 0 else int(0.85 * free_b / (2 * obs_dim + 12))) // 2048 * 2048)
+
+        class O5C:
+            pass
+        O5C.obs_dim, O5C.buffer_size, O5C.batch_size, O5C.save_dir = obs_dim, capc, B5, "."
+        rbc = d.ReplayBufferDQN(O5C, 0, seed=0, compact_obs=True)
+        z = torch.zeros(2048, device="cuda")
+        t0 = time.perf_counter()
+        for s0 in range(0, capc, 2048):
+            n = min(2048, capc - s0)
+            x = torch.randint(0, 256, (n, obs_dim), device="cuda", generator=g).float()
+            rbc.store_batch(x, z[:n], z[:n], x, z[:n])
+        del x
+        rbc.check()
+        torch.cuda.synchronize()
+        t_fill = time.perf_counter() - t0
+        t_gc = timed(lambda: rbc.sample_batch_device(B5), 64)
+        moved = B5 * (2 * obs_dim + 12 + 2 * 4 * obs_dim + 12 + 4)      # uint8 rows + three scalars read, float32 batch written, index read
+        out["config5_gather_compact"] = {"batch": B5, "ring_transitions": capc, "ring_GB": capc * (2 * obs_dim + 12) / 1e9, "us": t_gc * 1e6,
+                                         "fill_s": t_fill, "bytes_moved_per_batch": moved, "GBps": moved / t_gc / 1e9,
+                                         "frac_of_hbm_peak": moved / t_gc / 1e9 / PEAK_HBM_GBPS,
+                                         "delivered_float32_GBps": B5 * (2 * T5 + 4) / t_gc / 1e9,
+                                         "what": "sample_batch(512) out of the 4 M-transition compact ring (uint8 observations, float32 batch): "
+                                                 "config 5's stated replay capacity on one MI355X; results bit-identical to the float32 ring's on "
+                                                 "integer-valued pixels (tests/test_gpu_replay.py)"}
+        if l5 is not None:
+            def iteration_c():
+                l5.train(rbc.sample_batch_device(B5), 0)
+            t_ic = timed(iteration_c, 20, warm=3)
+            out["config5_learner_iteration_compact"] = {"ms": t_ic * 1e3, "iterations_per_s": 1.0 / t_ic, "sample_ms": t_gc * 1e3}
+    except Exception as e:  # noqa
+        out["config5_gather_compact"] = {"error": str(e)[:200]}
+    del rbc, l5
     torch.cuda.empty_cache()
     return out
 

@@ -15,7 +15,9 @@ DDRL_ERR_EMPTY_BUFFER = -2
 DDRL_ERR_HIP = -3
 DDRL_ERR_NOMEM = -4
 DDRL_ERR_UNSUPPORTED = -5
+DDRL_ERR_NOT_REPRESENTABLE = -6
 DDRL_REPLAY_ACTS_1D = 1
+DDRL_REPLAY_U8_OBS = 2
 DDRL_ENV_STATE_FIELDS = 32
 SAC1_STAGES = 12
 DQN_STAGES = 9   # include/ddrl.h: DDRL_DQN_STAGES
@@ -73,6 +75,9 @@ SIGNATURES = {
     "ddrl_replay_counts": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), _P]),
     "ddrl_replay_buffers": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P)]),
     "ddrl_replay_set_counts": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P]),
+    "ddrl_replay_create_typed": (c_int, [POINTER(_P), c_int, c_int64, c_int32, POINTER(c_int32), _P, c_int64, c_int64]),
+    "ddrl_replay_rows_export": (c_int, [_P, c_int32, c_int64, c_int64, _P, _P]),
+    "ddrl_replay_rows_import": (c_int, [_P, c_int32, c_int64, c_int64, _P, _P]),
     "ddrl_replay_mt_state": (c_int, [_P, _P, POINTER(c_int32), _P]),
     "ddrl_ps_create": (c_int, [POINTER(_P), c_int, c_int64]),
     "ddrl_ps_destroy": (c_int, [_P]),
@@ -178,7 +183,7 @@ def check(rc):
     msg = load().ddrl_last_error().decode("utf-8", "replace")
     if rc == DDRL_ERR_EMPTY_BUFFER:
         raise ValueError(msg or "high <= 0")  # what np.random.randint(0, 0, n) raises in the reference
-    if rc == DDRL_ERR_BAD_ARG:
+    if rc == DDRL_ERR_BAD_ARG or rc == DDRL_ERR_NOT_REPRESENTABLE:
         raise ValueError("ddrl: " + msg)
     if rc == DDRL_ERR_NOMEM:
         raise MemoryError("ddrl: " + msg)

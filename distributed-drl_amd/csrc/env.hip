@@ -616,6 +616,7 @@ int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay,
     const ddrl_replay_dev::SamplerView rv = ddrl_replay_sampler_view(replay);
     DDRL_REQUIRE(rv.ring.n_arr == 5 && rv.ring.w[0] == 8 && rv.ring.w[1] == 8 && rv.ring.w[2] == 2 && rv.ring.w[3] == 1 && rv.ring.w[4] == 1,
                  "replay row shape must be (obs1[8], obs2[8], acts[2], rews, done)");
+    DDRL_REQUIRE(!rv.ring.kind[0] && !rv.ring.kind[1], "the fused rollout step stores into float32 rings only (not a compact uint8 ring)");
     DDRL_REQUIRE(n_steps >= 1, "n_steps must be >= 1");
     ddrl::DeviceGuard g(h->device);
     RolloutArgs a{};

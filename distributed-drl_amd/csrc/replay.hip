@@ -36,6 +36,43 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, Sto
     // (64-bit div/mod per element made this kernel 10x slower than the copy it is).
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ring.kind[which] == 1) {
+        // compact array: 16 float32 in -> 16 bytes out per lane (4 when the row is not a whole number of 16-element groups);
+        // a value that does not survive the round trip (not an integer in [0, 255], NaN) raises the sticky error — the ring
+        // is opt-in for integer-valued pixels and must never change a value silently
+        unsigned char *d8 = reinterpret_cast<unsigned char *>(dst);
+        const int G = ((width & 15) == 0 && aligned16(dst, src)) ? 16 : 1;
+        const int wg = width / G;
+        const long long total = (n - skip) * wg;
+        const long long base_row = (ptr + skip) % cap;
+        bool bad = false;
+        for (long long e = t0; e < total; e += stride) {
+            const long long ri = e / wg;
+            const int c = (int)(e - ri * wg);
+            long long row = base_row + ri;
+            if (row >= cap) row -= cap;
+            const long long so = (skip + ri) * width + (long long)c * G, dof = row * width + (long long)c * G;
+            if (G == 16) {
+                const float4 *s4 = reinterpret_cast<const float4 *>(src + so);
+                const float4 v0 = s4[0], v1 = s4[1], v2 = s4[2], v3 = s4[3];
+                const float f[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+                unsigned u[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned b = (unsigned)(int)fminf(fmaxf(f[k], 0.f), 255.f);
+                    bad |= !((float)b == f[k]);
+                    u[k >> 2] |= b << (8 * (k & 3));
+                }
+                *reinterpret_cast<uint4 *>(d8 + dof) = make_uint4(u[0], u[1], u[2], u[3]);
+            } else {
+                const float f = src[so];
+                const unsigned b = (unsigned)(int)fminf(fmaxf(f, 0.f), 255.f);
+                bad |= !((float)b == f);
+                d8[dof] = (unsigned char)b;
+            }
+        }
+        if (bad) st->error = DDRL_ERR_NOT_REPRESENTABLE;
+    } else {
     const bool v4 = (width & 3) == 0 && aligned16(dst, src);
     const int wv = v4 ? width >> 2 : width;  // row width in vector elements
     const long long total = (n - skip) * wv;
@@ -59,6 +96,7 @@ __global__ void __launch_bounds__(256) k_store(RingState *st, RingPtrs ring, Sto
             if (v4) reinterpret_cast<float4 *>(dst)[dof] = reinterpret_cast<const float4 *>(src)[so];
             else dst[dof] = src[so];
         }
+    }
     }
     // last block to finish advances the cursor (every block has read st->ptr before its ticket)
     __syncthreads();
@@ -169,6 +207,30 @@ __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, co
     const int width = ring.w[j];
     const float *src = ring.a[j] + row * width;
     float *dst = out.a[j] + (long long)b * width;
+    if (ring.kind[j] == 1) {
+        // compact array: one 16-byte load -> four float4 stores per lane, four loads in flight (the row is 28 224 B at config 5)
+        const unsigned char *s8 = reinterpret_cast<const unsigned char *>(ring.a[j]) + row * width;
+        if ((width & 15) == 0 && aligned16(out.a[j], ring.a[j])) {
+            const int w16 = width >> 4;
+            const uint4 *s16 = reinterpret_cast<const uint4 *>(s8);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            auto put = [&](int e, const uint4 v) {
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    d4[4 * e + k] = make_float4((float)(u[k] & 255u), (float)((u[k] >> 8) & 255u), (float)((u[k] >> 16) & 255u), (float)(u[k] >> 24));
+            };
+            int e = tid;
+            for (; e + 3 * 256 < w16; e += 4 * 256) {
+                const uint4 a0 = s16[e], a1 = s16[e + 256], a2 = s16[e + 512], a3 = s16[e + 768];
+                put(e, a0); put(e + 256, a1); put(e + 512, a2); put(e + 768, a3);
+            }
+            for (; e < w16; e += 256) put(e, s16[e]);
+        } else {
+            for (int e = tid; e < width; e += 256) dst[e] = (float)s8[e];
+        }
+        return;
+    }
     if ((width & 3) == 0 && aligned16(out.a[j], ring.a[j])) {
         const int w4 = width >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
@@ -188,6 +250,15 @@ __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, co
 // (or 4-B) element, all rows of an array in one grid-stride sweep — k_gather's workgroup-per-row would be launch-bound.
 __global__ void __launch_bounds__(256) k_gather_small(RingPtrs ring, BatchPtrs out, const long long *__restrict__ idx, int B) {
     const int j = blockIdx.y, width = ring.w[j];
+    if (ring.kind[j] == 1) {
+        const unsigned char *r8 = reinterpret_cast<const unsigned char *>(ring.a[j]);
+        const unsigned total = (unsigned)B * (unsigned)width;
+        for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+            const unsigned b = e / (unsigned)width, c = e - b * (unsigned)width;
+            out.a[j][e] = (float)r8[idx[b] * width + c];
+        }
+        return;
+    }
     const bool v4 = (width & 3) == 0 && aligned16(out.a[j], ring.a[j]);  // packed blocks start arrays at any float offset
     const unsigned wv = v4 ? width >> 2 : width, total = (unsigned)B * wv;
     for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
@@ -196,6 +267,31 @@ __global__ void __launch_bounds__(256) k_gather_small(RingPtrs ring, BatchPtrs o
         if (v4) reinterpret_cast<float4 *>(out.a[j])[e] = reinterpret_cast<const float4 *>(ring.a[j])[so];
         else out.a[j][e] = ring.a[j][so];
     }
+}
+
+// Ring rows [row0, row0 + nrows) of one array as float32 (export) or from float32 (import): the .npy checkpoint of
+// algos/dqn/train.py:82-108 is float32 whatever the storage kind.
+__global__ void __launch_bounds__(256) k_rows_export(RingPtrs ring, int j, long long row0, long long nrows, float *__restrict__ out) {
+    const long long total = nrows * ring.w[j], off = row0 * ring.w[j];
+    const unsigned char *r8 = reinterpret_cast<const unsigned char *>(ring.a[j]);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+        out[e] = ring.kind[j] == 1 ? (float)r8[off + e] : ring.a[j][off + e];
+}
+__global__ void __launch_bounds__(256) k_rows_import(RingState *st, RingPtrs ring, int j, long long row0, long long nrows, const float *__restrict__ src) {
+    const long long total = nrows * ring.w[j], off = row0 * ring.w[j];
+    unsigned char *r8 = reinterpret_cast<unsigned char *>(ring.a[j]);
+    bool bad = false;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const float f = src[e];
+        if (ring.kind[j] == 1) {
+            const unsigned b = (unsigned)(int)fminf(fmaxf(f, 0.f), 255.f);
+            bad |= !((float)b == f);
+            r8[off + e] = (unsigned char)b;
+        } else {
+            ring.a[j][off + e] = f;
+        }
+    }
+    if (bad) st->error = DDRL_ERR_NOT_REPRESENTABLE;
 }
 
 __global__ void k_set_feed(RingState *st, Feed f) { st->feed = f; }
@@ -240,6 +336,10 @@ static int refresh_counts(ddrl_replay *h, hipStream_t s) {
             ddrl::set_error("high <= 0");  // the sampler drew from an empty ring (the reference's ValueError)
             return DDRL_ERR_EMPTY_BUFFER;
         }
+        if (tmp.error == DDRL_ERR_NOT_REPRESENTABLE) {
+            ddrl::set_error("a value stored into a compact (uint8) ring array was not an integer in [0, 255]: the ring holds a clamped/truncated value there");
+            return DDRL_ERR_NOT_REPRESENTABLE;
+        }
         ddrl::set_error("a feed-plan entry was out of range (wrong batch size, region or batch index): that update trained on a stale input set");
         return tmp.error;
     }
@@ -251,6 +351,10 @@ static long long row_floats(const ddrl_replay *h) {
     long long t = 0;
     for (int j = 0; j < h->ring.n_arr; ++j) t += h->ring.w[j];
     return t;
+}
+static bool has_compact(const ddrl_replay *h) {
+    for (int j = 0; j < h->ring.n_arr; ++j) if (h->ring.kind[j]) return true;
+    return false;
 }
 bool ddrl_replay_can_fuse(ddrl_replay_t *h, int64_t batch) {
     const long long bytes = batch * row_floats(h) * (long long)sizeof(float);
@@ -267,7 +371,13 @@ extern "C" {
 
 int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays, const int32_t *widths_h,
                           int64_t steps_inc, int64_t samples_inc) {
+    return ddrl_replay_create_typed(out, device, capacity, n_arrays, widths_h, nullptr, steps_inc, samples_inc);
+}
+
+int ddrl_replay_create_typed(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays, const int32_t *widths_h,
+                             const uint8_t *kinds_h, int64_t steps_inc, int64_t samples_inc) {
     DDRL_REQUIRE(out != nullptr && widths_h != nullptr, "NULL pointer");
+    for (int j = 0; kinds_h && j < n_arrays && j < MAX_ARRAYS; ++j) DDRL_REQUIRE(kinds_h[j] <= 1, "array kind must be 0 (float32) or 1 (uint8)");
     DDRL_REQUIRE(capacity > 0 && capacity <= 0xFFFFFFFFll, "capacity must be in [1, 2^32-1]");
     DDRL_REQUIRE(n_arrays >= 1 && n_arrays <= MAX_ARRAYS, "n_arrays must be in [1, 6]");
     for (int j = 0; j < n_arrays; ++j) DDRL_REQUIRE(widths_h[j] > 0, "row widths must be positive");
@@ -283,7 +393,8 @@ int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int
     hipError_t e = hipSuccess;
     for (int j = 0; j < n_arrays && e == hipSuccess; ++j) {
         h->ring.w[j] = widths_h[j];
-        e = hipMalloc(&h->ring.a[j], (size_t)capacity * widths_h[j] * sizeof(float));
+        h->ring.kind[j] = kinds_h ? kinds_h[j] : 0;
+        e = hipMalloc(&h->ring.a[j], (size_t)capacity * widths_h[j] * (h->ring.kind[j] ? 1 : sizeof(float)));
     }
     if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(RingState));
     h->idx_cap = 1 << 16;
@@ -296,7 +407,7 @@ int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int
     }
     // np.zeros for every ring (example/dsac.py:21-25)
     for (int j = 0; j < n_arrays; ++j)
-        DDRL_HIP_CHECK(hipMemsetAsync(h->ring.a[j], 0, (size_t)capacity * widths_h[j] * sizeof(float), nullptr));
+        DDRL_HIP_CHECK(hipMemsetAsync(h->ring.a[j], 0, (size_t)capacity * widths_h[j] * (h->ring.kind[j] ? 1 : sizeof(float)), nullptr));
     DDRL_HIP_CHECK(hipMemsetAsync(h->state, 0, sizeof(RingState), nullptr));
     k_mt_seed<<<1, 64, 0, nullptr>>>(h->state, 0u);
     DDRL_LAUNCH_CHECK();
@@ -310,7 +421,9 @@ int ddrl_replay_create(ddrl_replay_t **out, int device, int64_t capacity, int ob
     DDRL_REQUIRE(obs_dim > 0 && act_dim > 0, "obs_dim/act_dim must be positive");
     DDRL_REQUIRE(!(flags & DDRL_REPLAY_ACTS_1D) || act_dim == 1, "ACTS_1D needs act_dim == 1");
     const int32_t widths[5] = {obs_dim, obs_dim, act_dim, 1, 1};  // obs1 obs2 acts rews done
-    const int rc = ddrl_replay_create_ex(out, device, capacity, 5, widths, 1, 1);
+    const uint8_t u8 = (flags & DDRL_REPLAY_U8_OBS) ? 1 : 0;
+    const uint8_t kinds[5] = {u8, u8, 0, 0, 0};
+    const int rc = ddrl_replay_create_typed(out, device, capacity, 5, widths, kinds, 1, 1);
     if (rc == DDRL_OK) (*out)->flags = flags;
     return rc;
 }
@@ -360,6 +473,7 @@ int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n,
 int ddrl_replay_store_masked_ex(ddrl_replay_t *h, const float *const *src_h, const uint8_t *mask_d, int64_t n, void *stream) {
     DDRL_REQUIRE(h != nullptr && src_h != nullptr && mask_d != nullptr, "NULL pointer");
     DDRL_REQUIRE(n >= 0 && n < 0x7fffffffll, "n must be in [0, 2^31)");
+    DDRL_REQUIRE(!has_compact(h), "masked store into a compact (uint8) ring is not built");
     if (n == 0) return DDRL_OK;
     StoreSrc srcs{};
     int widest = 1;
@@ -548,6 +662,29 @@ int ddrl_replay_buffers(ddrl_replay_t *h, float **obs1_d, float **obs2_d, float 
     if (acts_d) *acts_d = h->ring.a[2];
     if (rews_d) *rews_d = h->ring.a[3];
     if (done_d) *done_d = h->ring.a[4];
+    return DDRL_OK;
+}
+
+int ddrl_replay_rows_export(ddrl_replay_t *h, int32_t array, int64_t row0, int64_t nrows, float *out_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && out_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(array >= 0 && array < h->ring.n_arr && row0 >= 0 && nrows > 0 && row0 + nrows <= h->ring.capacity, "array / row range out of bounds");
+    ddrl::DeviceGuard g(h->device);
+    long long blocks = (nrows * h->ring.w[array] + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_rows_export<<<(unsigned)blocks, 256, 0, ddrl::as_stream(stream)>>>(h->ring, array, row0, nrows, out_d);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_replay_rows_import(ddrl_replay_t *h, int32_t array, int64_t row0, int64_t nrows, const float *src_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && src_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(array >= 0 && array < h->ring.n_arr && row0 >= 0 && nrows > 0 && row0 + nrows <= h->ring.capacity, "array / row range out of bounds");
+    ddrl::DeviceGuard g(h->device);
+    long long blocks = (nrows * h->ring.w[array] + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_rows_import<<<(unsigned)blocks, 256, 0, ddrl::as_stream(stream)>>>(h->state, h->ring, array, row0, nrows, src_d);
+    DDRL_LAUNCH_CHECK();
+    h->h_dirty = true;   // a value outside uint8 leaves the sticky error: the next host look at the ring reports it
     return DDRL_OK;
 }
 

@@ -42,9 +42,13 @@ constexpr int MAX_ARRAYS = 6;
 // [capacity][w[j]] row-major.  The SAC layouts (example/dsac.py:20-27) are the instance
 // {obs1[obs], obs2[obs], acts[act], rews[1], done[1]}; the n-step window buffer of
 // algos/sac1/sac_ray.py:40-51 is {buffer_o[(Ln+1)*obs], buffer_a[Ln*act], buffer_r[Ln], buffer_d[Ln]}.
+// kind[j] = 1: array j is stored as uint8 (the opt-in COMPACT ring for integer-valued pixel observations, DDRL_REPLAY_U8_OBS):
+// a[j] then points at capacity * w[j] BYTES.  The surface stays float32 — store converts (a value that is not an integer in
+// [0, 255] sets the sticky DDRL_ERR_NOT_REPRESENTABLE), every gather converts back: bit-identical to the float32 ring on such data.
 struct RingPtrs {
     float *a[MAX_ARRAYS];
     int w[MAX_ARRAYS];
+    unsigned char kind[MAX_ARRAYS];
     int n_arr;
     long long capacity;
     long long steps_inc, samples_inc;  // counter increments per store / per sample (sac_ray.py:68,75: num_buffers)
@@ -94,7 +98,15 @@ __device__ __forceinline__ bool aligned16(const void *a, const void *b) {
 }
 
 __device__ __forceinline__ void gather_rows(const float *__restrict__ ring, float *__restrict__ out,
-                                            const unsigned *s_idx, int B, int width, int tid, int nthreads) {
+                                            const unsigned *s_idx, int B, int width, int tid, int nthreads, int kind = 0) {
+    if (kind == 1) {   // compact array: bytes in, float32 out
+        const unsigned char *r8 = reinterpret_cast<const unsigned char *>(ring);
+        for (int e = tid; e < B * width; e += nthreads) {
+            const int b = e / width, c = e - b * width;
+            out[e] = (float)r8[(long long)s_idx[b] * width + c];
+        }
+        return;
+    }
     if ((width & 3) == 0 && aligned16(ring, out)) {
         const int w4 = width >> 2;
         const float4 *r4 = reinterpret_cast<const float4 *>(ring);
@@ -218,7 +230,7 @@ __device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < MAX_ARRAYS; ++j)
-            if (j < ring.n_arr) gather_rows(ring.a[j], out.a[j], s_idx, B, ring.w[j], tid, SAMPLE_THREADS);
+            if (j < ring.n_arr) gather_rows(ring.a[j], out.a[j], s_idx, B, ring.w[j], tid, SAMPLE_THREADS, ring.kind[j]);
     }
 }
 

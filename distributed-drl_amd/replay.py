@@ -24,13 +24,17 @@ class ReplayBuffer:
     _default_batch = 32
     _acts_1d = False
 
-    def __init__(self, obs_dim, act_dim, size, device=None, seed=None):
+    def __init__(self, obs_dim, act_dim, size, device=None, seed=None, compact_obs=False):
+        """compact_obs=True (opt-in): obs1_buf / obs2_buf live as uint8 behind the same float32 surface — for integer-valued pixel
+        observations (config 5: 4 M transitions of 84x84x4 frames = 226 GB instead of 903 GB).  Storing anything that is not an
+        integer in [0, 255] raises ValueError at the next get_counts / sample_batch / check()."""
         _lib.require_gpu()
         self._lib = _lib.load()
         self.obs_dim, self.act_dim, self.max_size = int(obs_dim), int(act_dim), int(size)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.compact_obs = bool(compact_obs)
         h = ctypes.c_void_p()
-        flags = _lib.DDRL_REPLAY_ACTS_1D if self._acts_1d else 0
+        flags = (_lib.DDRL_REPLAY_ACTS_1D if self._acts_1d else 0) | (_lib.DDRL_REPLAY_U8_OBS if self.compact_obs else 0)
         _lib.check(self._lib.ddrl_replay_create(ctypes.byref(h), self.device.index, self.max_size, self.obs_dim,
                                                 self.act_dim, flags))
         self._h = h
@@ -163,14 +167,38 @@ class ReplayBuffer:
     def size(self):
         return self._counts()[1]
 
+    _RING_NAMES = ("obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf")
+
+    def _ring_shapes(self):
+        N = self.max_size
+        return [(N, self.obs_dim), (N, self.obs_dim), (N,) if self._acts_1d else (N, self.act_dim), (N,), (N,)]
+
     def rings(self):
-        """Views of the five rings as torch tensors (device memory owned by the handle)."""
+        """Views of the five rings as torch tensors (device memory owned by the handle).  Compact observation arrays come back
+        as float32 COPIES (rows_export) — the float32 values the reference's arrays would hold."""
         p = [ctypes.c_void_p() for _ in range(5)]
         _lib.check(self._lib.ddrl_replay_buffers(self._h, *[ctypes.byref(x) for x in p]))
-        N = self.max_size
-        shapes = [(N, self.obs_dim), (N, self.obs_dim), (N,) if self._acts_1d else (N, self.act_dim), (N,), (N,)]
-        names = ["obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf"]
-        return {n: _view(ptr.value, s, self.device) for n, ptr, s in zip(names, p, shapes)}
+        out = {}
+        for j, (n, ptr, s) in enumerate(zip(self._RING_NAMES, p, self._ring_shapes())):
+            out[n] = self.rows(j, 0, self.max_size).reshape(s) if (self.compact_obs and j < 2) else _view(ptr.value, s, self.device)
+        return out
+
+    def rows(self, array, row0, nrows):
+        """Ring rows [row0, row0 + nrows) of array 0..4 as a fresh float32 device tensor, whatever the storage kind."""
+        w = int(np.prod(self._ring_shapes()[array][1:])) if len(self._ring_shapes()[array]) > 1 else 1
+        out = torch.empty(int(nrows), w, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_replay_rows_export(self._h, int(array), int(row0), int(nrows), _lib.dptr(out), _lib.stream_ptr()))
+        return out
+
+    def set_rows(self, array, row0, values):
+        values = self._f32(values)
+        w = int(np.prod(self._ring_shapes()[array][1:])) if len(self._ring_shapes()[array]) > 1 else 1
+        nrows = values.numel() // w
+        _lib.check(self._lib.ddrl_replay_rows_import(self._h, int(array), int(row0), int(nrows), _lib.dptr(values), _lib.stream_ptr()))
+
+    def check(self):
+        """Surface the ring's sticky device-side error now (an empty-ring draw inside a graph, a value a compact array cannot hold)."""
+        self._counts()
 
     def mt_state(self):
         key = np.empty(624, dtype=np.uint32)
@@ -194,9 +222,13 @@ class ReplayBufferDQN(ReplayBuffer):
     opt, get_counts -> (learner_steps, actor_steps, size), save/load of the .npy checkpoint."""
     _acts_1d = True
 
-    def __init__(self, opt, buffer_index, device=None, seed=None):
+    CHUNK_ROWS = 4096   # rows per device <-> host transfer of save / load (462 MB of float32 at config 5's row width)
+
+    def __init__(self, opt, buffer_index, device=None, seed=None, compact_obs=None):
+        """compact_obs (default: opt.compact_obs, else False): uint8 storage of the pixel observations behind the float32 surface."""
         self.opt, self.buffer_index = opt, buffer_index
-        super().__init__(opt.obs_dim, 1, opt.buffer_size, device=device, seed=seed)
+        compact = bool(getattr(opt, "compact_obs", False)) if compact_obs is None else bool(compact_obs)
+        super().__init__(opt.obs_dim, 1, opt.buffer_size, device=device, seed=seed, compact_obs=compact)
 
     def store(self, obs, act, rew, next_obs, done, worker_index=None):
         super().store(obs, act, rew, next_obs, done)
@@ -216,8 +248,14 @@ class ReplayBufferDQN(ReplayBuffer):
         — the on-disk format of algos/dqn/train.py:82-90."""
         path = self._ckpt(checkpoint_path)
         os.makedirs(path, exist_ok=True)
-        for name, t in self.rings().items():
-            np.save(os.path.join(path, "%s-%s" % (name, self.buffer_index)), t.cpu().numpy())
+        for j, (name, shape) in enumerate(zip(self._RING_NAMES, self._ring_shapes())):
+            # float32 .npy whatever the storage kind, written chunk by chunk (the arrays do not fit host memory at config 5's size)
+            mm = np.lib.format.open_memmap(os.path.join(path, "%s-%s.npy" % (name, self.buffer_index)), mode="w+", dtype=np.float32, shape=shape)
+            for r0 in range(0, self.max_size, self.CHUNK_ROWS):
+                n = min(self.CHUNK_ROWS, self.max_size - r0)
+                mm[r0:r0 + n] = self.rows(j, r0, n).cpu().numpy().reshape((n,) + shape[1:])
+            mm.flush()
+            del mm
         ptr, size, steps, samples = self._counts()
         np.save(os.path.join(path, "buffer_infos-%s" % self.buffer_index),
                 np.array((ptr, size, self.max_size, steps, samples)))
@@ -225,10 +263,11 @@ class ReplayBufferDQN(ReplayBuffer):
     def load(self, checkpoint_path=None):
         """algos/dqn/train.py:92-108."""
         path = self._ckpt(checkpoint_path)
-        rings = self.rings()
-        for name, t in rings.items():
-            arr = np.load(os.path.join(path, "%s-%s.npy" % (name, self.buffer_index)))
-            t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).reshape(t.shape))
+        for j, name in enumerate(self._RING_NAMES):
+            arr = np.load(os.path.join(path, "%s-%s.npy" % (name, self.buffer_index)), mmap_mode="r")
+            for r0 in range(0, self.max_size, self.CHUNK_ROWS):
+                n = min(self.CHUNK_ROWS, self.max_size - r0)
+                self.set_rows(j, r0, torch.from_numpy(np.array(arr[r0:r0 + n], dtype=np.float32)))
         infos = np.load(os.path.join(path, "buffer_infos-%s.npy" % self.buffer_index))
         _lib.check(self._lib.ddrl_replay_set_counts(self._h, int(infos[0]), int(infos[1]), int(infos[3]),
                                                     int(infos[4]), _lib.stream_ptr()))

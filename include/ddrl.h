@@ -39,7 +39,8 @@ typedef enum {
     DDRL_ERR_EMPTY_BUFFER = -2, /* sample from an empty ring: reference raises ValueError("high <= 0") */
     DDRL_ERR_HIP = -3,
     DDRL_ERR_NOMEM = -4,
-    DDRL_ERR_UNSUPPORTED = -5
+    DDRL_ERR_UNSUPPORTED = -5,
+    DDRL_ERR_NOT_REPRESENTABLE = -6 /* a value stored into a compact (uint8) ring array was not an integer in [0, 255] */
 } ddrl_status;
 
 int ddrl_version(void);
@@ -54,6 +55,12 @@ int ddrl_device_arch(int device, char *buf_h, int buflen);
 typedef struct ddrl_replay ddrl_replay_t;
 
 #define DDRL_REPLAY_ACTS_1D 1u /* algos/dqn/train.py:48: acts_buf is [N] (act_dim must be 1) */
+/* Opt-in COMPACT ring for integer-valued pixel observations (config 5: 84x84x4 frames, algos/dqn/train.py:43-52 at 4 M transitions =
+ * 903 GB as float32): obs1 / obs2 are stored as uint8 — 4 M transitions = 226 GB, one MI355X — behind the unchanged float32
+ * surface.  store converts; a value that is not an integer in [0, 255] raises the sticky DDRL_ERR_NOT_REPRESENTABLE (reported by
+ * the next ddrl_replay_counts / ddrl_replay_sample that looks at the ring, like the sampler's errors); sample / gather / rows_export
+ * convert back, so every result is bit-identical to the float32 ring's on such data. */
+#define DDRL_REPLAY_U8_OBS 2u
 
 /* ReplayBuffer.__init__(obs_dim, act_dim, size)  (example/dsac.py:20-27): five zero-filled
  * float32 struct-of-arrays rings obs1[N,obs] obs2[N,obs] acts[N,act] rews[N] done[N];
@@ -102,6 +109,9 @@ int ddrl_replay_counts(ddrl_replay_t *h, int64_t *ptr_h, int64_t *size_h, int64_
  * widths_h / src_h / out_h / arrays_h are HOST arrays (of ints / of device pointers), in ring order. */
 int ddrl_replay_create_ex(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays,
                           const int32_t *widths_h, int64_t steps_inc, int64_t samples_inc);
+/* The same with a storage kind per array: kinds_h[j] = 0 float32, 1 uint8 (see DDRL_REPLAY_U8_OBS; NULL = all float32). */
+int ddrl_replay_create_typed(ddrl_replay_t **out, int device, int64_t capacity, int32_t n_arrays, const int32_t *widths_h,
+                             const uint8_t *kinds_h, int64_t steps_inc, int64_t samples_inc);
 int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n, void *stream);
 /* store() for the rows whose mask_d[i] != 0 (device uint8[n]), in row order: the n-step rollout stores
  * a window only for the envs whose deque is full (algos/sac1/sac_ray.py:243-246).  The row count
@@ -136,6 +146,11 @@ int ddrl_replay_buffers_ex(ddrl_replay_t *h, float **arrays_h, int32_t *widths_h
  * exactly these five arrays + (ptr,size,max_size,steps,sample_times)). */
 int ddrl_replay_buffers(ddrl_replay_t *h, float **obs1_d, float **obs2_d, float **acts_d,
                         float **rews_d, float **done_d);
+/* Ring rows [row0, row0 + nrows) of array `array` as float32 into out_d[nrows, w] / from src_d — whatever the storage kind: how the
+ * .npy checkpoint of algos/dqn/train.py:82-108 (float32 arrays) is streamed out of / into a compact ring, chunk by chunk.  (The
+ * raw pointers of ddrl_replay_buffers* address BYTES for a uint8 array.)  A non-representable value on import: sticky error as in store. */
+int ddrl_replay_rows_export(ddrl_replay_t *h, int32_t array, int64_t row0, int64_t nrows, float *out_d, void *stream);
+int ddrl_replay_rows_import(ddrl_replay_t *h, int32_t array, int64_t row0, int64_t nrows, const float *src_d, void *stream);
 /* Restore counters after loading the arrays (algos/dqn/train.py:92-108). */
 int ddrl_replay_set_counts(ddrl_replay_t *h, int64_t ptr, int64_t size, int64_t steps,
                            int64_t sample_times, void *stream);

@@ -435,3 +435,110 @@ def test_config5_rows_beyond_4gib_byte_offsets(ddrl):
     check(buf.gather_device(torch.from_numpy(hi).cuda()), hi)                # ddrl_replay_gather at the far end of the arrays
     del buf
     torch.cuda.empty_cache()
+
+
+# ---- the opt-in compact (uint8) ring for integer-valued pixel observations: config 5 at its stated capacity ----------------
+class _PixOpt:
+    def __init__(self, cap, obs_dim=84 * 84 * 4, B=512, save_dir="."):
+        self.obs_dim, self.buffer_size, self.batch_size, self.save_dir = obs_dim, cap, B, save_dir
+
+
+def _pixel_transitions(rs, n, obs_dim):
+    o = rs.randint(0, 256, (n, obs_dim)).astype(np.float32)
+    o2 = rs.randint(0, 256, (n, obs_dim)).astype(np.float32)
+    return o, rs.randint(0, 4, n).astype(np.float32), rs.randn(n).astype(np.float32), o2, (rs.rand(n) < 0.1).astype(np.float32)
+
+
+@pytest.mark.parametrize("obs_dim,cap", [(84 * 84 * 4, 40), (50, 9), (64, 300)])
+def test_compact_ring_is_bit_identical_to_the_float32_ring(ddrl, tmp_path, obs_dim, cap):
+    """Same stores (wrap, a batch larger than the capacity), same seed: index streams, gathered batches, ring contents, counters
+    and the .npy checkpoint of the compact ring equal the float32 ring's bit for bit — and both equal the oracle.  Row widths that
+    are / are not whole 16-element groups (the vector and the scalar conversion paths)."""
+    from oracle.replay_oracle import ReplayBufferOracle
+    rs = np.random.RandomState(3)
+    f32 = ddrl.ReplayBufferDQN(_PixOpt(cap, obs_dim, 32, str(tmp_path / "f")), 0, seed=7)
+    u8 = ddrl.ReplayBufferDQN(_PixOpt(cap, obs_dim, 32, str(tmp_path / "u")), 0, seed=7, compact_obs=True)
+    ora = ReplayBufferOracle(obs_dim, 1, cap, acts_1d=True, seed=7)
+    assert u8.compact_obs and not f32.compact_obs
+    for n in (cap - 3, 7, 2 * cap + 5, 1):
+        tr = _pixel_transitions(rs, n, obs_dim)
+        o, a, r, o2, d = tr
+        for b in (f32, u8):
+            b.store_batch(*(torch.from_numpy(x).cuda() for x in (o, a, r, o2, d)))
+        ora.store_batch(o, a, r, o2, d)
+        for B in (32, 5):
+            g1, g2, w = f32.sample_batch_device(B, with_indices=True), u8.sample_batch_device(B, with_indices=True), ora.sample_batch(B)
+            np.testing.assert_array_equal(g2["idxs"].cpu().numpy(), ora.last_idxs)
+            for k in ("obs1", "obs2", "acts", "rews", "done", "idxs"):
+                assert torch.equal(g1[k], g2[k]), k
+            for k in w:
+                np.testing.assert_array_equal(g2[k].cpu().numpy(), w[k])
+    r1, r2 = f32.rings(), u8.rings()
+    for k in r1:
+        assert r2[k].dtype == torch.float32 and torch.equal(r1[k], r2[k]), k
+    np.testing.assert_array_equal(r2["obs2_buf"].cpu().numpy(), ora.obs2_buf)
+    assert u8.get_counts() == f32.get_counts() == ora.get_counts()
+    idx = torch.from_numpy(rs.randint(0, cap, 11)).cuda()
+    assert torch.equal(u8.gather_device(idx)["obs1"], f32.gather_device(idx)["obs1"])
+    # checkpoint: float32 .npy files in the reference's format (algos/dqn/train.py:82-108), identical bytes, and each loads into the other kind
+    f32.save(); u8.save()
+    for name in ("obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf", "buffer_infos"):
+        a, b = np.load(tmp_path / "f" / "checkpoint" / ("%s-0.npy" % name)), np.load(tmp_path / "u" / "checkpoint" / ("%s-0.npy" % name))
+        assert a.dtype == b.dtype and np.array_equal(a, b), name
+    back = ddrl.ReplayBufferDQN(_PixOpt(cap, obs_dim, 32, str(tmp_path / "f")), 0, seed=1, compact_obs=True)
+    back.load()
+    for k, t in back.rings().items():
+        assert torch.equal(t, r1[k]), k
+    assert back.get_counts() == f32.get_counts()
+
+
+def test_compact_ring_refuses_values_it_cannot_hold(ddrl):
+    """The compact ring is lossless or loud: a fractional, negative, > 255 or NaN observation raises at the next look at the ring."""
+    for bad in (0.5, -1.0, 256.0, float("nan")):
+        buf = ddrl.ReplayBufferDQN(_PixOpt(8, 48, 4), 0, seed=0, compact_obs=True)
+        o = np.full((3, 48), 7.0, np.float32)
+        z = np.zeros(3, np.float32)
+        buf.store_batch(*(torch.from_numpy(x).cuda() for x in (o, z, z, o, z)))
+        buf.check()
+        o[1, 17] = bad
+        buf.store_batch(*(torch.from_numpy(x).cuda() for x in (o, z, z, o, z)))
+        with pytest.raises(ValueError, match="not an integer in"):
+            buf.check()
+        buf.check()   # reported once, then cleared
+
+
+def test_config5_ring_at_its_stated_capacity_of_4m_transitions(ddrl):
+    """BASELINE config 5: a 4 M-transition replay of 84x84x4 observations (algos/dqn/train.py:43-52; 903 GB as float32) on ONE MI355X
+    as the compact ring (225.8 GB of uint8 observations).  Rows at the far end of the arrays (byte offsets beyond 100 GB), the wrap
+    at 4 M, and sample_batch(512) over the full ring against NumPy's own index stream."""
+    free_b, _ = torch.cuda.mem_get_info()
+    cap, obs_dim = 4 * 10 ** 6, 84 * 84 * 4
+    need = 2 * cap * obs_dim + 12 * cap + (2 << 30)
+    if free_b < need:
+        pytest.skip("needs %.0f GB of free HBM, %.0f free" % (need / 1e9, free_b / 1e9))
+    buf = ddrl.ReplayBufferDQN(_PixOpt(cap), 0, seed=123, compact_obs=True)
+    rs = np.random.RandomState(8)
+    n = 600
+    o, a, r, o2, d = _pixel_transitions(rs, n, obs_dim)
+    from distributed_drl_amd import _lib
+    _lib.check(buf._lib.ddrl_replay_set_counts(buf._h, cap - 400, cap - 400, cap - 400, 0, _lib.stream_ptr()))   # cursor 400 rows before the end
+    buf.store_batch(*(torch.from_numpy(x).cuda() for x in (o, a, r, o2, d)))             # rows cap-400 .. cap-1, then 0 .. 199
+    assert buf.get_counts() == (0, cap + 200, cap) and buf.ptr == 200
+    np.testing.assert_array_equal(buf.rows(0, cap - 400, 400).cpu().numpy(), o[:400])
+    np.testing.assert_array_equal(buf.rows(1, 0, 200).cpu().numpy(), o2[400:])
+    g = buf.sample_batch_device(512, with_indices=True)
+    want = np.random.RandomState(123).randint(0, cap, 512)
+    np.testing.assert_array_equal(g["idxs"].cpu().numpy(), want)
+    idx = g["idxs"].cpu().numpy()
+    hit = np.nonzero((idx >= cap - 400) | (idx < 200))[0]
+    for b in hit:   # (a 512-draw over 4 M rows rarely lands in the 600 stored ones; gather_device below makes sure some do)
+        row = idx[b] - (cap - 400) if idx[b] >= cap - 400 else idx[b] + 400
+        np.testing.assert_array_equal(g["obs1"][b].cpu().numpy(), o[row])
+    sel = torch.tensor([cap - 1, cap - 400, 0, 199, cap // 2], device="cuda")
+    gg = buf.gather_device(sel)
+    np.testing.assert_array_equal(gg["obs1"][:4].cpu().numpy(), o[[399, 0, 400, 599]])
+    np.testing.assert_array_equal(gg["obs2"][:4].cpu().numpy(), o2[[399, 0, 400, 599]])
+    assert float(gg["obs1"][4].abs().max()) == 0.0
+    np.testing.assert_array_equal(gg["rews"][:4].cpu().numpy(), r[[399, 0, 400, 599]])
+    del buf
+    torch.cuda.empty_cache()
