@@ -377,15 +377,18 @@ def config5_stages(args, d):
         st = l5.stage_times(b5, reps=20)
         h1, h2, A = 400, 300, 4
         # algorithmic FLOPs per launch group: three forwards (main @ x, main @ x2, target @ x2); backward of main @ x
-        fl = {"layer1_forward": 2.0 * B5 * obs_dim * h1 * 3, "layer2_forward": 2.0 * B5 * h1 * h2 * 3, "head_forward": 2.0 * B5 * h2 * A * 3,
-              "head_backward": 2.0 * B5 * h2 * A * 2, "layer2_backward": 2.0 * B5 * h1 * h2 * 2, "layer1_wgrad": 2.0 * B5 * (obs_dim + 1) * h1}
+        fl = {"layer1_forward": 2.0 * B5 * obs_dim * h1 * 3, "layer2_forward": 2.0 * B5 * h1 * h2 * 3, "head": 2.0 * B5 * h2 * A * 4,
+              "layer2_backward": 2.0 * B5 * h1 * h2 * 2 + 2.0 * B5 * h2 * A, "layer1_wgrad": 2.0 * B5 * (obs_dim + 1) * h1}
         n_par = obs_dim * h1 + h1 + h1 * h2 + h2 + h2 * A + A
         adam_bytes = 40.0 * n_par                      # 28 B/param optimizer + 12 B/param target traffic
-        names_k = {"layer1_forward": "k_wide<true> (504 workgroups, split-K) + k_wide_reduce", "layer2_forward": "k_gemm", "head_forward": "k_gemm",
-                   "head_backward": "k_gemm (dgrad + wgrad jobs)", "layer2_backward": "k_gemm (dgrad + wgrad jobs)", "layer1_wgrad": "k_wide<false>"}
-        order = ("stage", "layer1_forward", "layer2_forward", "head_forward", "rows", "head_backward", "layer2_backward", "layer1_wgrad", "adam_polyak")
+        names_k = {"layer1_forward": "k_wide<true> (504 workgroups, split-K) + k_wide_reduce", "layer2_forward": "k_gemm",
+                   "head": "k_dqn_head (Q of the three evaluations, backup / loss / dQ, head dgrad: one launch)",
+                   "layer2_backward": "k_gemm (layer-2 dgrad + wgrad, head wgrad)", "layer1_wgrad": "k_wide<false>"}
+        order = ("stage", "layer1_forward", "layer2_forward", "head", "unused4", "unused5", "layer2_backward", "layer1_wgrad", "adam_polyak")
         per = {}
         for k, ms in zip(order, st):
+            if k.startswith("unused"):
+                continue
             e = {"us": ms * 1e3}
             if k in fl:
                 e.update({"kernel": names_k[k], "flop": fl[k], "achieved_TFLOPs": fl[k] / (ms * 1e-3) / 1e12,
@@ -398,7 +401,7 @@ def config5_stages(args, d):
         out["ddqn_update_cfg5"] = {
             "batch": 512, "obs_dim": obs_dim, "ms": t_u * 1e3, "updates_per_s": 1.0 / t_u,
             "what": "one Double-DQN update at config 5's learner shape on a device batch, eager: layer 1 (K = 28 224) on the LDS-DMA tiles of "
-                    "csrc/wide_l1.h, layers 2 / 3 on k_gemm, flat Adam + polyak",
+                    "csrc/wide_l1.h, layer 2 on k_gemm, the head in one launch (k_dqn_head), flat Adam + polyak",
             "roofline": {"kernel": "layer-1 forward (dominant): " + names_k["layer1_forward"], "bound": "mfma",
                          "achieved": per["layer1_forward"]["achieved_TFLOPs"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": per["layer1_forward"]["frac"], "traffic": None,

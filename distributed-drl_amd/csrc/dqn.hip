@@ -17,98 +17,192 @@
 // ==========================================================================================
 namespace {
 
-struct DqnRows {
-    const float *Q;      // [3][B][ldq]: q(x) main, q(x2) main, q_next(x2) target
+// ------------------------------------------------------------------------------------------
+// k_dqn_head: everything between the layer-2 forward and the layer-2 backward in ONE launch (was: head forward as three
+// k_gemm jobs, the rows kernel, the head dgrad as a k_gemm job — 31 us of launch-bound kernels at batch 512):
+//   Q[ev] = [H2[ev] | 1] [W3 ; b3]              every evaluation's n_actions outputs (K = hidden2 + 1: the bias is the last row)
+//   DDQN rows (actor_learner.py:40-55)           a_one_hot, q_value, argmax of the online q(x2), q_target, q_backup, q_loss, dQ
+//   SQN rows (sqn/actor_learner.py:40-58)        log-softmax entropy of q1(x2), min of the targets' greedy values, q_backup, dQ1, dQ2
+//   dZ2[n] = (dQ[n] W3[n]^T) .* (H2[gev[n]] > 0)
+// One workgroup = HEAD_ROWS batch rows; the loss is summed over the workgroups' partials by the last one to finish, in
+// workgroup order (deterministic).  The head kernels' gradient [H2 | 1]^T dQ stays a k_gemm job (now of the layer-2 backward launch).
+// ------------------------------------------------------------------------------------------
+constexpr int HEAD_ROWS = 4, HEAD_MAXA = 16, HEAD_MAXEV = 5;
+struct HeadArgs {
+    const float *H2;                 // [nev][B][ldh2], ones column at h2
+    const float *W3b[HEAD_MAXEV];    // [W3 ; b3] of evaluation ev: (h2 + 1) rows of A
+    const float *W3n[2];             // ... of the differentiated network n (main)
     const float *acts, *rew, *done;
-    float *dQ;           // [B][ldq]
-    float *loss;         // [1]
-    float *qsel;         // [B] q(x)[a] (diagnostic output)
-    int B, A, ldq;
-    float gamma;
-};
-// one workgroup; thread r handles row r (B <= 1024 per pass), then a fixed-order tree reduction
-__global__ void __launch_bounds__(256) k_dqn_rows(DqnRows a) {
-    __shared__ float s_red[256];
-    float acc = 0.f;
-    const long long BQ = (long long)a.B * a.ldq;
-    for (int r0 = 0; r0 < a.B; r0 += 256) {
-        const int r = r0 + threadIdx.x;
-        if (r < a.B) {
-            const float *q = a.Q + (long long)r * a.ldq, *qx2 = q + BQ, *qn = qx2 + BQ;
-            const int act = (int)a.acts[r];                       // tf.cast(a_ph, tf.int32)
-            int best = 0;
-            float bv = qx2[0];
-            for (int c = 1; c < a.A; ++c) { const float v = qx2[c]; if (v > bv) { bv = v; best = c; } }  // tf.argmax: first maximum
-            const float q_value = q[(act >= 0 && act < a.A) ? act : 0];
-            const float valid = (act >= 0 && act < a.A) ? 1.0f : 0.0f;  // one_hot of an out-of-range index is all zeros
-            const float backup = a.rew[r] + (a.gamma * (1.0f - a.done[r])) * qn[best];
-            const float e = backup - q_value * valid;
-            acc += e * e;
-            const float g = -e / (float)a.B;
-            for (int c = 0; c < a.ldq; ++c) a.dQ[(long long)r * a.ldq + c] = (c == act && c < a.A) ? g : 0.f;
-            if (a.qsel) a.qsel[r] = q_value * valid;
-        }
-    }
-    s_red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.loss[0] = 0.5f * (s_red[0] / (float)a.B);
-}
-
-// SQN rows.  Q slots: 0 q1(x)  1 q1(x2)  2 q2(x)  3 q1_target(x2)  4 q2_target(x2);  dQ slots: 0 q1, 1 q2.
-struct SqnRows {
-    const float *Q;
-    const float *acts, *rew, *done;
-    float *dQ;     // [2][B][ldq]
-    float *loss;   // [1] q_loss = q1_loss + q2_loss
-    int B, A, ldq;
+    float *Q, *dQ, *dZ2, *part, *qsel;
+    int *zero_words;                 // polled words of a LATER launch of this update (k_wide_sk's flags), zeroed here: n_zero ints
+    int n_zero;
+    int B, A, ldq, h2, ldh2, nev, nnet, sqn;
+    int gev[2], nev_of_net[2];       // evaluation whose staged [W3 ; b3] is network n's main copy
+    int ldw;                         // floats per staged [W3 ; b3]: (h2 + 1) * A rounded up to 4
     float gamma, alpha;
 };
-__global__ void __launch_bounds__(256) k_sqn_rows(SqnRows a) {
-    __shared__ float s_red[256];
-    float acc = 0.f;
-    const long long BQ = (long long)a.B * a.ldq;
-    for (int r0 = 0; r0 < a.B; r0 += 256) {
-        const int r = r0 + threadIdx.x;
-        if (r < a.B) {
-            const float *q1 = a.Q + (long long)r * a.ldq, *q1x2 = q1 + BQ, *q2 = q1x2 + BQ, *q1t = q2 + BQ, *q2t = q1t + BQ;
-            const int act = (int)a.acts[r];
-            const bool valid = act >= 0 && act < a.A;
-            // pi_log = log_softmax(q1(x2) / alpha); "entropy_x2" = sum exp(pi_log) * pi_log  (core.py:32-42)
-            float zmax = q1x2[0] / a.alpha;
-            for (int c = 1; c < a.A; ++c) zmax = fmaxf(zmax, q1x2[c] / a.alpha);
-            float se = 0.f;
-            for (int c = 0; c < a.A; ++c) se += expf(q1x2[c] / a.alpha - zmax);
-            const float lse = logf(se);
-            float plogp = 0.f;
-            for (int c = 0; c < a.A; ++c) {
-                const float pl = (q1x2[c] / a.alpha - zmax) - lse;
-                plogp += expf(pl) * pl;
+static size_t head_lds_bytes(const HeadArgs &a) { return ((size_t)a.nev * HEAD_ROWS * a.ldh2 + (size_t)a.nev * a.ldw) * sizeof(float); }
+__global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
+    // the workgroup's H2 rows and every evaluation's [W3 ; b3] are staged into LDS with ALL loads in flight at once (the first cut
+    // read them inside the dot-product loops: 30 dependent round trips per wave, 30 us for 3.7 MFLOP)
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float *sH = hsm;                                        // [nev][HEAD_ROWS][ldh2]
+    float *sW = hsm + (size_t)a.nev * HEAD_ROWS * a.ldh2;   // [nev][ldw]
+    __shared__ float sQ[HEAD_MAXEV][HEAD_ROWS][HEAD_MAXA];
+    __shared__ float sdQ[2][HEAD_ROWS][HEAD_MAXA];
+    __shared__ float s_loss[HEAD_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * HEAD_ROWS;
+    const long long BH = (long long)a.B * a.ldh2, BQ = (long long)a.B * a.ldq;
+    const int K = a.h2 + 1;
+    {
+        // four loads per lane in flight per round (a plain load-store loop waits for every load before it issues the next one)
+        const int l4 = a.ldh2 >> 2, n4 = a.nev * HEAD_ROWS * l4;
+        for (int e0 = tid; e0 < n4; e0 += 4 * 256) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                const int ec = e < n4 ? e : 0;
+                const int ev = ec / (HEAD_ROWS * l4), rem = ec - ev * (HEAD_ROWS * l4), lr = rem / l4, c4 = rem - lr * l4;
+                const int row = r0 + lr < a.B ? r0 + lr : a.B - 1;
+                v[u] = *reinterpret_cast<const float4 *>(a.H2 + ev * BH + (long long)row * a.ldh2 + 4 * c4);
+                if (r0 + lr >= a.B) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            float m1 = q1t[0], m2 = q2t[0];   // q_mu_ = q_[argmax q_] = max q_ (each target network's own greedy value)
-            for (int c = 1; c < a.A; ++c) { m1 = fmaxf(m1, q1t[c]); m2 = fmaxf(m2, q2t[c]); }
-            const float v_backup = fminf(m1, m2) - a.alpha * plogp;                 // actor_learner.py:47-50
-            const float q_backup = a.rew[r] + (a.gamma * (1.0f - a.done[r])) * v_backup;
-            const float e1 = q_backup - (valid ? q1[act] : 0.f), e2 = q_backup - (valid ? q2[act] : 0.f);
-            acc += e1 * e1 + e2 * e2;
-            const float g1 = -e1 / (float)a.B, g2 = -e2 / (float)a.B;
-            for (int c = 0; c < a.ldq; ++c) {
-                const bool hit = valid && c == act;
-                a.dQ[(long long)r * a.ldq + c] = hit ? g1 : 0.f;
-                a.dQ[BQ + (long long)r * a.ldq + c] = hit ? g2 : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + 256 * u < n4) reinterpret_cast<float4 *>(sH)[e0 + 256 * u] = v[u];
+        }
+        const int nw = K * a.A, nw4 = (nw + 3) / 4;
+        for (int ev = 0; ev < a.nev; ++ev) {
+            const float *src = a.W3b[ev];
+            if ((((unsigned long long)src) & 15ull) == 0) {   // (reads up to three floats past the bias: inside the parameter slab)
+                for (int e0 = tid; e0 < nw4; e0 += 4 * 256) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4 *>(src)[e0 + 256 * u < nw4 ? e0 + 256 * u : 0];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e0 + 256 * u < nw4) reinterpret_cast<float4 *>(sW + (size_t)ev * a.ldw)[e0 + 256 * u] = v[u];
+                }
+            } else {
+                for (int e = tid; e < nw; e += 256) sW[(size_t)ev * a.ldw + e] = src[e];
             }
         }
     }
-    s_red[threadIdx.x] = acc;
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
-        __syncthreads();
+    // ---- Q: wave w takes row w; the lanes split k, fixed-order butterfly
+    {
+        const int lr = w, row = r0 + lr;
+        for (int ev = 0; ev < a.nev; ++ev) {
+            float acc[HEAD_MAXA];
+#pragma unroll
+            for (int c = 0; c < HEAD_MAXA; ++c) acc[c] = 0.f;
+            const float *x = sH + ((size_t)ev * HEAD_ROWS + lr) * a.ldh2;
+            const float *wk = sW + (size_t)ev * a.ldw;
+            if (a.A == 4) {
+                for (int k = lane; k < K; k += 64) {
+                    const float xv = x[k];
+                    const float4 wv = *reinterpret_cast<const float4 *>(wk + 4 * k);
+                    acc[0] = fmaf(xv, wv.x, acc[0]); acc[1] = fmaf(xv, wv.y, acc[1]); acc[2] = fmaf(xv, wv.z, acc[2]); acc[3] = fmaf(xv, wv.w, acc[3]);
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) {
+                    const float xv = x[k];
+#pragma unroll
+                    for (int c = 0; c < HEAD_MAXA; ++c)
+                        if (c < a.A) acc[c] = fmaf(xv, wk[k * a.A + c], acc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < HEAD_MAXA; ++c) {
+                if (c < a.A) {
+                    float v = acc[c];
+                    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                    if (lane == 0) {
+                        sQ[ev][lr][c] = v;
+                        if (row < a.B) a.Q[ev * BQ + (long long)row * a.ldq + c] = v;
+                    }
+                }
+            }
+        }
     }
-    if (threadIdx.x == 0) a.loss[0] = 0.5f * (s_red[0] / (float)a.B);
+    __syncthreads();
+    // ---- rows
+    if (tid < HEAD_ROWS) {
+        const int row = r0 + tid;
+        float l = 0.f;
+        if (row < a.B) {
+            const int act = (int)a.acts[row];                       // tf.cast(a_ph, tf.int32)
+            const bool valid = act >= 0 && act < a.A;               // one_hot of an out-of-range index is all zeros
+            if (!a.sqn) {
+                const float *q = sQ[0][tid], *qx2 = sQ[1][tid], *qn = sQ[2][tid];
+                int best = 0;
+                float bv = qx2[0];
+                for (int c = 1; c < a.A; ++c) { const float v = qx2[c]; if (v > bv) { bv = v; best = c; } }  // tf.argmax: first maximum
+                const float q_value = valid ? q[act] : 0.f;
+                const float backup = a.rew[row] + (a.gamma * (1.0f - a.done[row])) * qn[best];
+                const float e = backup - q_value;
+                l = e * e;
+                const float g = -e / (float)a.B;
+                for (int c = 0; c < a.ldq; ++c) {
+                    const float v = (valid && c == act) ? g : 0.f;
+                    if (c < HEAD_MAXA) sdQ[0][tid][c] = v;
+                    a.dQ[(long long)row * a.ldq + c] = v;
+                }
+                if (a.qsel) a.qsel[row] = q_value;
+            } else {
+                const float *q1 = sQ[0][tid], *q1x2 = sQ[1][tid], *q2 = sQ[2][tid], *q1t = sQ[3][tid], *q2t = sQ[4][tid];
+                // pi_log = log_softmax(q1(x2) / alpha); "entropy_x2" = sum exp(pi_log) * pi_log  (core.py:32-42)
+                float zmax = q1x2[0] / a.alpha;
+                for (int c = 1; c < a.A; ++c) zmax = fmaxf(zmax, q1x2[c] / a.alpha);
+                float se = 0.f;
+                for (int c = 0; c < a.A; ++c) se += expf(q1x2[c] / a.alpha - zmax);
+                const float lse = logf(se);
+                float plogp = 0.f;
+                for (int c = 0; c < a.A; ++c) {
+                    const float pl = (q1x2[c] / a.alpha - zmax) - lse;
+                    plogp += expf(pl) * pl;
+                }
+                float m1 = q1t[0], m2 = q2t[0];   // q_mu_ = q_[argmax q_] = max q_ (each target network's own greedy value)
+                for (int c = 1; c < a.A; ++c) { m1 = fmaxf(m1, q1t[c]); m2 = fmaxf(m2, q2t[c]); }
+                const float v_backup = fminf(m1, m2) - a.alpha * plogp;                 // actor_learner.py:47-50
+                const float q_backup = a.rew[row] + (a.gamma * (1.0f - a.done[row])) * v_backup;
+                const float e1 = q_backup - (valid ? q1[act] : 0.f), e2 = q_backup - (valid ? q2[act] : 0.f);
+                l = e1 * e1 + e2 * e2;
+                const float g1 = -e1 / (float)a.B, g2 = -e2 / (float)a.B;
+                for (int c = 0; c < a.ldq; ++c) {
+                    const bool hit = valid && c == act;
+                    if (c < HEAD_MAXA) { sdQ[0][tid][c] = hit ? g1 : 0.f; sdQ[1][tid][c] = hit ? g2 : 0.f; }
+                    a.dQ[(long long)row * a.ldq + c] = hit ? g1 : 0.f;
+                    a.dQ[BQ + (long long)row * a.ldq + c] = hit ? g2 : 0.f;
+                }
+            }
+        }
+        s_loss[tid] = l;
+    }
+    __syncthreads();
+    // ---- dZ2
+    for (int idx = tid; idx < a.nnet * HEAD_ROWS * a.h2; idx += 256) {
+        const int n = idx / (HEAD_ROWS * a.h2), rem = idx - n * (HEAD_ROWS * a.h2), lr = rem / a.h2, j = rem - lr * a.h2;
+        const int row = r0 + lr;
+        if (row < a.B) {
+            const float *wj = sW + (size_t)a.nev_of_net[n] * a.ldw + j * a.A;
+            float v = 0.f;
+            for (int c = 0; c < a.A; ++c) v = fmaf(sdQ[n][lr][c], wj[c], v);
+            const float hmask = sH[((size_t)a.gev[n] * HEAD_ROWS + lr) * a.ldh2 + j];
+            a.dZ2[((long long)n * a.B + row) * a.h2 + j] = hmask > 0.f ? v : 0.f;
+        }
+    }
+    if (a.zero_words)
+        for (int i = blockIdx.x * 256 + tid; i < a.n_zero; i += gridDim.x * 256) a.zero_words[i] = 0;
+    // ---- loss: this workgroup's rows in order; the flat Adam launch at the end of the update sums the partials in workgroup order
+    // (an in-kernel last-arriver needs an L2 write-back per workgroup on this multi-XCD part: 19 us for the whole kernel)
+    if (tid == 0) {
+        float p = 0.f;
+        for (int r = 0; r < HEAD_ROWS; ++r) p += s_loss[r];
+        a.part[blockIdx.x] = p;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_dqn_stage(const float *o1, const float *o2, const float *ac, const float *r, const float *d,
@@ -137,14 +231,20 @@ struct ddrl_dqn {
     OptState *opt;
     int opt_cur;
     Seg *segs_d;
-    GemmJobs g_f1, g_f2, g_f3, g_b3, g_b2, g_b1;
-    DqnRows rows;
-    SqnRows srows;
+    GemmJobs g_f1, g_f2, g_f3, g_b2, g_b1;   // g_f3: the head forward as GEMM jobs, ddrl_dqn_q only (the update's head lives in k_dqn_head)
+    HeadArgs head;
+    float *hpart;
     AdamArgs ad;
     bool wide;            // layer 1 on wide_l1.h
     WideArgs wf, ww[2];   // forward (all evaluations), wgrad per network
     int wf_x2[WD_MAXEV];  // which input an evaluation reads: 0 obs1, 1 obs2
     float *wpart, *wconsts;
+    // stream-K layer-1 wgrad (k_wide_sk): per network the fragment table; one slab / flag array / epoch shared (the launches are stream-ordered)
+    SkArgs sk[2];
+    bool sk_on;
+    SkFrag *sk_frags_d;
+    float *sk_slab;
+    int *sk_flag;
 };
 
 extern "C" {
@@ -153,6 +253,7 @@ int ddrl_dqn_destroy(ddrl_dqn_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
     (void)hipFree(h->slab);
+    (void)hipFree(h->sk_frags_d); (void)hipFree(h->sk_slab); (void)hipFree(h->sk_flag);
     delete h;
     return DDRL_OK;
 }
@@ -169,6 +270,7 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     DDRL_REQUIRE(out != nullptr && cfg != nullptr, "NULL pointer");
     DDRL_REQUIRE(cfg->obs_dim > 0 && cfg->n_actions > 0 && cfg->hidden1 > 0 && cfg->hidden2 > 0 && cfg->batch > 0, "dims must be positive");
     DDRL_REQUIRE(cfg->variant == DDRL_DDQN || (cfg->variant == DDRL_SQN && cfg->alpha > 0.0), "variant must be DDRL_DDQN, or DDRL_SQN with alpha > 0");
+    DDRL_REQUIRE(cfg->n_actions <= HEAD_MAXA, "n_actions > 16 unsupported by the head kernel");
     ddrl::DeviceGuard g(device);
     if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
     ddrl_dqn *h = new ddrl_dqn();
@@ -202,6 +304,7 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     ALLOC(x1, (size_t)B * h->ldx); ALLOC(x2, (size_t)B * h->ldx); ALLOC(acts, B); ALLOC(rew, B); ALLOC(done, B);
     ALLOC(H1, (size_t)5 * B * h->ldh1); ALLOC(H2, (size_t)5 * B * h->ldh2); ALLOC(Q, (size_t)5 * B * h->ldq); ALLOC(dQ, (size_t)2 * B * h->ldq);
     ALLOC(dZ2, (size_t)2 * B * h2); ALLOC(dZ1, (size_t)2 * B * h1); ALLOC(loss, 4); ALLOC(qsel, B);
+    ALLOC(hpart, (size_t)(B + HEAD_ROWS - 1) / HEAD_ROWS + 64);
     h->wide = wide_applies(o, h1);
     const int nev_all = cfg->variant == DDRL_SQN ? 5 : 3;
     if (h->wide) {
@@ -266,15 +369,8 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     for (int n = 0; n < h->nnet; ++n) {
         const int ev = gev[n];
         float *dQ = h->dQ + (long long)n * BQ, *dZ2 = h->dZ2 + (long long)n * B * h2, *dZ1 = h->dZ1 + (long long)n * B * h1;
-        {   // dZ2 = (dQ * W3^T) .* (H2 > 0): A = dQ [B x A] (row stride ldq), B(k, j) = W3[j * A + k]
-            GemmJob j{};
-            j.adam_off = -1;
-            j.A = dQ; j.B = Pm + h->W3[n]; j.C = dZ2; j.bias = nullptr; j.mask = h->H2 + ev * BH2;
-            j.M = B; j.N = h2; j.K = A; j.lda = h->ldq; j.ldb = A; j.ldc = h2; j.ldmask = h->ldh2; j.a_kc = 1; j.b_kc = 1; j.relu = 0;
-            set_fast(j);
-            gemm_add(h->g_b3, j);
-        }
-        gemm_add(h->g_b3, gemm_wgrad(h->H2 + ev * BH2, h->ldh2, h2, dQ, h->ldq, A, G + h->W3[n], A, B));
+        // (dZ2 = (dQ * W3^T) .* (H2 > 0) comes out of k_dqn_head) the head kernels' gradient [H2 | 1]^T dQ rides in the layer-2 backward launch
+        gemm_add(h->g_b2, gemm_wgrad(h->H2 + ev * BH2, h->ldh2, h2, dQ, h->ldq, A, G + h->W3[n], A, B));
         gemm_add(h->g_b2, gemm_dgrad(dZ2, Pm + h->W2[n], h->H1 + ev * BH1, h->ldh1, dZ1, B, h1, h2));
         gemm_add(h->g_b2, gemm_wgrad(h->H1 + ev * BH1, h->ldh1, h1, dZ2, h2, h2, G + h->W2[n], h2, B));
         gemm_add(h->g_b1, gemm_wgrad(h->x1, h->ldx, o, dZ1, h1, h1, G + h->W1[n], h1, B));
@@ -285,11 +381,54 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         }
     }
     if (h->wide) { h->wf.part = h->wpart; h->wf.consts = h->wconsts; h->wf.a_rows = B; h->wf.ldo = h->ldh1; }
-    h->srows = SqnRows{h->Q, h->acts, h->rew, h->done, h->dQ, h->loss, B, A, h->ldq, (float)cfg->gamma, (float)cfg->alpha};
-    h->rows = DqnRows{h->Q, h->acts, h->rew, h->done, h->dQ, h->loss, h->qsel, B, A, h->ldq, (float)cfg->gamma};
+    h->sk_on = false; h->sk_frags_d = nullptr; h->sk_slab = nullptr; h->sk_flag = nullptr;
+    if (h->wide && !(getenv("DDRL_WIDE_SK") && atoi(getenv("DDRL_WIDE_SK")) == 0)) {
+        // the wgrad as equal shares of the stage sequence over <= 512 resident workgroups (two per CU) when the shape splits that way
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        std::vector<SkFrag> fr;
+        const int nwg = wide_plan_sk(h->ww[0], 2 * ncu, fr);
+        if (nwg > 1) {
+            hipError_t e2 = hipMalloc((void **)&h->sk_frags_d, fr.size() * sizeof(SkFrag));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&h->sk_slab, (size_t)nwg * 4 * WD_NB * 16 * 64 * sizeof(float));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&h->sk_flag, (size_t)(nwg + 1) * sizeof(int));
+            if (e2 == hipSuccess) e2 = hipMemset(h->sk_flag, 0, (size_t)(nwg + 1) * sizeof(int));
+            if (e2 == hipSuccess) e2 = hipMemcpy(h->sk_frags_d, fr.data(), fr.size() * sizeof(SkFrag), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) {
+                for (int n = 0; n < h->nnet; ++n) {
+                    h->sk[n].w = h->ww[n]; h->sk[n].frags = h->sk_frags_d; h->sk[n].slab = h->sk_slab; h->sk[n].flag = h->sk_flag;
+                    h->sk[n].nwg = nwg; h->sk[n].epoch = n + 1;   // (the networks' launches of one update share the flags: one epoch each)
+                }
+                h->sk_on = true;
+            }
+        }
+    }
+    {
+        HeadArgs &H = h->head;
+        H = HeadArgs{};
+        H.H2 = h->H2;
+        for (int ev = 0; ev < nev; ++ev) H.W3b[ev] = par[ev] + h->W3[net[ev]];
+        for (int n = 0; n < h->nnet; ++n) { H.W3n[n] = Pm + h->W3[n]; H.gev[n] = gev[n]; H.nev_of_net[n] = gev[n]; }   // evaluation gev[n] runs on network n's main copy
+        H.ldw = (int)pad4((long long)(h2 + 1) * A);
+        H.acts = h->acts; H.rew = h->rew; H.done = h->done;
+        H.Q = h->Q; H.dQ = h->dQ; H.dZ2 = h->dZ2; H.part = h->hpart; H.qsel = sqn ? nullptr : h->qsel;
+        H.B = B; H.A = A; H.ldq = h->ldq; H.h2 = h2; H.ldh2 = h->ldh2; H.nev = nev; H.nnet = h->nnet; H.sqn = sqn ? 1 : 0;
+        H.gamma = (float)cfg->gamma; H.alpha = (float)cfg->alpha;
+        if (h->sk_on) { H.zero_words = h->sk_flag; H.n_zero = h->sk[0].nwg + 1; }   // this update's k_wide_sk polls them
+    }
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, h->total_int, 0, 0,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak), nullptr, 0, 0, 0, 0, 0u};
+    DDRL_REQUIRE(head_lds_bytes(h->head) <= 150 * 1024, "hidden2 too wide for the head kernel's LDS staging");
+    {   // the attribute belongs to the function on this device, not to the handle: it only ever grows
+        static size_t granted[64] = {0};
+        const size_t need = head_lds_bytes(h->head);
+        if (device >= 0 && device < 64 && need > granted[device]) {
+            DDRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            granted[device] = need;
+        }
+    }
     *out = h;
     return DDRL_OK;
 }
@@ -336,11 +475,13 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
     int e = 0;
 #define STAGE_MARK() do { if (ev) DDRL_HIP_CHECK(hipEventRecord(ev[e++], s)); } while (0)
     STAGE_MARK();
-    // wide layer 1 reads the caller's observation rows in place (16-byte aligned rows: obs_dim % 4 == 0 there); otherwise
-    // they are staged into the padded images with the ones column
+    // wide layer 1 reads the caller's observation rows in place (16-byte aligned rows: obs_dim % 4 == 0 there) and the head kernel
+    // the caller's acts / rews / done: no staging launch at all; otherwise everything is staged into the padded images
     const bool in_place = h->wide && al16(obs1_d) && al16(obs2_d);
-    const int n = in_place ? B : (B * o > B ? B * o : B);
-    k_dqn_stage<<<(n + 255) / 256, 256, 0, s>>>(obs1_d, obs2_d, acts_d, rews_d, done_d, h->x1, h->x2, h->acts, h->rew, h->done, B, in_place ? 0 : o, h->ldx);
+    if (!in_place) {
+        const int n = B * o > B ? B * o : B;
+        k_dqn_stage<<<(n + 255) / 256, 256, 0, s>>>(obs1_d, obs2_d, acts_d, rews_d, done_d, h->x1, h->x2, h->acts, h->rew, h->done, B, o, h->ldx);
+    }
     STAGE_MARK();   // 0 stage
     if (h->wide) {
         WideArgs f = h->wf;
@@ -355,21 +496,29 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
     STAGE_MARK();   // 1 layer-1 forward (+ split-K reduce)
     launch_gemm(h->g_f2, s);
     STAGE_MARK();   // 2 layer-2 forward
-    launch_gemm(h->g_f3, s);
-    STAGE_MARK();   // 3 head forward
-    if (h->cfg.variant == DDRL_SQN) k_sqn_rows<<<1, 256, 0, s>>>(h->srows);
-    else k_dqn_rows<<<1, 256, 0, s>>>(h->rows);
-    STAGE_MARK();   // 4 rows: backup, loss, dQ
-    launch_gemm(h->g_b3, s);
-    STAGE_MARK();   // 5 head dgrad + wgrad
+    {
+        HeadArgs H = h->head;
+        if (in_place) { H.acts = acts_d; H.rew = rews_d; H.done = done_d; }
+        k_dqn_head<<<(unsigned)((B + HEAD_ROWS - 1) / HEAD_ROWS), 256, head_lds_bytes(H), s>>>(H);
+    }
+    STAGE_MARK();   // 3 head: Q of every evaluation, backup / loss / dQ, dZ2
+    STAGE_MARK();   // 4 (folded into 3)
+    STAGE_MARK();   // 5 (folded into 3 and 6)
     launch_gemm(h->g_b2, s);
     STAGE_MARK();   // 6 layer-2 dgrad + wgrad
     if (h->wide) {
         for (int nn = 0; nn < h->nnet; ++nn) {
-            WideArgs g = h->ww[nn];
-            g.ev[0].A = in_place ? obs1_d : h->x1;
-            g.ev[0].lda = in_place ? o : h->ldx;
-            launch_wide_wgrad(g, s);
+            if (h->sk_on) {
+                SkArgs g = h->sk[nn];
+                g.w.ev[0].A = in_place ? obs1_d : h->x1;
+                g.w.ev[0].lda = in_place ? o : h->ldx;
+                launch_wide_sk(g, s);
+            } else {
+                WideArgs g = h->ww[nn];
+                g.ev[0].A = in_place ? obs1_d : h->x1;
+                g.ev[0].lda = in_place ? o : h->ldx;
+                launch_wide_wgrad(g, s);
+            }
         }
     } else {
         launch_gemm(h->g_b1, s);
@@ -380,7 +529,8 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
         h->ad.adam_blocks = (int)blocks;
         h->ad.opt = h->opt + h->opt_cur; h->ad.opt_next = h->opt + (h->opt_cur ^ 1);
         h->opt_cur ^= 1;
-        k_adam_polyak<<<(unsigned)blocks, 256, 0, s>>>(h->ad);
+        h->ad.loss_part = h->hpart; h->ad.loss_out = h->loss; h->ad.loss_n = (B + HEAD_ROWS - 1) / HEAD_ROWS; h->ad.loss_scale = 0.5f / (float)B;
+        k_adam_polyak<<<(unsigned)blocks + 1, 256, 0, s>>>(h->ad);   // + one workgroup: the loss mean from k_dqn_head's partials
     }
     STAGE_MARK();   // 8 flat Adam + polyak
 #undef STAGE_MARK

@@ -671,8 +671,29 @@ struct AdamArgs {
     ddrl_replay_dev::RingState *rs;
     ddrl_replay_dev::RingPtrs ring;
     ddrl_replay_dev::BatchPtrs sout;
+    // optional: one extra workgroup (block adam_blocks, do_sample == 0) finishes a loss mean from per-workgroup partials that an
+    // earlier launch left (k_dqn_head): loss_out[0] = loss_scale * sum_b loss_part[b], b in order
+    const float *loss_part;
+    float *loss_out;
+    int loss_n;
+    float loss_scale;
 };
 __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
+    if (a.loss_part && !a.do_sample && (int)blockIdx.x == a.adam_blocks) {
+        __shared__ float s_part[256];
+        float tot = 0.f;
+        for (int b0 = 0; b0 < a.loss_n; b0 += 256) {
+            s_part[threadIdx.x] = b0 + (int)threadIdx.x < a.loss_n ? a.loss_part[b0 + threadIdx.x] : 0.f;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int n = a.loss_n - b0 < 256 ? a.loss_n - b0 : 256;
+                for (int b = 0; b < n; ++b) tot += s_part[b];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.loss_out[0] = a.loss_scale * tot;
+        return;
+    }
     if (a.do_sample && (int)blockIdx.x == a.adam_blocks) {
         // Rides along: `idxs = np.random.randint(0, size, B)` + the five gathers of the NEXT update
         // (example/dsac.py:39-45) into the learner's other input set.  Adam touches no input set and

@@ -21,6 +21,7 @@
 #pragma once
 #include "gemm_core.h"
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -250,6 +251,208 @@ __global__ void __launch_bounds__(256) k_wide_reduce(WideArgs a) {
     *reinterpret_cast<float4 *>(E.out + (long long)row * a.ldo + c4) = acc;
 }
 
+// ==========================================================================================
+// k_wide_sk: the layer-1 weight gradient with the STAGE SEQUENCE, not the tile, as the unit of work ("stream-K").
+// [dW1 ; db1] = [X | 1]^T dZ1 has 221 row tiles x 3 column tiles (5, 4, 4 units) of 16 stages at config 5: 663 workgroups for
+// 512 resident slots — 151 slots run a second tile while 361 idle (k_wide<false>: 1.7 rounds, MFMA busy 0.48).  Here exactly
+// `nwg` <= 512 resident workgroups each take an equal share of the weighted stage sequence (a stage of an NU-unit tile weighs NU;
+// tiles in (row tile, column tile) order, so a workgroup's tiles share their X rows): a tail fragment of the tile its
+// predecessor started, whole tiles, a head fragment of the tile its successor finishes.  A split tile is combined in-launch:
+// the successor computes its (later-stage) fragment FIRST and publishes the accumulators as a slab (sc1 write-through stores, vmcnt
+// drain, barrier, relaxed agent-scope flag; the flags are zeroed by an earlier launch of the same update: the guide's hand-off recipe R1); the workgroup
+// that holds the head fragment computes it LAST, by which time the slab has long arrived, adds it (sc1 loads) in the fixed order
+// head + tail and writes the tile.  Every sum has one fixed order for a given shape: bit-identical run to run.  A share is at
+// least one tile long, so a tile never spans three workgroups and a workgroup only ever waits for its successor's first action.
+// ==========================================================================================
+struct SkFrag { int tile, s0, s1, role; };   // role 0: whole tile -> output; 1: tail part -> slab; 2: head part + successor's slab -> output; -1: none
+struct SkArgs {
+    WideArgs w;
+    const SkFrag *frags;   // [nwg][3]
+    float *slab;           // [nwg][4 waves][WD_NB][16 regs][64 lanes]
+    int *flag;             // [nwg]
+    int nwg, epoch;
+};
+__device__ __forceinline__ void sk_store_sc1(float *p, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
+    constexpr int WV = 4, WD_KB = 32, ROWS = 32 * WV, AOP = ROWS * WD_KB, WD_BOP = WD_KB * WD_BW, NG = WD_KB / 8;
+    constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;
+    const WideArgs &a = sa.w;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *sA = wsm, *sB = wsm + 2 * AOP;
+    const int wg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WideEval E = a.ev[0];
+    const int T = (a.K + WD_KB - 1) / WD_KB, ntc = a.cnt[0] + a.cnt[1];
+    const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
+    for (int f = 0; f < 3; ++f) {
+        const SkFrag fr = sa.frags[3 * wg + f];
+        if (fr.role < 0) continue;   // block-uniform
+        const int mt = fr.tile / ntc, ct = fr.tile - mt * ntc;
+        const int c = ct >= a.cnt[0] ? 1 : 0;
+        const int NU = a.nu[c];
+        const int unit0 = c ? a.cnt[0] * a.nu[0] + (ct - a.cnt[0]) * NU : ct * NU;
+        const int m0 = mt * ROWS, n0 = unit0 * 32;
+        const float *pa[APW], *pb[BPW];
+        int ak[APW], bk[BPW], amode = 1;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int I = APW * w + i;
+            const int kk = 2 * I + (lane >> 5), i0 = m0 + 4 * (lane & 31);
+            ak[i] = kk;
+            amode = i0 < a.a_rows ? 1 : i0 == a.a_rows ? 2 : 0;
+            pa[i] = E.A + (long long)kk * E.lda + (amode == 1 ? i0 : 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int f4 = 64 * (BPW * w + j) + lane, kk = f4 / (WD_BW / 4), c4 = f4 - kk * (WD_BW / 4);
+            bk[j] = kk;
+            pb[j] = (c4 < NU * 8 && n0 + 4 * c4 < a.N) ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;
+        }
+        auto issue = [&](int st, int buf) {
+            const int k = st * WD_KB;
+            const unsigned dA = lds_addr(sA + buf * AOP + 256 * APW * w), dB = lds_addr(sB + buf * WD_BOP + 256 * BPW * w);
+#pragma unroll
+            for (int g = 0; g < APW; ++g) {
+                const float *src = amode == 2 ? ones_blk : (amode == 1 && k + ak[g] < a.K) ? pa[g] + (long long)k * E.lda : zero_blk;
+                glds16(src, dA + 1024 * g);
+            }
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
+        };
+        floatx16 acc[WD_NB];
+#pragma unroll
+        for (int u = 0; u < WD_NB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        const bool active = m0 + 32 * w < a.M;
+        auto compute = [&](const float *cA, const float *cB, auto nu_c) {
+            constexpr int NUC = decltype(nu_c)::value;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float av[4], bv[NUC][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = cA[(8 * g + 4 * h + j) * ROWS + 32 * w + l31];
+#pragma unroll
+                for (int u = 0; u < NUC; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * WD_BW + 32 * u + l31];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < NUC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[u][j], acc[u], 0, 0, 0);
+            }
+        };
+        auto run = [&](auto nu_c) {
+            issue(fr.s0, 0);
+            wide_dma_wait();
+            __syncthreads();
+            for (int st = fr.s0; st < fr.s1; ++st) {
+                const int cur = (st - fr.s0) & 1;
+                if (st + 1 < fr.s1) issue(st + 1, cur ^ 1);
+                if (active) compute(sA + cur * AOP, sB + cur * WD_BOP, nu_c);
+                wide_dma_wait();
+                __syncthreads();
+            }
+        };
+        if (fr.s0 < fr.s1 && fr.s1 <= T) {
+            if (NU == 5) run(std::integral_constant<int, 5>{});
+            else if (NU == 4) run(std::integral_constant<int, 4>{});
+            else if (NU == 3) run(std::integral_constant<int, 3>{});
+            else if (NU == 2) run(std::integral_constant<int, 2>{});
+            else run(std::integral_constant<int, 1>{});
+        }
+        if (fr.role == 1) {
+            // publish: [wave][unit][four-register group][lane] float4 — one fully coalesced 1 KB line per wave-instruction
+            float *S = sa.slab + (((long long)wg * WV + w) * WD_NB) * 16 * 64;
+#pragma unroll
+            for (int u = 0; u < WD_NB; ++u)
+                if (u < NU)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        sk_store_sc1(S + ((u * 4 + q) * 64 + lane) * 4, make_float4(acc[u][4 * q], acc[u][4 * q + 1], acc[u][4 * q + 2], acc[u][4 * q + 3]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(sa.flag + wg, sa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (fr.role == 2) {
+            // consume (guide, Guideline 16 recipe R1): ONE lane polls the ONE word relaxed, ONE agent-scope acquire drops this CU's
+            // stale L1 lines, its vmcnt drain holds the barrier for the invalidate, then every wave reads the slab with plain loads
+            // (all of them in flight at once)
+            if (tid == 0) {
+                while (__hip_atomic_load(sa.flag + wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sa.epoch) __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            const float *S = sa.slab + (((long long)(wg + 1) * WV + w) * WD_NB) * 16 * 64;
+            float4 sv[WD_NB][4];
+#pragma unroll
+            for (int u = 0; u < WD_NB; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sv[u][q] = *reinterpret_cast<const float4 *>(S + (((u < NU ? u : 0) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int u = 0; u < WD_NB; ++u)
+                if (u < NU)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[u][4 * q] += sv[u][q].x; acc[u][4 * q + 1] += sv[u][q].y; acc[u][4 * q + 2] += sv[u][q].z; acc[u][4 * q + 3] += sv[u][q].w;
+                    }
+        }
+#pragma unroll
+        for (int u = 0; u < WD_NB; ++u)
+            if (u < NU) {
+                const int col = n0 + 32 * u + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < a.M && col < a.N) E.out[(long long)row * a.N + col] = acc[u][r];
+                }
+            }
+    }
+}
+
+// Host side of k_wide_sk: the fragments of every workgroup.  `a` is a one-evaluation, one-K-range plan (wide_plan(..., split = false)).
+static int wide_plan_sk(const WideArgs &a, int slots, std::vector<SkFrag> &frags) {
+    const int ntc = a.cnt[0] + a.cnt[1], ntile = a.m_tiles * ntc, T = (a.K + 31) / 32;
+    auto nu_of = [&](int t) { const int ct = t % ntc; return ct < a.cnt[0] ? a.nu[0] : a.nu[1]; };
+    long long W = 0, wmax = 0;
+    for (int t = 0; t < ntile; ++t) { W += (long long)T * nu_of(t); if ((long long)T * nu_of(t) > wmax) wmax = (long long)T * nu_of(t); }
+    int nwg = slots;
+    if ((long long)nwg * wmax > W) nwg = (int)(W / wmax);   // a share is at least one (largest) tile long
+    if (nwg < 1) nwg = 1;
+    // boundary i in weighted units -> (tile, stage): the stage a boundary falls into starts the successor's fragment
+    std::vector<int> bt(nwg + 1), bs(nwg + 1);
+    {
+        int t = 0;
+        long long t_start = 0;
+        for (int i = 0; i <= nwg; ++i) {
+            const long long b = i == nwg ? W : (W * i) / nwg;
+            while (t < ntile && t_start + (long long)T * nu_of(t) <= b) { t_start += (long long)T * nu_of(t); ++t; }
+            bt[i] = t;
+            bs[i] = t < ntile ? (int)((b - t_start) / nu_of(t)) : 0;
+        }
+    }
+    frags.assign((size_t)nwg * 3, SkFrag{0, 0, 0, -1});
+    for (int i = 0; i < nwg; ++i) {
+        SkFrag *f = &frags[(size_t)3 * i];
+        int t0 = bt[i];
+        if (bs[i] > 0) { f[0] = SkFrag{t0, bs[i], T, 1}; ++t0; }             // the tail of the tile the predecessor finishes: first, published
+        const int t1 = bt[i + 1];                                            // whole tiles [t0, t1)
+        // whole tiles are run as one "fragment" each; the table holds three entries, so more than one whole tile per workgroup
+        // (small problems) is expressed by shrinking nwg: here a share is < 2 tiles + change by construction only when nwg == slots
+        if (t1 - t0 > 1) return -1;
+        if (t1 - t0 == 1) f[1] = SkFrag{t0, 0, T, 0};
+        if (bs[i + 1] > 0) f[2] = SkFrag{t1, 0, bs[i + 1], 2};               // the head of the tile the successor's slab completes: last
+    }
+    return nwg;
+}
+
 // the wide path takes layer 1 when the observation is wide enough for the split-K forward to fill the chip
 static bool wide_applies(int obs, int h1) { return obs >= 1024 && obs % 4 == 0 && h1 % 4 == 0; }
 
@@ -290,6 +493,8 @@ static hipError_t wide_prepare() {
     WideArgs z{};
     hipError_t e = wide_launch<true, 4, 32>(z, nullptr, true);
     if (e == hipSuccess) e = wide_launch<false, 4, 32>(z, nullptr, true);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_sk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)((size_t)2 * (128 * 32 + 32 * WD_BW) * sizeof(float)));
     return e;
 }
 static void launch_wide_fwd(const WideArgs &a, hipStream_t s) {
@@ -298,5 +503,9 @@ static void launch_wide_fwd(const WideArgs &a, hipStream_t s) {
     k_wide_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a);
 }
 static void launch_wide_wgrad(const WideArgs &a, hipStream_t s) { (void)wide_launch<false, 4, 32>(a, s, false); }
+static void launch_wide_sk(const SkArgs &a, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (128 * 32 + 32 * WD_BW) * sizeof(float);
+    k_wide_sk<<<a.nwg, 256, lds, s>>>(a);
+}
 
 }  // namespace

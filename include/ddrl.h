@@ -471,8 +471,9 @@ int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream)
 int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
                   const float *done_d, float *loss_d, float *q_d, void *stream);
 /* `reps` updates (each exactly ddrl_dqn_step) with a HIP event between the launch groups on `stream`; stage_ms_h[DDRL_DQN_STAGES] receives
- * the mean milliseconds of: 0 input staging, 1 layer-1 forward of all evaluations (+ split-K reduce), 2 layer-2 forward, 3 head forward,
- * 4 rows (backup / loss / dQ), 5 head dgrad + wgrad, 6 layer-2 dgrad + wgrad, 7 layer-1 wgrad, 8 flat Adam + polyak.  Synchronises
+ * the mean milliseconds of: 0 input staging (nothing when the rows are read in place), 1 layer-1 forward of all evaluations (+ split-K
+ * reduce), 2 layer-2 forward, 3 the head launch (Q of every evaluation, backup / loss / dQ, head dgrad), 4 and 5 unused (0),
+ * 6 layer-2 dgrad + wgrad + head wgrad, 7 layer-1 wgrad, 8 flat Adam + polyak.  Synchronises
  * `stream`.  Measurement aid of bench.py's config-5 roofline block (the reference has no counterpart). */
 #define DDRL_DQN_STAGES 9
 int ddrl_dqn_step_timed(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
