@@ -1,5 +1,7 @@
 # usage (GPU box): bash tools/ddqn_cfg5_prof.sh <outdir>  — kernel trace + PMC passes over config 5's Double-DQN update (tools/ddqn_cfg5_prof.py)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/$1; mkdir -p $O
+set -eu
+grep() { command grep "$@" || true; }   # display filters: no match is not an error under set -e
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"; O=gpurun_out/${1:?usage: pass an output tag}; mkdir -p $O
 echo "config 5's learner (Double-DQN update, obs 28 224, batch 512, hidden (400, 300)), tools/ddqn_cfg5_prof.py 30, eager:" > $O/ddqn_cfg5.txt
 python3 tools/ddqn_cfg5_prof.py 50 2>&1 | grep "ddqn update" >> $O/ddqn_cfg5.txt
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 tools/ddqn_cfg5_prof.py 30 > $O/trace.log 2>&1

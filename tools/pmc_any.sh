@@ -1,5 +1,7 @@
 # usage: bash tools/pmc_any.sh <outdir> "<counters...>"  — one rocprofv3 --pmc pass over tools/insitu.py, summary per kernel
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/$1; mkdir -p $O; shift
+set -eu
+grep() { command grep "$@" || true; }   # display filters: no match is not an error under set -e
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"; O=gpurun_out/${1:?usage: pass an output tag}; mkdir -p $O; shift
 for c in "$@"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-60)
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -- python3 tools/insitu.py 40 > $O/pmc_$tag.log 2>&1

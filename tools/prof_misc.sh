@@ -1,5 +1,7 @@
 # The round's micro-benchmark / side measurements, as text files under gpurun_out/<tag>/ (copy what is cited into profiles/).
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/${1:-r3m}; mkdir -p $O
+set -eu
+grep() { command grep "$@" || true; }   # display filters: no match is not an error under set -e
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"; O=gpurun_out/${1:-r3m}; mkdir -p $O
 tools/l2_persist_bench.bin > $O/l2_persist.txt 2>&1
 hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o /tmp/xcc tools/xcc_bench.hip 2>/dev/null && /tmp/xcc > $O/xcc_placement.txt 2>&1
 python3 tools/dp_host_cost.py 2>&1 | grep "us/update" > $O/dp_host_cost.txt

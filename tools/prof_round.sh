@@ -2,7 +2,9 @@
 # dispatch in the cache state the update sequence leaves: tools/insitu.py, eager launches — PMC collection does not survive
 # hipGraph replays on this ROCm) and over the same launches repeated back to back (warm: tools/stage_times.py).
 # usage: bash tools/prof_round.sh <tag>   ->  gpurun_out/<tag>/*, then `python3 tools/make_traffic.py gpurun_out/<tag> rNN` on the host
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/${1:-r3p}; mkdir -p $O
+set -eu
+grep() { command grep "$@" || true; }   # display filters: no match is not an error under set -e
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"; O=gpurun_out/${1:-r3p}; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 2 --gpu-seconds 0 --cpu-budget 3 --no-stages > $O/bench_traced.json 2> $O/bench_traced.err
 python3 tools/trace_summary.py $O/trace > $O/kernel_trace_summary.txt; cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv; rm -rf $O/trace
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 tools/insitu.py 40 > $O/pmc_$c.log 2>&1; python3 tools/pmc_summary.py $O/pmc_$c > $O/pmc_$c.txt 2>&1; rm -rf $O/pmc_$c; done
