@@ -16,6 +16,7 @@ DDRL_ERR_HIP = -3
 DDRL_ERR_NOMEM = -4
 DDRL_ERR_UNSUPPORTED = -5
 DDRL_ERR_NOT_REPRESENTABLE = -6
+DDRL_ERR_RCCL = -7
 DDRL_REPLAY_ACTS_1D = 1
 DDRL_REPLAY_U8_OBS = 2
 DDRL_ENV_STATE_FIELDS = 32
@@ -130,6 +131,15 @@ SIGNATURES = {
     "ddrl_actor_versions_enable": (c_int, [_P, c_int32, _P]),
     "ddrl_actor_versions_state": (c_int, [_P, _P, _P, _P]),
     "ddrl_actor_versions_adopt": (c_int, [_P, _P, c_int64, _P]),
+    "ddrl_comm_unique_id": (c_int, [_P]),
+    "ddrl_comm_init": (c_int, [POINTER(_P), c_int, c_int32, c_int32, _P]),
+    "ddrl_comm_destroy": (c_int, [_P]),
+    "ddrl_comm_bcast_params": (c_int, [_P, _P, c_int64, c_int32, _P]),
+    "ddrl_comm_allreduce_grads": (c_int, [_P, _P, c_int64, _P]),
+    "ddrl_comm_send_batch": (c_int, [_P, _P, c_int64, c_int32, _P]),
+    "ddrl_comm_recv_batch": (c_int, [_P, _P, c_int64, c_int32, _P]),
+    "ddrl_comm_group_start": (c_int, []),
+    "ddrl_comm_group_end": (c_int, []),
     "ddrl_dqn_param_count": (c_int, [_P, POINTER(c_int64)]),
     "ddrl_dqn_create": (c_int, [POINTER(_P), c_int, _P]),
     "ddrl_dqn_destroy": (c_int, [_P]),

@@ -84,6 +84,8 @@ class HyperParameters:
         self.Ln, self.action_repeat, self.save_freq = 8, 2, 1
         self.obs_shape, self.act_shape = (obs_dim,), (act_dim,)
         self.num_envs = 1     # vectorised rollouts: envs stepped together by one worker
+        import os
+        self.summary_dir = os.getcwd() + "/tboard_ray"   # hyperparams.py:99 (TensorBoard scalars of the job == "main" actor)
 
     def config(self, batch=None, variant=0):
         return _lib.Sac1Config(obs_dim=self.obs_dim, act_dim=self.act_dim, hidden1=self.hidden_sizes[0],
@@ -417,6 +419,9 @@ class Actor(_Net):
         self._flat_set(torch.from_numpy(glorot_init(self.specs, opt.seed)).to(self.device))
 
     def __del__(self):
+        w = getattr(self, "_writer", None)
+        if w is not None and hasattr(w, "close"):
+            w.close()
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._lib.ddrl_actor_destroy(h)
@@ -476,10 +481,14 @@ class Actor(_Net):
                 ep_len += 1
             rew.append(ep_ret)
         logdir = getattr(self.opt, "summary_dir", None)
-        if logdir:
+        if logdir and self.job == "main":   # the reference creates its FileWriter for job == "main" only (actor_learner.py:176-179)
             if getattr(self, "_writer", None) is None:
+                import datetime
                 from .logx import SummaryWriter
-                self._writer = SummaryWriter(logdir)
+                # one run directory per writer, named like the reference's: successive runs do not merge into one curve
+                run = "%s-%s-workers_num:%s%%%s" % (datetime.datetime.now(), getattr(self.opt, "env_name", ""), getattr(self.opt, "num_workers", 1),
+                                                      getattr(self.opt, "a_l_ratio", ""))
+                self._writer = SummaryWriter(logdir + "/" + run)
             sample_times = 0
             if replay_buffer is not None:
                 from .workers import _get, _remote

@@ -129,7 +129,7 @@ def worker_test(ps, args, start_time=None, n=10, make_env=None, make_agent=None,
         make_env = lambda name: _default_env(name, args)
     if make_agent is None:
         from .agent import Actor
-        make_agent = lambda a: Actor(a, job="main")
+        make_agent = lambda a: Actor(a, job="test")   # example/dsac.py's test worker logs through EpochLogger only (no tf.summary writer)
     start_time = time.time() if start_time is None else start_time
     agent = make_agent(args)
     keys = agent.get_weights()[0]

@@ -40,7 +40,8 @@ typedef enum {
     DDRL_ERR_HIP = -3,
     DDRL_ERR_NOMEM = -4,
     DDRL_ERR_UNSUPPORTED = -5,
-    DDRL_ERR_NOT_REPRESENTABLE = -6 /* a value stored into a compact (uint8) ring array was not an integer in [0, 255] */
+    DDRL_ERR_NOT_REPRESENTABLE = -6, /* a value stored into a compact (uint8) ring array was not an integer in [0, 255] */
+    DDRL_ERR_RCCL = -7 /* RCCL could not be loaded, or a collective / point-to-point call failed (ddrl_last_error has RCCL's text) */
 } ddrl_status;
 
 int ddrl_version(void);
@@ -509,6 +510,35 @@ int ddrl_winq_buffers(ddrl_winq_t *h, float **arrays_h, int32_t **t_queue_h);
 int ddrl_normal_fill(float *out_d, int64_t n, uint32_t seed, uint64_t counter, void *stream);
 int ddrl_uniform_fill(float *out_d, int64_t n, float lo, float hi, uint32_t seed, uint64_t counter,
                       void *stream);
+
+/* ===================================================================================== */
+/* comm_*: the path's cross-process traffic as RCCL calls (one process per GPU, xGMI), for  */
+/* hosts that bind this library without PyTorch — SURVEY 8(b), last row.  The Python package */
+/* issues the same collectives through torch.distributed (backend "nccl" = RCCL).           */
+/* RCCL is bound at run time: a copy the process already holds is shared, else librccl.so.1  */
+/* (DDRL_RCCL_PATH overrides).  All buffers are DEVICE float32; calls are asynchronous on    */
+/* `stream`; every rank of the communicator makes the matching call.                          */
+/* ===================================================================================== */
+typedef struct ddrl_comm ddrl_comm_t;
+#define DDRL_COMM_ID_BYTES 128
+/* Rank 0 creates the communicator id and hands the 128 bytes to every other rank out of band (the launcher's
+ * rendezvous: a file, an environment variable, MPI ...); then EVERY rank calls ddrl_comm_init with it (collective). */
+int ddrl_comm_unique_id(uint8_t *id_h);
+int ddrl_comm_init(ddrl_comm_t **out, int device, int32_t rank, int32_t world, const uint8_t *id_h);
+int ddrl_comm_destroy(ddrl_comm_t *h);
+/* ps.push(keys, values) on the learner + ps.pull(keys) on every worker (example/dsac.py:59-65; every 300 updates,
+ * algos/sac1/sac1.py:149): ONE broadcast of the flat parameter vector (ddrl_sac1_get_weights / ddrl_ps layout), in place. */
+int ddrl_comm_bcast_params(ddrl_comm_t *h, float *flat_d, int64_t n, int32_t root, void *stream);
+/* Data-parallel learners (example/dsac.py:233 runs num_learners of them unsynchronised; here synchronous): mean of the flat
+ * gradient over the communicator's ranks, in place (ddrl_sac1_grad_buffer's vector between compute_grads and apply_grads). */
+int ddrl_comm_allreduce_grads(ddrl_comm_t *h, float *flat_d, int64_t n, void *stream);
+/* The block of batches a shard owner drew for a learner's step (ddrl_replay_sample_many -> ddrl_replay_set_feed): the reply of
+ * `replay_buffer[i].sample_batch.remote()` (algos/sac1/sac_ray.py:137-141), one point-to-point message per (owner, learner). */
+int ddrl_comm_send_batch(ddrl_comm_t *h, const float *block_d, int64_t n, int32_t peer, void *stream);
+int ddrl_comm_recv_batch(ddrl_comm_t *h, float *block_d, int64_t n, int32_t peer, void *stream);
+/* ncclGroupStart / ncclGroupEnd: several sends / receives as one operation (a rank that both serves and learns; a send to self). */
+int ddrl_comm_group_start(void);
+int ddrl_comm_group_end(void);
 
 #ifdef __cplusplus
 }

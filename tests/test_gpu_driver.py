@@ -252,7 +252,9 @@ def test_worker_test_sac1_saves_best_weights(tmp_path):
     assert best > -1000 and any("weights saved" in l for l in lines) and any(l.startswith("test_reward:") for l in lines)
     import glob
     from distributed_drl_amd import logx
-    ev = logx.read_scalars(glob.glob(str(tmp_path / "tb" / "events.out.tfevents.*"))[0])
+    runs = glob.glob(str(tmp_path / "tb" / "*-LunarLanderContinuous-v2-workers_num:1%2"))   # one run directory, named as actor_learner.py:177-179 names it
+    assert len(runs) == 1
+    ev = logx.read_scalars(glob.glob(runs[0] + "/events.out.tfevents.*")[0])
     assert len(ev) == 2 and all(tag == "Reward" and step == 0 for step, tag, _ in ev)   # one scalar per round, at step sample_times
     w = pickle.load(open(tmp_path / "weights.pickle", "rb"))
     assert set(w.keys()) == set(keys)
