@@ -208,24 +208,24 @@ __global__ void __launch_bounds__(256) k_gather(RingPtrs ring, BatchPtrs out, co
     const float *src = ring.a[j] + row * width;
     float *dst = out.a[j] + (long long)b * width;
     if (ring.kind[j] == 1) {
-        // compact array: one 16-byte load -> four float4 stores per lane, four loads in flight (the row is 28 224 B at config 5)
+        // compact array: one dword (four pixels) in -> one float4 out per lane, so that a wave's store instruction writes 1 KB of
+        // consecutive bytes (the first cut — a 16-byte load and four float4 stores at a 64-byte lane stride — wrote partial lines:
+        // 2.9 TB/s); eight loads in flight per lane.  The batch written is 4x the bytes read: the stores set the rate.
         const unsigned char *s8 = reinterpret_cast<const unsigned char *>(ring.a[j]) + row * width;
-        if ((width & 15) == 0 && aligned16(out.a[j], ring.a[j])) {
-            const int w16 = width >> 4;
-            const uint4 *s16 = reinterpret_cast<const uint4 *>(s8);
+        if ((width & 3) == 0 && aligned16(out.a[j], ring.a[j])) {
+            const int w4 = width >> 2;
+            const unsigned *s32 = reinterpret_cast<const unsigned *>(s8);
             float4 *d4 = reinterpret_cast<float4 *>(dst);
-            auto put = [&](int e, const uint4 v) {
-                const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    d4[4 * e + k] = make_float4((float)(u[k] & 255u), (float)((u[k] >> 8) & 255u), (float)((u[k] >> 16) & 255u), (float)(u[k] >> 24));
-            };
+            auto cvt = [](unsigned u) { return make_float4((float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24)); };
             int e = tid;
-            for (; e + 3 * 256 < w16; e += 4 * 256) {
-                const uint4 a0 = s16[e], a1 = s16[e + 256], a2 = s16[e + 512], a3 = s16[e + 768];
-                put(e, a0); put(e + 256, a1); put(e + 512, a2); put(e + 768, a3);
+            for (; e + 7 * 256 < w4; e += 8 * 256) {
+                unsigned u[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] = s32[e + 256 * k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d4[e + 256 * k] = cvt(u[k]);
             }
-            for (; e < w16; e += 256) put(e, s16[e]);
+            for (; e < w4; e += 256) d4[e] = cvt(s32[e]);
         } else {
             for (int e = tid; e < width; e += 256) dst[e] = (float)s8[e];
         }

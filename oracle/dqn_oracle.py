@@ -3,9 +3,10 @@
 CPU restatement (torch autograd) of the Double-DQN learner of algos/dqn/actor_learner.py:19-107 on
 the network of algos/dqn/core.py:15-18,40-50.  Only tests/ may import this.
 
-PARITY UNPINNED (TensorFlow 1.x absent, no golden vectors in the reference): restated from the
-published ops — tf.one_hot / tf.argmax (first maximum) / tf.stop_gradient, tf.train.AdamOptimizer as
-in oracle/sac1_oracle.py — and checked by finite differences in tests/test_oracle_sac1.py.
+PARITY: composition PINNED by tests/golden/dqn_math.* and sqn_math.* — algos/dqn and algos/sqn actor_learner.py + core.py executed on
+oracle/tf_shim.py (oracle/gen_golden_math.py), incl. config 5's learner shape (batch 512, 28 224-wide pixel observations);
+tests/test_oracle_math_fixtures.py holds both oracles to them at 1e-10 in float64.  From memory (the shim's definitions): tf.one_hot /
+tf.argmax (first maximum) / tf.stop_gradient / tf.nn.log_softmax / tf.make_template, tf.train.AdamOptimizer as in oracle/sac1_oracle.py.
 """
 from collections import OrderedDict
 

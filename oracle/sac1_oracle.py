@@ -11,16 +11,22 @@ Follows:
   Actor.get_action                   algos/sac1/actor_learner.py:195-197
   values                             algos/sac1/hyperparams.py:60,67,78,79,82
 
-PARITY UNPINNED: the arithmetic lives in TensorFlow 1.x (tf.layers.dense, tf.train.AdamOptimizer,
-tf.random_normal), a third-party dependency that is absent from /root/reference and from this
-image, version unpinned (API usage implies 1.12-1.15); the reference holds no tests or golden
-vectors for it.  Restated from the published algorithms:
-  * tf.layers.dense: y = x @ kernel[in,out] + bias; default init glorot-uniform / zeros.
+PARITY: composition PINNED, primitives from memory.  The arithmetic lives in TensorFlow 1.x (tf.layers.dense,
+tf.train.AdamOptimizer, tf.random_normal), a third-party dependency that is absent from /root/reference and from this
+image (version unpinned; API usage implies 1.12-1.15); the reference holds no tests or golden vectors for it.  What pins
+this file: tests/golden/sac1_math.* are produced by EXECUTING the reference's own algos/sac1/actor_learner.py + core.py on
+oracle/tf_shim.py (a lazy TF1-graph stand-in over torch float64; oracle/gen_golden_math.py) — losses, q1/q2/logp_pi per row,
+every per-variable gradient, parameters / targets / Adam slots after three sequential train() calls from main != target,
+Actor.get_action, the variable names and order of get_weights() — and tests/test_oracle_math_fixtures.py holds this oracle to
+them at 1e-10 in float64.  So which tensor feeds which loss, the constants, the clip, the squash / scale order, which
+variables each optimizer steps and the polyak pairing are the reference's code, executed.  What stays from memory (it is the
+shim's definition too, see its header):
+  * tf.layers.dense: y = x @ kernel[in,out] + bias; default init glorot-uniform / zeros; variable naming dense, dense_1, ...
   * tf.train.AdamOptimizer (ApplyAdam): alpha_t = lr*sqrt(1-b2^t)/(1-b1^t);
     m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha_t/(sqrt(v)+eps);  b^t kept as
     running products in the parameter dtype; one optimizer (own t) per minimize() call.
-  * tf.random_normal is replaced by EXPLICIT noise inputs eps_x, eps_x2, eps_t.
-  * execution order fixed as: all forward values and both gradients from pre-update parameters
+  * tf.random_normal is replaced by EXPLICIT noise inputs eps_x, eps_x2, eps_t (the graph's 4th draw is never fetched).
+  * execution order of one sess.run: all forward values and both gradients from pre-update parameters
     -> Adam(pi) -> Adam(q1,q2) -> polyak with the post-update main.
 Self-consistency is checked in tests/test_oracle_sac1.py (closed forms, finite differences in
 float64, float32-vs-float64 agreement).

@@ -8,9 +8,9 @@ Follows:
   mlp_actor_critic (pi, q1, q2, q1_pi, q2_pi, v)     example/core.py:98-127
   min double-Q, q_backup, v_backup, the four losses   example/model.py:33-45
   Adam(pi) -> Adam(q1, q2, v) -> polyak(all main)     example/model.py:47-64
-PARITY UNPINNED for the same reason as oracle/sac1_oracle.py (TensorFlow 1.x is absent; no golden
-vectors in the reference): restated from the published ops, checked by finite differences and
-closed forms in tests/test_oracle_sac1.py::test_sacv_*.
+PARITY: composition PINNED by tests/golden/sacv_math.* — example/model.py + example/core.py executed on oracle/tf_shim.py with
+example/dsac.py's own args (oracle/gen_golden_math.py); tests/test_oracle_math_fixtures.py holds this oracle to them at 1e-10
+in float64.  The TF primitives (dense, ApplyAdam, variable naming) stay from memory, as in oracle/sac1_oracle.py.
 """
 from collections import OrderedDict
 
