@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) k_wide_reduce(WideArgs a) {
 // predecessor started, whole tiles, a head fragment of the tile its successor finishes.  A split tile is combined in-launch:
 // the successor computes its (later-stage) fragment FIRST and publishes the accumulators as a slab (sc1 write-through stores, vmcnt
 // drain, barrier, relaxed agent-scope flag; the flags are zeroed by an earlier launch of the same update: the guide's hand-off recipe R1); the workgroup
-// that holds the head fragment computes it LAST, by which time the slab has long arrived, adds it (sc1 loads) in the fixed order
+// that holds the head fragment computes it LAST, by which time the slab has long arrived, adds it in the fixed order
 // head + tail and writes the tile.  Every sum has one fixed order for a given shape: bit-identical run to run.  A share is at
 // least one tile long, so a tile never spans three workgroups and a workgroup only ever waits for its successor's first action.
 // ==========================================================================================
@@ -347,25 +347,27 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
                     for (int u = 0; u < NUC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[u][j], acc[u], 0, 0, 0);
             }
         };
-        auto run = [&](auto nu_c) {
-            issue(fr.s0, 0);
+        auto run = [&](auto nu_c, int s_begin, int s_end) {
+            issue(s_begin, 0);
             wide_dma_wait();
             __syncthreads();
-            for (int st = fr.s0; st < fr.s1; ++st) {
-                const int cur = (st - fr.s0) & 1;
-                if (st + 1 < fr.s1) issue(st + 1, cur ^ 1);
+            for (int st = s_begin; st < s_end; ++st) {
+                const int cur = (st - s_begin) & 1;
+                if (st + 1 < s_end) issue(st + 1, cur ^ 1);
                 if (active) compute(sA + cur * AOP, sB + cur * WD_BOP, nu_c);
                 wide_dma_wait();
                 __syncthreads();
             }
         };
-        if (fr.s0 < fr.s1 && fr.s1 <= T) {
-            if (NU == 5) run(std::integral_constant<int, 5>{});
-            else if (NU == 4) run(std::integral_constant<int, 4>{});
-            else if (NU == 3) run(std::integral_constant<int, 3>{});
-            else if (NU == 2) run(std::integral_constant<int, 2>{});
-            else run(std::integral_constant<int, 1>{});
-        }
+        auto run_nu = [&](int s_begin, int s_end) {
+            if (s_begin >= s_end || s_end > T) return;
+            if (NU == 5) run(std::integral_constant<int, 5>{}, s_begin, s_end);
+            else if (NU == 4) run(std::integral_constant<int, 4>{}, s_begin, s_end);
+            else if (NU == 3) run(std::integral_constant<int, 3>{}, s_begin, s_end);
+            else if (NU == 2) run(std::integral_constant<int, 2>{}, s_begin, s_end);
+            else run(std::integral_constant<int, 1>{}, s_begin, s_end);
+        };
+        run_nu(fr.s0, fr.s1);
         if (fr.role == 1) {
             // publish: [wave][unit][four-register group][lane] float4 — one fully coalesced 1 KB line per wave-instruction
             float *S = sa.slab + (((long long)wg * WV + w) * WD_NB) * 16 * 64;
@@ -384,8 +386,18 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
             // consume (guide, Guideline 16 recipe R1): ONE lane polls the ONE word relaxed, ONE agent-scope acquire drops this CU's
             // stale L1 lines, its vmcnt drain holds the barrier for the invalidate, then every wave reads the slab with plain loads
             // (all of them in flight at once)
+            // The spin is bounded: the successor publishes as its FIRST action, so with the dispatcher's in-order placement the word is
+            // there long before it is asked for — but dispatch order is no contract, so after ~1 s the kernel traps (a loud HIP error on the
+            // next call) instead of hanging the device.  (Measured alternatives that kept computing instead — this workgroup finishing the
+            // tile's remaining stages itself — cost the fast path 8-14 us of the 11 us gained: a second call site of the stage loop,
+            // accumulators live across the fragment loop, or a second __shared__ object, which makes hipcc wait vmcnt(0) before every
+            // ds_read behind the LDS-DMA loads: 130 -> 182 us.)
             if (tid == 0) {
-                while (__hip_atomic_load(sa.flag + wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sa.epoch) __builtin_amdgcn_s_sleep(4);
+                int spin = 0;
+                while (__hip_atomic_load(sa.flag + wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sa.epoch) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spin > (1 << 21)) __builtin_trap();
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
