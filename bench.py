@@ -346,6 +346,43 @@ def stage_measurements(args, opt, rb, roll, d):
         del lp, m, rbv
     except Exception as e:  # noqa
         out["sac_v_update"] = {"error": repr(e)[:200]}
+    try:   # the reference's own call shapes: host NumPy in / out, one transition per store (PCIe-inclusive; never `value`)
+        import numpy as np
+        from distributed_drl_amd.agent import Learner
+        rbh = d.ReplayBufferSAC1(8, 2, 100000, seed=5)
+        rs = np.random.RandomState(0)
+        oo, aa = rs.randn(8), rs.uniform(-1, 1, 2).astype(np.float32)
+        for _ in range(200):
+            rbh.store(oo, aa, 0.5, oo, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            rbh.store(oo, aa, 0.5, oo, False)                  # example/dsac.py:111: one transition, five host arrays
+        torch.cuda.synchronize()
+        t_store = (time.perf_counter() - t0) / 2000
+        fill_replay(rbh, 100000, 9)
+        t0 = time.perf_counter()
+        for _ in range(300):
+            bh = rbh.sample_batch(B)                            # dict of fresh float32 NumPy arrays (device -> host)
+        t_samp = (time.perf_counter() - t0) / 300
+        lh = Learner(opt, job="learner", index=77)
+        for _ in range(5):
+            lh.train(bh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            lh.train(rbh.sample_batch(B))                       # worker_train's loop body through the host surface
+        torch.cuda.synchronize()
+        t_iter = (time.perf_counter() - t0) / 300
+        out["host_surface_pcie_inclusive"] = {
+            "store_per_s": 1.0 / t_store, "store_us": t_store * 1e6, "sample_batch_per_s": 1.0 / t_samp, "sample_batch_us": t_samp * 1e6,
+            "sample_plus_train_per_s": 1.0 / t_iter, "sample_plus_train_us": t_iter * 1e6,
+            "what": "the reference's call shapes with HOST buffers crossing PCIe on every call: ReplayBuffer.store(obs, act, rew, next_obs, done) "
+                    "of one transition (five NumPy values up), sample_batch(256) (a dict of NumPy arrays down), and worker_train's loop body "
+                    "train(sample_batch()) (batch down and up again, eager launches).  Reported beside the device-resident figures, never as `value`."}
+        del rbh, lh
+    except Exception as e:  # noqa
+        out["host_surface_pcie_inclusive"] = {"error": repr(e)[:200]}
     if args.cfg5_capacity != 0:
         out.update(config5_stages(args, d))
     return out
