@@ -5,5 +5,5 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_
   tag=$(echo $c | tr ' ' '_' | cut -c1-50)
   rocprofv3 --pmc $c --output-format csv -d $O/p_$tag -- python3 tools/rollout_prof.py 100 4096 > $O/p_$tag.log 2>&1
   python3 tools/pmc_summary.py $O/p_$tag > $O/p_$tag.txt 2>&1; rm -rf $O/p_$tag
-  grep "k_actor_fwd\|k_env_step_pi\|counters" $O/p_$tag.txt
+  grep "k_actor_f\|k_env_ste\|k_version\|counters" $O/p_$tag.txt
 done
