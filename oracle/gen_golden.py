@@ -12,6 +12,10 @@ inputs/outputs as small data fixtures under tests/golden/.
 No reference source (or bytecode) is copied; only input/output vectors are written.
 Nothing at test/bench run time reads /root/reference.
 
+The learner MATH fixtures (tests/golden/{sac1,sacv,dqn,sqn}_math.*) come from oracle/gen_golden_math.py, which executes the
+reference's learner classes on oracle/tf_shim.py; this script runs it at the end (a separate process: it installs its own
+`tensorflow` stand-in).
+
 Usage:  python oracle/gen_golden.py            # rewrites tests/golden/*.npz|*.json
 """
 import importlib.util
@@ -403,6 +407,8 @@ def main():
         sys.modules.pop(m, None)
     sac_ray = _load(os.path.join(REF, "algos", "sac1", "sac_ray.py"), "ref_sac_ray", os.path.join(REF, "algos", "sac1"))
     gen_nstep(sac_ray)
+    import subprocess
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen_golden_math.py")])
     print("golden fixtures written to", OUT)
     for fn in sorted(os.listdir(OUT)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(OUT, fn))))
