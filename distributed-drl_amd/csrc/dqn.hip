@@ -6,10 +6,11 @@
 // Double-DQN learner (algos/dqn/actor_learner.py:19-107 on algos/dqn/core.py:40-50):
 // q = mlp(obs -> h1 -> h2 -> n_actions), q_x2 = the same variables at obs2, q_next = target(obs2);
 // q_target = q_next[argmax q_x2]; q_loss = 0.5 mean((r + gamma (1-d) q_target - q[a])^2);
-// one Adam over main/q1, polyak over all.  Every layer (also layer 1: obs_dim is arbitrary here) is a
-// job of the generic MFMA GEMM kernel; 8 launches per update.  Wide observations (obs_dim >= 1024, config 5's 28 224) take
-// layer 1 through the tiled kernels of wide_l1.h instead (forward split over K + reduce; wgrad), reading the caller's
-// observation rows in place.
+// one Adam over main/q1, polyak over all.  Layers 1 and 2 (obs_dim is arbitrary here) are jobs of the generic MFMA GEMM kernel,
+// the head (its forward for every evaluation, the reference's row logic, its dgrad) is ONE launch (k_dqn_head), Adam + polyak one
+// flat launch that also finishes the loss mean: 6 launches per update (+ a staging launch when the rows cannot be read in place).
+// Wide observations (obs_dim >= 1024, config 5's 28 224) take layer 1 through the tiled kernels of wide_l1.h instead (forward split
+// over K + reduce; the weight gradient as equal shares of the stage sequence, k_wide_sk), reading the caller's observation rows in place.
 // variant DDRL_SQN = the soft-Q learner of algos/sqn/actor_learner.py:19-78 on algos/sqn/core.py:30-79:
 // twin networks main/q1, main/q2; evaluations q1(x), q1(x2) (its softmax policy's sum p log p at x2),
 // q2(x) and the targets q1_(x2), q2_(x2); v_backup = min(max q1_, max q2_) - alpha * sum p log p;

@@ -6,7 +6,8 @@
 //
 //   k_wide<true>   forward, split K: partial pre-activations P[ev][s] = X[ev][:, Ks] * W1[ev][Ks, :]
 //   k_wide_reduce  H1[ev] = relu(sum_s P[ev][s] + b1) in split order (deterministic)
-//   k_wide<false>  [dW1 ; db1] = [X | 1]^T dZ1, the whole batch as K
+//   k_wide<false>  [dW1 ; db1] = [X | 1]^T dZ1, the whole batch as K, one tile per workgroup (shapes that do not split evenly)
+//   k_wide_sk      the same product as equal shares of the stage sequence over all resident workgroups (config 5: below)
 //
 // One workgroup = 128 output rows x NU <= 5 column units of 32 (32-36 FLOP per operand byte): 4 waves x (32 rows x NU units),
 // both operands staged through LDS 32 k at a time (double-buffered 2 x 36 KB, so two workgroups share a CU; whole 128-byte
