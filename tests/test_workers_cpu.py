@@ -274,3 +274,15 @@ def test_tensorboard_event_file_roundtrip(tmp_path):
     assert logx.read_scalars(w.path) == [(0, "Reward", -183.5), (300, "Reward", 12.25), (70000, "Reward", 251.0)]
     raw = open(w.path, "rb").read()
     assert b"brain.Event:2" in raw[:64] and os.path.basename(w.path).startswith("events.out.tfevents.")
+
+
+def test_traffic_file_was_taken_on_the_current_kernels():
+    """profiles/traffic.json (the PMC passes behind bench.py's roofline.traffic) carries the sha256 of csrc/*.h, *.hip it was taken on:
+    a kernel change without a new tools/prof_round.sh + tools/make_traffic.py pass fails here, not silently in the bench line."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert t.get("kernel_source_sha256") == bench.kernel_source_hash()
