@@ -490,6 +490,12 @@ def config5_stages(args, d):
                                                 "sample_share": t_g / t_i,
                                                 "what": "sample_batch(512) from the %.0f GB ring + one Double-DQN update, back to back on one stream: the "
                                                         "K = 28 224 layer-1 GEMMs (MFMA-bound), not the 231 MB gather (HBM-bound), set the rate" % (cap * T5 / 1e9)}
+            t_f = timed(lambda: l5.train_from(rb5, 0), 20, warm=3)
+            out["config5_learner_iteration_fused"] = {"ms": t_f * 1e3, "iterations_per_s": 1.0 / t_f, "vs_two_calls": t_f / t_i,
+                                                      "what": "the same iteration as ONE call (ddrl_dqn_step_ring): indices drawn on the ring's stream, acts / rews / done "
+                                                              "gathered, the layer-1 forward's LDS-DMA loads reading the sampled observation rows straight out of the "
+                                                              "ring through the index list, only obs1 (for the weight gradient) gathered: 58 MB of the 231 MB batch; "
+                                                              "bit-identical results (tests/test_gpu_math_fixtures.py)"}
     except Exception as e:  # noqa  (an out-of-memory box must not lose the headline line)
         out["config5_gather"] = dict(out.get("config5_gather", {}), error=str(e)[:200])
     del rb5

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ddrl_replay_counts": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), _P]),
     "ddrl_replay_buffers": (c_int, [_P, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P)]),
     "ddrl_replay_set_counts": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P]),
+    "ddrl_replay_sample_indices": (c_int, [_P, c_int64, _P, _P]),
     "ddrl_replay_create_typed": (c_int, [POINTER(_P), c_int, c_int64, c_int32, POINTER(c_int32), _P, c_int64, c_int64]),
     "ddrl_replay_rows_export": (c_int, [_P, c_int32, c_int64, c_int64, _P, _P]),
     "ddrl_replay_rows_import": (c_int, [_P, c_int32, c_int64, c_int64, _P, _P]),
@@ -148,6 +149,7 @@ SIGNATURES = {
     "ddrl_dqn_import": (c_int, [_P, c_int, _P, _P]),
     "ddrl_dqn_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ddrl_dqn_step_timed": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "ddrl_dqn_step_ring": (c_int, [_P, _P, _P, _P, _P, _P]),
     "ddrl_dqn_q": (c_int, [_P, _P, c_int64, _P, _P]),
     "ddrl_winq_create": (c_int, [POINTER(_P), c_int, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "ddrl_winq_destroy": (c_int, [_P]),

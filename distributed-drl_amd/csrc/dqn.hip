@@ -206,6 +206,30 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
     }
 }
 
+// acts / rews / done of the sampled rows (ddrl_dqn_step_ring: the observation rows stay in the ring)
+__global__ void __launch_bounds__(256) k_dqn_gather3(const float *__restrict__ ra, const float *__restrict__ rr, const float *__restrict__ rd,
+                                                     const long long *__restrict__ idx, float *acts, float *rew, float *done, long long *idx_out, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) {
+        const long long r = idx[i];
+        acts[i] = ra[r]; rew[i] = rr[r]; done[i] = rd[r];
+        if (idx_out) idx_out[i] = r;
+    }
+}
+
+// rows ridx[b] of a ring array -> the staged image x1 [B][ldx] (its ones column is physical and untouched): four 16-byte loads in flight per lane
+__global__ void __launch_bounds__(256) k_dqn_gather_rows(const float *__restrict__ ring, const long long *__restrict__ ridx, float *__restrict__ x1, int width, int ldx) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(ring + ridx[blockIdx.x] * (long long)width);
+    float4 *d4 = reinterpret_cast<float4 *>(x1 + (long long)blockIdx.x * ldx);
+    const int w4 = width >> 2, tid = threadIdx.x;
+    int e = tid;
+    for (; e + 3 * 256 < w4; e += 4 * 256) {
+        const float4 a0 = s4[e], a1 = s4[e + 256], a2 = s4[e + 512], a3 = s4[e + 768];
+        d4[e] = a0; d4[e + 256] = a1; d4[e + 512] = a2; d4[e + 768] = a3;
+    }
+    for (; e < w4; e += 256) d4[e] = s4[e];
+}
+
 __global__ void __launch_bounds__(256) k_dqn_stage(const float *o1, const float *o2, const float *ac, const float *r, const float *d,
                                                    float *x1, float *x2, float *acts, float *rew, float *done, int B, int obs, int ldx) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -235,6 +259,7 @@ struct ddrl_dqn {
     GemmJobs g_f1, g_f2, g_f3, g_b2, g_b1;   // g_f3: the head forward as GEMM jobs, ddrl_dqn_q only (the update's head lives in k_dqn_head)
     HeadArgs head;
     float *hpart;
+    long long *ring_idx;  // the sampled indices of ddrl_dqn_step_ring
     AdamArgs ad;
     bool wide;            // layer 1 on wide_l1.h
     WideArgs wf, ww[2];   // forward (all evaluations), wgrad per network
@@ -306,6 +331,8 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     ALLOC(H1, (size_t)5 * B * h->ldh1); ALLOC(H2, (size_t)5 * B * h->ldh2); ALLOC(Q, (size_t)5 * B * h->ldq); ALLOC(dQ, (size_t)2 * B * h->ldq);
     ALLOC(dZ2, (size_t)2 * B * h2); ALLOC(dZ1, (size_t)2 * B * h1); ALLOC(loss, 4); ALLOC(qsel, B);
     ALLOC(hpart, (size_t)(B + HEAD_ROWS - 1) / HEAD_ROWS + 64);
+    float *ring_idx_f = nullptr;
+    items.push_back(Item{&ring_idx_f, reserve((size_t)2 * B + 64)});
     h->wide = wide_applies(o, h1);
     const int nev_all = cfg->variant == DDRL_SQN ? 5 : 3;
     if (h->wide) {
@@ -324,6 +351,7 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         return DDRL_ERR_NOMEM;
     }
     for (auto &it : items) *it.p = h->slab + it.off;
+    h->ring_idx = reinterpret_cast<long long *>(ring_idx_f);   // (slab offsets are multiples of 64 floats: 8-byte aligned)
     h->opt = reinterpret_cast<OptState *>(h->slab + opt_off);
     h->segs_d = reinterpret_cast<Seg *>(h->slab + segs_off);
     DDRL_HIP_CHECK(hipMemcpy(h->segs_d, h->segs.data(), h->segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
@@ -470,8 +498,9 @@ int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream)
 
 // The launches of one update.  ev != nullptr: an event after every stage (DDRL_DQN_STAGES + 1 events, ev[0] first) for
 // ddrl_dqn_step_timed; the update itself is the same either way.
+// ridx != nullptr: obs1_d / obs2_d are the replay ring's observation arrays and batch row r is their row ridx[r] (ddrl_dqn_step_ring).
 static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,
-                           float *loss_d, float *q_d, hipStream_t s, hipEvent_t *ev) {
+                           float *loss_d, float *q_d, hipStream_t s, hipEvent_t *ev, const long long *ridx = nullptr) {
     const int B = h->cfg.batch, o = h->cfg.obs_dim;
     int e = 0;
 #define STAGE_MARK() do { if (ev) DDRL_HIP_CHECK(hipEventRecord(ev[e++], s)); } while (0)
@@ -489,6 +518,7 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
         for (int k = 0; k < f.nev; ++k) {
             f.ev[k].A = in_place ? (h->wf_x2[k] ? obs2_d : obs1_d) : (h->wf_x2[k] ? h->x2 : h->x1);
             f.ev[k].lda = in_place ? o : h->ldx;
+            f.ev[k].ridx = ridx;
         }
         launch_wide_fwd(f, s);
     } else {
@@ -508,16 +538,20 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
     launch_gemm(h->g_b2, s);
     STAGE_MARK();   // 6 layer-2 dgrad + wgrad
     if (h->wide) {
+        // ring rows (ridx): the gradient contracts over the batch rows, so it reads a gathered copy of obs1 (the one array of the
+        // batch that is still materialised: 58 MB of the 231)
+        const bool direct = in_place && !ridx;
+        if (ridx) k_dqn_gather_rows<<<B, 256, 0, s>>>(obs1_d, ridx, h->x1, o, h->ldx);
         for (int nn = 0; nn < h->nnet; ++nn) {
             if (h->sk_on) {
                 SkArgs g = h->sk[nn];
-                g.w.ev[0].A = in_place ? obs1_d : h->x1;
-                g.w.ev[0].lda = in_place ? o : h->ldx;
+                g.w.ev[0].A = direct ? obs1_d : h->x1;
+                g.w.ev[0].lda = direct ? o : h->ldx;
                 launch_wide_sk(g, s);
             } else {
                 WideArgs g = h->ww[nn];
-                g.ev[0].A = in_place ? obs1_d : h->x1;
-                g.ev[0].lda = in_place ? o : h->ldx;
+                g.ev[0].A = direct ? obs1_d : h->x1;
+                g.ev[0].lda = direct ? o : h->ldx;
                 launch_wide_wgrad(g, s);
             }
         }
@@ -549,6 +583,29 @@ int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const
     DDRL_REQUIRE(h != nullptr && obs1_d && obs2_d && acts_d && rews_d && done_d, "NULL pointer");
     ddrl::DeviceGuard g(h->device);
     return dqn_step_launch(h, obs1_d, obs2_d, acts_d, rews_d, done_d, loss_d, q_d, ddrl::as_stream(stream), nullptr);
+}
+
+int ddrl_dqn_step_ring(ddrl_dqn_t *h, ddrl_replay_t *replay, float *loss_d, float *q_d, int64_t *idx_out_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && replay != nullptr, "NULL handle");
+    const int B = h->cfg.batch, o = h->cfg.obs_dim;
+    const ddrl_replay_dev::SamplerView rv = ddrl_replay_sampler_view(replay);
+    if (!h->wide) {
+        ddrl::set_error("ddrl_dqn_step_ring needs the wide layer-1 path (obs_dim >= 1024): use ddrl_replay_sample + ddrl_dqn_step");
+        return DDRL_ERR_UNSUPPORTED;
+    }
+    DDRL_REQUIRE(rv.ring.n_arr == 5 && rv.ring.w[0] == o && rv.ring.w[1] == o && rv.ring.w[2] == 1 && rv.ring.w[3] == 1 && rv.ring.w[4] == 1,
+                 "the ring must be (obs1[obs_dim], obs2[obs_dim], acts, rews, done) of this learner's observation width");
+    if (rv.ring.kind[0] || rv.ring.kind[1]) {
+        ddrl::set_error("ddrl_dqn_step_ring reads float32 observation rows: a compact (uint8) ring goes through ddrl_replay_sample + ddrl_dqn_step");
+        return DDRL_ERR_UNSUPPORTED;
+    }
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    long long *idx = h->ring_idx;
+    int rc = ddrl_replay_sample_indices(replay, B, reinterpret_cast<int64_t *>(idx), stream);   // np.random.randint(0, size, B); sample_times += 1
+    if (rc != DDRL_OK) return rc;
+    k_dqn_gather3<<<(B + 255) / 256, 256, 0, s>>>(rv.ring.a[2], rv.ring.a[3], rv.ring.a[4], idx, h->acts, h->rew, h->done, reinterpret_cast<long long *>(idx_out_d), B);
+    return dqn_step_launch(h, rv.ring.a[0], rv.ring.a[1], h->acts, h->rew, h->done, loss_d, q_d, s, nullptr, idx);
 }
 
 int ddrl_dqn_step_timed(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d, const float *done_d,

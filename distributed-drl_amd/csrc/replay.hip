@@ -561,6 +561,27 @@ int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, 
     return DDRL_OK;
 }
 
+int ddrl_replay_sample_indices(ddrl_replay_t *h, int64_t batch, int64_t *idx_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && idx_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(batch > 0 && batch <= (1 << 24), "batch must be in [1, 2^24]");
+    DDRL_REQUIRE(!h->feed_on, "a feed plan is attached to this ring");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    if (h->h_size <= 0 || h->h_dirty) {
+        int rc = refresh_counts(h, s);
+        if (rc != DDRL_OK) return rc;
+        if (h->h_size <= 0) {
+            ddrl::set_error("high <= 0");  // message of the reference's ValueError
+            return DDRL_ERR_EMPTY_BUFFER;
+        }
+    }
+    BatchPtrs none{};
+    k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, none, (int)batch, reinterpret_cast<long long *>(idx_d), 0);
+    DDRL_LAUNCH_CHECK();
+    h->h_samples += h->ring.samples_inc;
+    return DDRL_OK;
+}
+
 int ddrl_replay_sample(ddrl_replay_t *h, int64_t batch, float *obs1_d, float *obs2_d, float *acts_d,
                        float *rews_d, float *done_d, int64_t *idx_d, void *stream) {
     DDRL_REQUIRE(h != nullptr && h->ring.n_arr == 5, "not a 5-array (obs1, obs2, acts, rews, done) ring");

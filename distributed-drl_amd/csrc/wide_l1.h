@@ -36,6 +36,12 @@ struct WideEval {
     const float *bias;  // forward only
     float *out;         // forward: H1 [M][ldo] (written by k_wide_reduce)   wgrad: G [(a_rows + 1)][N]
     long long lda;
+    // optional row indirection of the forward's M rows: row r of the operand is row ridx[r] of A.  The observation rows of a sampled
+    // batch are then read straight out of the replay ring — the LDS-DMA loads take per-lane source addresses anyway — and three
+    // quarters of sample_batch(512)'s 231 MB gather never happen (ddrl_dqn_step_ring).  (The same for the K rows of the weight
+    // gradient was built and measured: ring-row numbers in LDS, one lookup per 1 KB piece — the kernel, already at 256 VGPRs, went
+    // from 134 to 163 us with 189 spilled SGPRs; the gradient contracts a gathered copy of obs1 instead.)
+    const long long *ridx;
 };
 struct WideArgs {
     WideEval ev[WD_MAXEV];
@@ -111,7 +117,8 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
         if (FWD) {
             const int row = 8 * I + (lane >> 3), q = (lane & 7) ^ ((row >> 1) & 7);
             ak[i] = 4 * q;
-            pa[i] = m0 + row < a.a_rows ? E.A + (long long)(m0 + row) * E.lda + 4 * q : nullptr;
+            const long long rr = (E.ridx && m0 + row < a.a_rows) ? E.ridx[m0 + row] : m0 + row;
+            pa[i] = m0 + row < a.a_rows ? E.A + rr * E.lda + 4 * q : nullptr;
         } else {
             const int kk = WV == 8 ? I : 2 * I + (lane >> 5), i0 = m0 + 4 * (WV == 8 ? lane : lane & 31);
             ak[i] = kk;

@@ -112,6 +112,24 @@ class Learner:
             return self.loss, q
         return None
 
+    def train_from(self, replay_buffer, cnt=0, return_outputs=False, with_indices=False):
+        """One iteration of the learner's loop — `agent.train(replay_buffer.sample_batch(), cnt)` (algos/dqn/train.py:66-76) — with the
+        layer-1 forward reading its observation rows straight out of the device ring (ddrl_dqn_step_ring): same index stream, same
+        counters, bit-identical results, a quarter of the batch materialised.  Falls back to sample_batch_device + train where the fused
+        path does not apply (a compact ring, observations narrower than 1024)."""
+        B = self.cfg.batch
+        q = torch.empty(B, self.cfg.n_actions, dtype=torch.float32, device=self.device) if return_outputs else None
+        idx = torch.empty(B, dtype=torch.int64, device=self.device) if with_indices else None
+        rc = self._lib.ddrl_dqn_step_ring(self._h, replay_buffer._h, _lib.dptr(self.loss), _lib.dptr(q), _lib.dptr(idx), _lib.stream_ptr())
+        if rc == _lib.DDRL_ERR_UNSUPPORTED:
+            b = replay_buffer.sample_batch_device(B, with_indices=with_indices)
+            out = self.train(b, cnt, return_outputs=return_outputs)
+            return (out + (b["idxs"],)) if (return_outputs and with_indices) else out
+        _lib.check(rc)
+        if return_outputs:
+            return (self.loss, q, idx) if with_indices else (self.loss, q)
+        return None
+
     def stage_times(self, batch, reps=10):
         """Mean milliseconds per launch group of `reps` updates on `batch` (ddrl_dqn_step_timed; bench.py's config-5 roofline)."""
         B = self.cfg.batch

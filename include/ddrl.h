@@ -120,6 +120,10 @@ int ddrl_replay_store_ex(ddrl_replay_t *h, const float *const *src_h, int64_t n,
 int ddrl_replay_store_masked_ex(ddrl_replay_t *h, const float *const *src_h, const uint8_t *mask_d, int64_t n, void *stream);
 int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, int64_t *idx_d, void *stream);
 int ddrl_replay_gather_ex(ddrl_replay_t *h, const int64_t *idx_d, int64_t batch, float *const *out_h, void *stream);
+/* The index draw of sample_batch alone: idx_d[batch] = np.random.randint(0, size, batch) on the ring's stream (advances it and
+ * sample_times exactly like ddrl_replay_sample); the rows stay where they are — for a consumer that reads them out of the ring itself
+ * (ddrl_dqn_step_ring). */
+int ddrl_replay_sample_indices(ddrl_replay_t *h, int64_t batch, int64_t *idx_d, void *stream);
 /* `count` consecutive sample_batch(batch) calls in one launch sequence: out_h[j] is [count*batch, w_j], batch i = rows
  * [i*batch, (i+1)*batch).  Consumes the index stream exactly like `count` separate calls and advances sample_times
  * by count * samples_inc.  A shard owner draws the block of batches it owes a remote learner for one step with it
@@ -471,6 +475,15 @@ int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream)
  * has passed the step (the ordinary stream-order contract of every borrowed input here); other inputs are copied by the first launch. */
 int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const float *acts_d, const float *rews_d,
                   const float *done_d, float *loss_d, float *q_d, void *stream);
+/* One whole iteration of the learner's loop — `batch = replay_buffer.sample_batch(); agent.train(batch, cnt)` (algos/dqn/train.py:66-76 +
+ * actor_learner.py:110-119) — without materialising the batch: the indices are drawn on the ring's own stream (== ddrl_replay_sample_indices),
+ * acts / rews / done are gathered (3 x batch floats), the layer-1 FORWARD of every evaluation reads its observation rows straight out of
+ * the ring through the index list (the LDS-DMA loads take per-lane source addresses), and only obs1 — which the layer-1 weight gradient
+ * contracts over the batch — is gathered (58 MB of config 5's 231 MB).  Results are bit-identical to ddrl_replay_sample + ddrl_dqn_step.
+ * Needs the wide layer-1 path (obs_dim >= 1024) and a float32 five-array ring of this observation width on the same device; else
+ * DDRL_ERR_UNSUPPORTED (use the two calls).  idx_out_d[batch] (nullable) receives the indices.  The ring rows must stay unchanged until
+ * `stream` has passed the call. */
+int ddrl_dqn_step_ring(ddrl_dqn_t *h, ddrl_replay_t *replay, float *loss_d, float *q_d, int64_t *idx_out_d, void *stream);
 /* `reps` updates (each exactly ddrl_dqn_step) with a HIP event between the launch groups on `stream`; stage_ms_h[DDRL_DQN_STAGES] receives
  * the mean milliseconds of: 0 input staging (nothing when the rows are read in place), 1 layer-1 forward of all evaluations (+ split-K
  * reduce), 2 layer-2 forward, 3 the head launch (Q of every evaluation, backup / loss / dQ, head dgrad), 4 and 5 unused (0),

@@ -194,6 +194,12 @@ class _Cfg5Opt:
     buffer_size, save_dir = 1536, "."
 
 
+def _pixel_like(rs, n, obs_dim):
+    o1 = rs.randint(0, 256, (n, obs_dim)).astype(np.float32)
+    o2 = rs.randint(0, 256, (n, obs_dim)).astype(np.float32)
+    return o1, rs.randint(0, 4, n).astype(np.float32), rs.randn(n).astype(np.float32), o2, (rs.rand(n) < 0.05).astype(np.float32)
+
+
 def _cfg5_batches(n, seed=1):
     g = torch.Generator(device="cuda").manual_seed(seed)
     o = _Cfg5Opt
@@ -289,3 +295,46 @@ def test_config5_whole_iteration_vs_oracle(ddrl):
     # always multiplied by a dead unit) the float32 and float64 steps may differ by up to lr each; everywhere else by rounding
     err = np.abs(a - b)
     assert err.max() <= 3 * 1.01 * o.lr and (err > 3 * 2e-2 * o.lr + 1e-7).mean() <= 1e-5, (err.max(), (err > 3 * 2e-2 * o.lr + 1e-7).mean())
+
+
+@pytest.mark.parametrize("variant", ["ddqn", "sqn"])
+def test_config5_iteration_out_of_the_ring_equals_sample_then_train(ddrl, variant):
+    """ddrl_dqn_step_ring — `agent.train(replay_buffer.sample_batch())` (algos/dqn/train.py:66-76) with the layer-1 GEMMs reading the
+    sampled observation rows straight out of the ring (no 231 MB batch) — against the two-call form on a twin ring and a twin learner:
+    the same indices (NumPy's stream), bit-identical loss, q, gradient, parameters, targets and Adam moments over three iterations,
+    the same counters and sampler state."""
+    from distributed_drl_amd import _lib, dqn
+    o = _Cfg5Opt
+    rings, learners = [], []
+    rs = np.random.RandomState(6)
+    tr = _pixel_like(rs, 1536, o.obs_dim)
+    for k in range(2):
+        buf = ddrl.ReplayBufferDQN(o, 0, seed=33)
+        buf.store_batch(*(torch.from_numpy(x).cuda() for x in tr))
+        rings.append(buf)
+        ln = (dqn.LearnerSQN if variant == "sqn" else dqn.Learner)(o, "learner")
+        names, vals = ln.get_weights()
+        ln.set_weights(names[:1], [vals[0] * np.float32(1.0 / 64)])
+        learners.append(ln)
+    want_idx = np.random.RandomState(33)
+    for it in range(3):
+        loss_a, q_a, idx_a = learners[0].train_from(rings[0], it, return_outputs=True, with_indices=True)
+        b = rings[1].sample_batch_device(512, with_indices=True)
+        loss_b, q_b = learners[1].train(b, it, return_outputs=True)
+        np.testing.assert_array_equal(idx_a.cpu().numpy(), want_idx.randint(0, 1536, 512))
+        assert torch.equal(idx_a, b["idxs"]) and torch.equal(loss_a, loss_b) and torch.equal(q_a, q_b), it
+        for w in (_lib.SAC1_GRAD, _lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V):
+            assert torch.equal(learners[0].export(w), learners[1].export(w)), (it, w)
+    assert rings[0].get_counts() == rings[1].get_counts() == (3, 1536, 1536)
+    k0, p0 = rings[0].mt_state()
+    k1, p1 = rings[1].mt_state()
+    assert p0 == p1 and (k0 == k1).all()
+    # where the fused path does not apply the same call falls back to the two-call form: a compact ring
+    cbuf = ddrl.ReplayBufferDQN(o, 0, seed=33, compact_obs=True)
+    cbuf.store_batch(*(torch.from_numpy(x).cuda() for x in tr))
+    fbuf = ddrl.ReplayBufferDQN(o, 0, seed=33)
+    fbuf.store_batch(*(torch.from_numpy(x).cuda() for x in tr))
+    la, lb = ((dqn.LearnerSQN if variant == "sqn" else dqn.Learner)(o, "learner") for _ in range(2))
+    la.train_from(cbuf, 0)
+    lb.train_from(fbuf, 0)
+    assert torch.equal(la.export(_lib.SAC1_MAIN), lb.export(_lib.SAC1_MAIN))
