@@ -132,6 +132,7 @@ SIGNATURES = {
     "ddrl_actor_versions_enable": (c_int, [_P, c_int32, _P]),
     "ddrl_actor_versions_state": (c_int, [_P, _P, _P, _P]),
     "ddrl_actor_versions_adopt": (c_int, [_P, _P, c_int64, _P]),
+    "ddrl_actor_act_versioned": (c_int, [_P, _P, _P, c_int64, c_int, c_int32, _P, _P]),
     "ddrl_comm_unique_id": (c_int, [_P]),
     "ddrl_comm_init": (c_int, [POINTER(_P), c_int, c_int32, c_int32, _P]),
     "ddrl_comm_destroy": (c_int, [_P]),

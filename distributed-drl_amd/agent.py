@@ -453,6 +453,17 @@ class Actor(_Net):
         ended = ended.to(device=self.device, dtype=torch.uint8).contiguous()
         _lib.check(self._lib.ddrl_actor_versions_adopt(self._h, _lib.dptr(ended), int(ended.numel()), _lib.stream_ptr()))
 
+    def get_actions_versioned(self, obs, horizon_steps, deterministic=False, eps=None, out=None):
+        """get_actions with every env evaluated against the policy version in its slot (enable_versions first; all max_rows envs)."""
+        obs = self._dev(obs, (-1, self.cfg.obs_dim))
+        n, a = obs.shape[0], self.cfg.act_dim
+        if not deterministic:
+            eps = self._normal(n * a).view(n, a) if eps is None else self._dev(eps, (n, a))
+        act = out if out is not None else torch.empty(n, a, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ddrl_actor_act_versioned(self._h, _lib.dptr(obs), _lib.dptr(eps if not deterministic else None), n,
+                                                      1 if deterministic else 0, int(horizon_steps), _lib.dptr(act), _lib.stream_ptr()))
+        return act
+
     def get_actions(self, obs, deterministic=False, eps=None, out=None):
         """Batched get_action on device tensors: obs[n, obs_dim] -> act[n, act_dim]."""
         obs = self._dev(obs, (-1, self.cfg.obs_dim))

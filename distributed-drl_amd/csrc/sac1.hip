@@ -1962,6 +1962,44 @@ __global__ void __launch_bounds__(1024) k_version_group(const int *__restrict__ 
     }
 }
 
+// get_action from the head partials of a (versioned) forward launch — what k_env_step_pi does before it steps the physics — for callers
+// that step their envs themselves (the n-step rollout: ddrl_actor_act_versioned).  One lane per row, same summation order.
+struct FinishArgs {
+    const float *hp;          // [8][n][16]
+    const float *bmu, *bls;   // slot 0's head biases; slot s: + s * vstride (slot == nullptr: the current weights')
+    const int *slot;
+    long long vstride, n;
+    const float *eps;         // [n][act] (nullptr when deterministic)
+    float *act_out;           // [n][act]
+    int act, nt2, deterministic;
+    float scale;
+};
+__global__ void __launch_bounds__(64) k_actor_finish(FinishArgs a) {
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x, n = a.n;
+    if (i >= n) return;
+    const int nq = (a.nt2 + 3) >> 2;
+    const long long voff = a.slot ? (long long)a.slot[i] * a.vstride : 0;
+    float mu[4], ls[4], ev[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float sm = 0.f, sl = 0.f;
+        if (c < a.act) {
+            for (int q = 0; q < nq; ++q) {   // n-tile order; slots beyond nt2 hold 0
+                const float4 m4 = *reinterpret_cast<const float4 *>(a.hp + ((long long)c * n + i) * 16 + 4 * q);
+                const float4 l4 = *reinterpret_cast<const float4 *>(a.hp + ((long long)(a.act + c) * n + i) * 16 + 4 * q);
+                sm += m4.x; sm += m4.y; sm += m4.z; sm += m4.w;
+                sl += l4.x; sl += l4.y; sl += l4.z; sl += l4.w;
+            }
+        }
+        const int cc = c < a.act ? c : 0;
+        mu[c] = sm + a.bmu[voff + cc];
+        ls[c] = sl + a.bls[voff + cc];
+        ev[c] = (a.deterministic || c >= a.act || !a.eps) ? 0.f : a.eps[i * a.act + c];
+    }
+    const ddrl_pol::PolRow pr = ddrl_pol::policy_row(mu, ls, ev, a.act, a.scale);
+    for (int c = 0; c < a.act; ++c) a.act_out[i * a.act + c] = a.deterministic ? tanhf(mu[c]) * a.scale : pr.act[c];
+}
+
 __global__ void __launch_bounds__(256) k_version_adopt(int *__restrict__ slot, const uint8_t *__restrict__ ended, long long n, const VerState *vs) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n && ended[i]) slot[i] = vs->newest;
@@ -2079,6 +2117,31 @@ int ddrl_actor_versions_state(ddrl_actor_t *h, int32_t *slot_of_env_d, int32_t *
         DDRL_HIP_CHECK(hipStreamSynchronize(s));
         state_h[0] = vs.newest; state_h[1] = vs.live; state_h[2] = vs.n_tiles; state_h[3] = vs.err;
     }
+    return DDRL_OK;
+}
+
+int ddrl_actor_act_versioned(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int64_t n, int deterministic, int32_t horizon_steps,
+                             float *act_d, void *stream) {
+    DDRL_REQUIRE(h != nullptr && obs_d != nullptr && act_d != nullptr, "NULL pointer");
+    DDRL_REQUIRE(h->n_slots > 0 && n == h->max_rows, "version store not enabled, or n != max_rows");
+    DDRL_REQUIRE(deterministic || eps_d != nullptr, "eps is required for stochastic actions");
+    DDRL_REQUIRE(h->cfg.act_dim <= 4 && horizon_steps >= 1, "act_dim <= 4 and horizon_steps >= 1");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    const ddrl_sac1_config_t &c = h->cfg;
+    DDRL_HIP_CHECK(hipMemcpyAsync(h->obs_d, obs_d, (size_t)n * c.obs_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // `horizon_steps` after the last set_weights every env has been through an episode end: one version, the plain launch
+    const bool versioned = h->steps_since_install < (long long)horizon_steps;
+    h->steps_since_install += 1;
+    const int rc = ddrl_actor_internal_forward(h, n, stream, versioned ? 1 : 0);
+    if (rc != DDRL_OK) return rc;
+    FinishArgs f{};
+    f.hp = h->hp_d; f.n = n; f.eps = deterministic ? nullptr : eps_d; f.act_out = act_d; f.act = c.act_dim; f.nt2 = (c.hidden2 + 31) / 32;
+    f.deterministic = deterministic; f.scale = (float)c.act_scale;
+    f.slot = versioned ? h->slot_d : nullptr; f.vstride = h->vstride;
+    f.bmu = (versioned ? h->vslab : h->pi_d) + h->Ld.pi_bmu; f.bls = (versioned ? h->vslab : h->pi_d) + h->Ld.pi_bls;
+    k_actor_finish<<<(unsigned)((n + 63) / 64), 64, 0, s>>>(f);
+    DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
 

@@ -419,15 +419,32 @@ class RolloutDeviceNStep:
         self.act = torch.empty(n, 2, dtype=torch.float32, device=self.env.device)
         self.pick = np.random.RandomState(int(opt.seed) + 7919 * int(worker_index))
         self.pull()
+        # Weight adoption as in RolloutDevice: "episode" (default) = every env acts on what ITS OWN episode end pulled
+        # (sac_ray.py:252-262: at `d or ep_len * action_repeat >= max_ep_len`, and only once the buffer's steps exceed start_steps),
+        # through the actor's version store; "step" = every env on the newest weights from the next vector step on.
+        self.adopt = getattr(opt, "adopt", "episode")
+        self._versions = False
+        self._learning = bool(getattr(opt, "weights_file", ""))   # steps > start_steps seen (sticky): pulls happen from then on
+        if self.adopt == "episode" and self.actor is not None and n % 32 == 0:
+            try:
+                self.actor.enable_versions(min(2048, min(n, self.limit_steps) + 2))
+                self._versions = True
+            except ValueError:       # a policy outside the direct-operand envelope: whole-vector swap
+                self._versions = False
 
     pull = RolloutDevice.pull
 
     def step(self):
         """One vector step = num_envs iterations of sac_ray.py:208-262."""
         env, opt = self.env, self.opt
+        if self._versions:
+            self.pull()              # what the server holds now is what an env ending its episode in this step would pull
         self.o.copy_(env.obs)
         if self.actor is not None and (self.filling_steps > opt.start_steps or getattr(opt, "weights_file", "")):
-            self.actor.get_actions(self.o, out=self.act)
+            if self._versions:
+                self.actor.get_actions_versioned(self.o, self.limit_steps, out=self.act)
+            else:
+                self.actor.get_actions(self.o, out=self.act)
         else:
             env.sample_actions(out=self.act)
             self.filling_steps += 1
@@ -436,8 +453,14 @@ class RolloutDeviceNStep:
         ready = self.winq.push(o2, self.act, r, d)
         rb = self.rbs[int(self.pick.choice(len(self.rbs), 1)[0])]   # replay_buffer[np.random.choice(opt.num_buffers, 1)[0]]
         rb.store_masked(*self.winq.arrays, ready)
+        if self._versions:
+            if not self._learning:   # sac_ray.py:255-259: the worker reads the buffer's counters at its episode end, after its store
+                self._learning = self.rbs[0].get_counts()[1] > opt.start_steps   # (a device round trip per step, in the filling phase only)
+            if self._learning:
+                self.actor.adopt_where_ended(ended)
         self.winq.begin(next_obs, ended)
-        self.pull()
+        if not self._versions:
+            self.pull()
 
 
 class TrainDevice:

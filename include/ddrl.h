@@ -429,6 +429,12 @@ int ddrl_env_step_wrapped(ddrl_env_t *h, float *act_d, float act_noise, float ob
 int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream);
 int ddrl_actor_versions_state(ddrl_actor_t *h, int32_t *slot_of_env_d, int32_t *state_h, void *stream);
 int ddrl_actor_versions_adopt(ddrl_actor_t *h, const uint8_t *ended_d, int64_t n, void *stream);
+/* get_action for all max_rows envs, each against the version in its slot (obs_d[n, obs_dim], eps_d[n, act] explicit normals, act_d[n, act]):
+ * the versioned form of ddrl_actor_act for a caller that steps its envs itself (the n-step rollout of algos/sac1/sac_ray.py:208-262, followed
+ * by ddrl_actor_versions_adopt with the step's episode ends).  horizon_steps = the envs' episode limit in calls: that many calls after the
+ * last set_weights every env has adopted the newest version and the plain single-version launch is used. */
+int ddrl_actor_act_versioned(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int64_t n, int deterministic, int32_t horizon_steps,
+                             float *act_d, void *stream);
 int ddrl_rollout_begin(ddrl_env_t *h, ddrl_actor_t *actor, void *stream);
 int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay, int32_t n_steps, uint32_t noise_seed,
                       uint64_t noise_ctr, int deterministic, float *act_out_d, float *next_obs_out_d, void *stream);

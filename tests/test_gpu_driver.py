@@ -548,3 +548,44 @@ def test_versioned_rollout_actions_match_each_versions_own_policy():
             vers[newest] = version(newest)
             ps.push(keys, vers[newest])
     assert len(set(holds)) >= 3
+
+
+def test_nstep_rollout_weight_adoption_equals_the_reference_workers():
+    """The n-step driver's worker (algos/sac1/sac_ray.py:208-262) pulls at ITS episode end, and only once the buffer's `steps` exceed
+    start_steps (:259-262).  RolloutDeviceNStep(adopt="episode") must act, per env and per step, on exactly the version that env's own
+    worker would hold.  Bias-coded versions, no action noise, staggered episode limits, a push after almost every step."""
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd.agent import HyperParameters, Learner
+    n, steps = 64, 50
+    opt = HyperParameters()
+    opt.num_envs, opt.seed, opt.Ln, opt.max_ep_len, opt.action_repeat, opt.start_steps = n, 3, 4, 14, 2, 0
+    opt.buffer_size, opt.batch_size, opt.num_buffers = 4000, 8, 1
+    opt.obs_noise, opt.act_noise, opt.reward_scale = 0.0, 0.0, 1
+    keys, vals = Learner(opt).get_weights()
+    ps = ddrl.ParameterServer(keys, _coded_weights(keys, vals, 0))
+    rb = ddrl.ReplayBufferNStep(opt)
+    ro = ddrl.RolloutDeviceNStep(ps, rb, opt)
+    assert ro._versions and ro.limit_steps == 7 and ro.actor.n_slots == 9
+    EPLEN = 10
+    st0 = ro.env.get_state()
+    st0[EPLEN] = torch.arange(n, device="cuda").float() % ro.limit_steps
+    ro.env.set_state(st0)
+    holds = np.zeros(n, int)       # the version env i's worker holds (the initial pull: version 0)
+    newest, learning, seen = 0, False, set()
+    for s in range(steps):
+        policy_phase = ro.filling_steps > opt.start_steps
+        ro.step()
+        learning = learning or rb.get_counts()[1] > opt.start_steps       # what the worker reads at its episode end, after its store (:255)
+        if policy_phase:
+            a0 = ro.act[:, 0].cpu().numpy()
+            used = np.rint(np.arctanh(np.clip(a0, -0.9999, 0.9999)) / 0.08 - 1).astype(int)
+            assert np.allclose(a0, np.tanh(0.08 * (used + 1)), atol=1e-6)
+            np.testing.assert_array_equal(used, holds, err_msg="step %d" % s)
+            seen.update(used.tolist())
+        ended = ro.env.ended.cpu().numpy().astype(bool)
+        if learning:
+            holds[ended] = newest
+        if s % 5 != 4:
+            newest += 1
+            ps.push(keys, _coded_weights(keys, vals, newest))
+    assert len(seen) >= 10 and not ro.actor.version_state(with_slots=False)[1]["out_of_slots"]
