@@ -589,3 +589,55 @@ def test_nstep_rollout_weight_adoption_equals_the_reference_workers():
             newest += 1
             ps.push(keys, _coded_weights(keys, vals, newest))
     assert len(seen) >= 10 and not ro.actor.version_state(with_slots=False)[1]["out_of_slots"]
+
+
+def test_new_entry_points_refuse_what_they_cannot_do():
+    """Error behaviour of the round-4 entry points (every function returns a status, nothing aborts): the version store twice / out of
+    range / on a policy outside the direct-operand envelope, versioned get_action without a store, the fused rollout step on a compact
+    ring, ddrl_dqn_step_ring on narrow observations."""
+    import ctypes
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd import _lib, dqn
+    from distributed_drl_amd.agent import Actor, HyperParameters
+    from distributed_drl_amd.env import VecLunarLander
+    lib = _lib.load()
+    opt = HyperParameters()
+    a = Actor(opt, max_rows=64)
+    assert lib.ddrl_actor_act_versioned(a._h, None, None, 64, 1, 10, None, None) == _lib.DDRL_ERR_BAD_ARG            # NULL pointers
+    obs = torch.zeros(64, 8, device="cuda")
+    act = torch.zeros(64, 2, device="cuda")
+    assert lib.ddrl_actor_act_versioned(a._h, _lib.dptr(obs), None, 64, 1, 10, _lib.dptr(act), None) == _lib.DDRL_ERR_BAD_ARG   # no store yet
+    assert lib.ddrl_actor_versions_enable(a._h, 1, None) == _lib.DDRL_ERR_BAD_ARG and lib.ddrl_actor_versions_enable(a._h, 5000, None) == _lib.DDRL_ERR_BAD_ARG
+    a.enable_versions(4)
+    assert lib.ddrl_actor_versions_enable(a._h, 4, None) == _lib.DDRL_ERR_BAD_ARG                                        # already enabled
+    assert b"already enabled" in lib.ddrl_last_error()
+    assert lib.ddrl_actor_act_versioned(a._h, _lib.dptr(obs), None, 32, 1, 10, _lib.dptr(act), None) == _lib.DDRL_ERR_BAD_ARG   # not all envs
+    a.get_actions_versioned(obs, 10, deterministic=True, out=act)
+    opt2 = HyperParameters()
+    opt2.hidden_sizes = (50, 34)                                                                                         # hidden % 4 != 0: generic kernels only
+    with pytest.raises(ValueError, match="direct-operand"):
+        Actor(opt2, max_rows=64).enable_versions(4)
+    # a store that runs out of slots says so (two slots, three versions in use) instead of corrupting a version some env acts on silently
+    b = Actor(opt, max_rows=64)
+    b.enable_versions(2)
+    keys, vals = b.get_weights()
+    ended = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    b.set_weights(keys, vals)                      # version 1 (slot 1); nobody on it yet
+    ended[:10] = 1
+    b.adopt_where_ended(ended)                     # ten envs move to slot 1: both slots in use
+    b.set_weights(keys, vals)                      # a third version: no free slot
+    assert b.version_state(with_slots=False)[1]["out_of_slots"]
+    # the fused rollout step stores float32 rows: a compact ring is refused
+    env = VecLunarLander(64, seed=0)
+    cring = ddrl.ReplayBuffer(8, 2, 256, compact_obs=True)
+    assert lib.ddrl_rollout_begin(env._h, a._h, None) == 0
+    assert lib.ddrl_rollout_step(env._h, a._h, cring._h, 1, 0, 0, 1, None, None, None) == _lib.DDRL_ERR_BAD_ARG
+    assert b"float32 rings only" in lib.ddrl_last_error()
+
+    class O:
+        obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed, buffer_size, save_dir = 12, 3, [16, 8], 0.99, 1e-3, 0.995, 8, 0, 64, "."
+    ln = dqn.Learner(O, "learner")
+    ring = ddrl.ReplayBufferDQN(O, 0, seed=1)
+    assert lib.ddrl_dqn_step_ring(ln._h, ring._h, None, None, None, None) == _lib.DDRL_ERR_UNSUPPORTED
+    with pytest.raises(ValueError, match="high <= 0"):
+        ln.train_from(ring)                        # the fallback's sample_batch on an empty ring: the reference's ValueError
