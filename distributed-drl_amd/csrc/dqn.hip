@@ -43,6 +43,43 @@ struct HeadArgs {
     float gamma, alpha;
 };
 static size_t head_lds_bytes(const HeadArgs &a) { return ((size_t)a.nev * HEAD_ROWS * a.ldh2 + (size_t)a.nev * a.ldw) * sizeof(float); }
+// the Q phase of k_dqn_head for four actions and NEV evaluations (Double-DQN: 3, SQN: 5): one wave = one batch row, the lanes
+// split k; every evaluation's loads are issued together and every sum goes through the butterfly together (a cross-lane exchange
+// is an LDS round trip: one chain per (evaluation, action) after the other was 5.3 us of the kernel)
+template <int NEV>
+__device__ __forceinline__ void head_q4(const HeadArgs &a, const float *sH, const float *sW, float *sQ, int lr, int row, int lane, int K, long long BQ) {
+    float acc[NEV][4];
+#pragma unroll
+    for (int ev = 0; ev < NEV; ++ev) acc[ev][0] = acc[ev][1] = acc[ev][2] = acc[ev][3] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float xv[NEV];
+        float4 wv[NEV];
+#pragma unroll
+        for (int ev = 0; ev < NEV; ++ev) {
+            xv[ev] = sH[((size_t)ev * HEAD_ROWS + lr) * a.ldh2 + k];
+            wv[ev] = *reinterpret_cast<const float4 *>(sW + (size_t)ev * a.ldw + 4 * k);
+        }
+#pragma unroll
+        for (int ev = 0; ev < NEV; ++ev) {
+            acc[ev][0] = fmaf(xv[ev], wv[ev].x, acc[ev][0]); acc[ev][1] = fmaf(xv[ev], wv[ev].y, acc[ev][1]);
+            acc[ev][2] = fmaf(xv[ev], wv[ev].z, acc[ev][2]); acc[ev][3] = fmaf(xv[ev], wv[ev].w, acc[ev][3]);
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+        for (int ev = 0; ev < NEV; ++ev)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[ev][c] += __shfl_xor(acc[ev][c], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int ev = 0; ev < NEV; ++ev) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sQ[(ev * HEAD_ROWS + lr) * HEAD_MAXA + c] = acc[ev][c];
+            if (row < a.B) *reinterpret_cast<float4 *>(a.Q + ev * BQ + (long long)row * a.ldq) = make_float4(acc[ev][0], acc[ev][1], acc[ev][2], acc[ev][3]);
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
     // the workgroup's H2 rows and every evaluation's [W3 ; b3] are staged into LDS with ALL loads in flight at once (the first cut
     // read them inside the dot-product loops: 30 dependent round trips per wave, 30 us for 3.7 MFLOP)
@@ -56,6 +93,9 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
     const int r0 = blockIdx.x * HEAD_ROWS;
     const long long BH = (long long)a.B * a.ldh2, BQ = (long long)a.B * a.ldq;
     const int K = a.h2 + 1;
+    // the row scalars the "rows" phase needs, requested now (a cold round trip otherwise sits between two barriers)
+    float p_act = 0.f, p_rew = 0.f, p_done = 0.f;
+    if (tid < HEAD_ROWS && r0 + tid < a.B) { p_act = a.acts[r0 + tid]; p_rew = a.rew[r0 + tid]; p_done = a.done[r0 + tid]; }
     {
         // four loads per lane in flight per round (a plain load-store loop waits for every load before it issues the next one)
         const int l4 = a.ldh2 >> 2, n4 = a.nev * HEAD_ROWS * l4;
@@ -95,35 +135,33 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
     // ---- Q: wave w takes row w; the lanes split k, fixed-order butterfly
     {
         const int lr = w, row = r0 + lr;
-        for (int ev = 0; ev < a.nev; ++ev) {
-            float acc[HEAD_MAXA];
+        if (a.A == 4 && a.nev == 3) head_q4<3>(a, sH, sW, &sQ[0][0][0], lr, row, lane, K, BQ);
+        else if (a.A == 4 && a.nev == 5) head_q4<5>(a, sH, sW, &sQ[0][0][0], lr, row, lane, K, BQ);
+        else {
+            for (int ev = 0; ev < a.nev; ++ev) {
+                float acc[HEAD_MAXA];
 #pragma unroll
-            for (int c = 0; c < HEAD_MAXA; ++c) acc[c] = 0.f;
-            const float *x = sH + ((size_t)ev * HEAD_ROWS + lr) * a.ldh2;
-            const float *wk = sW + (size_t)ev * a.ldw;
-            if (a.A == 4) {
-                for (int k = lane; k < K; k += 64) {
-                    const float xv = x[k];
-                    const float4 wv = *reinterpret_cast<const float4 *>(wk + 4 * k);
-                    acc[0] = fmaf(xv, wv.x, acc[0]); acc[1] = fmaf(xv, wv.y, acc[1]); acc[2] = fmaf(xv, wv.z, acc[2]); acc[3] = fmaf(xv, wv.w, acc[3]);
-                }
-            } else {
+                for (int c = 0; c < HEAD_MAXA; ++c) acc[c] = 0.f;
+                const float *x = sH + ((size_t)ev * HEAD_ROWS + lr) * a.ldh2;
+                const float *wk = sW + (size_t)ev * a.ldw;
                 for (int k = lane; k < K; k += 64) {
                     const float xv = x[k];
 #pragma unroll
                     for (int c = 0; c < HEAD_MAXA; ++c)
                         if (c < a.A) acc[c] = fmaf(xv, wk[k * a.A + c], acc[c]);
                 }
-            }
+                for (int o = 32; o >= 1; o >>= 1) {
 #pragma unroll
-            for (int c = 0; c < HEAD_MAXA; ++c) {
-                if (c < a.A) {
-                    float v = acc[c];
-                    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                    if (lane == 0) {
-                        sQ[ev][lr][c] = v;
-                        if (row < a.B) a.Q[ev * BQ + (long long)row * a.ldq + c] = v;
-                    }
+                    for (int c = 0; c < HEAD_MAXA; ++c)
+                        if (c < a.A) acc[c] += __shfl_xor(acc[c], o);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < HEAD_MAXA; ++c)
+                        if (c < a.A) {
+                            sQ[ev][lr][c] = acc[c];
+                            if (row < a.B) a.Q[ev * BQ + (long long)row * a.ldq + c] = acc[c];
+                        }
                 }
             }
         }
@@ -134,7 +172,7 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
         const int row = r0 + tid;
         float l = 0.f;
         if (row < a.B) {
-            const int act = (int)a.acts[row];                       // tf.cast(a_ph, tf.int32)
+            const int act = (int)p_act;                             // tf.cast(a_ph, tf.int32)
             const bool valid = act >= 0 && act < a.A;               // one_hot of an out-of-range index is all zeros
             if (!a.sqn) {
                 const float *q = sQ[0][tid], *qx2 = sQ[1][tid], *qn = sQ[2][tid];
@@ -142,7 +180,7 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
                 float bv = qx2[0];
                 for (int c = 1; c < a.A; ++c) { const float v = qx2[c]; if (v > bv) { bv = v; best = c; } }  // tf.argmax: first maximum
                 const float q_value = valid ? q[act] : 0.f;
-                const float backup = a.rew[row] + (a.gamma * (1.0f - a.done[row])) * qn[best];
+                const float backup = p_rew + (a.gamma * (1.0f - p_done)) * qn[best];
                 const float e = backup - q_value;
                 l = e * e;
                 const float g = -e / (float)a.B;
@@ -168,7 +206,7 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
                 float m1 = q1t[0], m2 = q2t[0];   // q_mu_ = q_[argmax q_] = max q_ (each target network's own greedy value)
                 for (int c = 1; c < a.A; ++c) { m1 = fmaxf(m1, q1t[c]); m2 = fmaxf(m2, q2t[c]); }
                 const float v_backup = fminf(m1, m2) - a.alpha * plogp;                 // actor_learner.py:47-50
-                const float q_backup = a.rew[row] + (a.gamma * (1.0f - a.done[row])) * v_backup;
+                const float q_backup = p_rew + (a.gamma * (1.0f - p_done)) * v_backup;
                 const float e1 = q_backup - (valid ? q1[act] : 0.f), e2 = q_backup - (valid ? q2[act] : 0.f);
                 l = e1 * e1 + e2 * e2;
                 const float g1 = -e1 / (float)a.B, g2 = -e2 / (float)a.B;
@@ -184,15 +222,17 @@ __global__ void __launch_bounds__(256) k_dqn_head(HeadArgs a) {
     }
     __syncthreads();
     // ---- dZ2
-    for (int idx = tid; idx < a.nnet * HEAD_ROWS * a.h2; idx += 256) {
-        const int n = idx / (HEAD_ROWS * a.h2), rem = idx - n * (HEAD_ROWS * a.h2), lr = rem / a.h2, j = rem - lr * a.h2;
-        const int row = r0 + lr;
-        if (row < a.B) {
-            const float *wj = sW + (size_t)a.nev_of_net[n] * a.ldw + j * a.A;
+    for (int nr = 0; nr < a.nnet * HEAD_ROWS; ++nr) {
+        const int n = nr / HEAD_ROWS, lr = nr % HEAD_ROWS, row = r0 + lr;
+        if (row >= a.B) continue;
+        const float *wn = sW + (size_t)a.nev_of_net[n] * a.ldw;
+        const float *hrow = sH + ((size_t)a.gev[n] * HEAD_ROWS + lr) * a.ldh2;
+        float *out = a.dZ2 + ((long long)n * a.B + row) * a.h2;
+        for (int j = tid; j < a.h2; j += 256) {
+            const float *wj = wn + j * a.A;
             float v = 0.f;
             for (int c = 0; c < a.A; ++c) v = fmaf(sdQ[n][lr][c], wj[c], v);
-            const float hmask = sH[((size_t)a.gev[n] * HEAD_ROWS + lr) * a.ldh2 + j];
-            a.dZ2[((long long)n * a.B + row) * a.h2 + j] = hmask > 0.f ? v : 0.f;
+            out[j] = hrow[j] > 0.f ? v : 0.f;
         }
     }
     if (a.zero_words)
