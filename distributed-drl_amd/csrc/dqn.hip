@@ -604,13 +604,12 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
         h->ad.adam_blocks = (int)blocks;
         h->ad.opt = h->opt + h->opt_cur; h->ad.opt_next = h->opt + (h->opt_cur ^ 1);
         h->opt_cur ^= 1;
-        h->ad.loss_part = h->hpart; h->ad.loss_out = h->loss; h->ad.loss_n = (B + HEAD_ROWS - 1) / HEAD_ROWS; h->ad.loss_scale = 0.5f / (float)B;
+        h->ad.loss_part = h->hpart; h->ad.loss_out = h->loss; h->ad.loss_out2 = loss_d; h->ad.loss_n = (B + HEAD_ROWS - 1) / HEAD_ROWS; h->ad.loss_scale = 0.5f / (float)B;
         k_adam_polyak<<<(unsigned)blocks + 1, 256, 0, s>>>(h->ad);   // + one workgroup: the loss mean from k_dqn_head's partials
     }
     STAGE_MARK();   // 8 flat Adam + polyak
 #undef STAGE_MARK
     DDRL_LAUNCH_CHECK();
-    if (loss_d) DDRL_HIP_CHECK(hipMemcpyAsync(loss_d, h->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (q_d) DDRL_HIP_CHECK(hipMemcpy2DAsync(q_d, (size_t)h->cfg.n_actions * sizeof(float), h->Q, (size_t)h->ldq * sizeof(float),
                                              (size_t)h->cfg.n_actions * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, s));
     return DDRL_OK;

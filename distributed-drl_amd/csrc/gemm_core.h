@@ -675,6 +675,7 @@ struct AdamArgs {
     // earlier launch left (k_dqn_head): loss_out[0] = loss_scale * sum_b loss_part[b], b in order
     const float *loss_part;
     float *loss_out;
+    float *loss_out2;        // optional second destination (the caller's buffer: a copy launch per update otherwise)
     int loss_n;
     float loss_scale;
 };
@@ -691,7 +692,10 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) a.loss_out[0] = a.loss_scale * tot;
+        if (threadIdx.x == 0) {
+            a.loss_out[0] = a.loss_scale * tot;
+            if (a.loss_out2) a.loss_out2[0] = a.loss_scale * tot;
+        }
         return;
     }
     if (a.do_sample && (int)blockIdx.x == a.adam_blocks) {

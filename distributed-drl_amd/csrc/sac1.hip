@@ -1923,14 +1923,40 @@ __global__ void __launch_bounds__(256) k_version_copy(const float *__restrict__ 
 
 // One workgroup: envs grouped by slot (counting sort; the order inside a group is immaterial — rows are computed
 // independently), one VerTile per 32 envs of a group.
+// arr[s] += 1 for every valid lane, the lane's position in its group returned.  A few thousand envs sit on a handful of versions most
+// of the time: 64 lanes on ONE LDS address are 64 serialised atomics, so the lanes that share the slot of the first pending lane go
+// as one atomic (four such rounds: the four largest groups of the wave, typically all of it); what is left takes its own.
+__device__ __forceinline__ int ver_group_add(int *arr, int s, bool valid, int lane) {
+    unsigned long long todo = __ballot(valid);
+    int pos = 0;
+    for (int round = 0; round < 4 && todo; ++round) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int s0 = __shfl(s, leader);
+        const bool mine = valid && s == s0;
+        const unsigned long long m = __ballot(mine);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&arr[s0], __popcll(m));
+        base = __shfl(base, leader);
+        if (mine) { pos = base + __popcll(m & ((1ull << lane) - 1ull)); valid = false; }
+        todo &= ~m;
+    }
+    if (valid) pos = atomicAdd(&arr[s], 1);
+    return pos;
+}
 __global__ void __launch_bounds__(1024) k_version_group(const int *__restrict__ slot, long long n, int n_slots, int *__restrict__ perm,
                                                         VerTile *__restrict__ tiles, VerState *vs) {
-    __shared__ int cnt[VER_MAX_SLOTS], start[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
-    __shared__ int wsum_c[16], wsum_t[16];
+    __shared__ int cnt[VER_MAX_SLOTS], cur[VER_MAX_SLOTS], start[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
+    __shared__ int wsum_c[16], wsum_t[16], s_nt;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    for (int j = t; j < VER_MAX_SLOTS; j += 1024) cnt[j] = 0;
+    // the first four envs of every thread stay in registers for both passes (n <= 4096: all of them), requested before anything else
+    int sv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sv[e] = t + 1024 * e < n ? slot[t + 1024 * e] : 0;
+    for (int j = t; j < VER_MAX_SLOTS; j += 1024) { cnt[j] = 0; cur[j] = 0; }
     __syncthreads();
-    for (long long i = t; i < n; i += 1024) atomicAdd(&cnt[slot[i]], 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ver_group_add(cnt, sv[e], t + 1024 * e < n, lane);
+    for (long long i0 = 4096; i0 < n; i0 += 1024) ver_group_add(cnt, i0 + t < n ? slot[i0 + t] : 0, i0 + t < n, lane);
     __syncthreads();
     // exclusive scans of the group sizes and of the groups' tile counts: two slots per thread, wave scan, wave totals
     const int c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
@@ -1947,18 +1973,29 @@ __global__ void __launch_bounds__(1024) k_version_group(const int *__restrict__ 
     const int ec = bc + sc - (c0 + c1), et = bt + st - (t0 + t1);   // exclusive prefix of this thread's pair
     start[2 * t] = ec; start[2 * t + 1] = ec + c0;
     tstart[2 * t] = et; tstart[2 * t + 1] = et + t0;
-    if (t == 1023) vs->n_tiles = bt + st;
+    if (t == 1023) { vs->n_tiles = bt + st; s_nt = bt + st; }
     __syncthreads();
-    for (int j = t; j < n_slots; j += 1024) {
-        const int c = cnt[j];
-        for (int k = 0; k < ((c + 31) >> 5); ++k) tiles[tstart[j] + k] = VerTile{j, start[j] + 32 * k, c - 32 * k < 32 ? c - 32 * k : 32, 0};
+    // tile ti belongs to the LAST slot whose first tile is <= ti (the empty slots behind it start where it ends)
+    for (int ti = t; ti < s_nt; ti += 1024) {
+        int lo = 0, hi = VER_MAX_SLOTS;            // first index with tstart > ti
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tstart[mid] > ti) hi = mid; else lo = mid + 1;
+        }
+        const int j = lo - 1, k = ti - tstart[j], c = cnt[j];
+        tiles[ti] = VerTile{j, start[j] + 32 * k, c - 32 * k < 32 ? c - 32 * k : 32, 0};
     }
-    __syncthreads();
-    for (int j = t; j < VER_MAX_SLOTS; j += 1024) cnt[j] = 0;   // reused as the groups' fill cursors
-    __syncthreads();
-    for (long long i = t; i < n; i += 1024) {
-        const int s = slot[i];
-        perm[start[s] + atomicAdd(&cnt[s], 1)] = (int)i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = t + 1024 * e < n;
+        const int p = ver_group_add(cur, sv[e], ok, lane);
+        if (ok) perm[start[sv[e]] + p] = t + 1024 * e;
+    }
+    for (long long i0 = 4096; i0 < n; i0 += 1024) {
+        const bool ok = i0 + t < n;
+        const int s = ok ? slot[i0 + t] : 0;
+        const int p = ver_group_add(cur, s, ok, lane);
+        if (ok) perm[start[s] + p] = (int)(i0 + t);
     }
 }
 
