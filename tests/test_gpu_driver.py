@@ -437,19 +437,26 @@ def test_vectorised_rollout_never_acts_on_weights_older_than_the_reference_worke
 
 
 def _coded_weights(keys, vals, v):
-    """Policy version v as a recognisable action: zero kernels, mu bias 0.08 (v + 1), log_std at its floor."""
+    """Policy version v as a recognisable action: zero kernels, mu biases 0.08 (v % 40 + 1) and 0.08 (v // 40 + 1) (two action
+    dims = two base-40 digits: tanh keeps 40 levels apart by > 5e-4), log_std at its floor."""
     out = []
     for k, w in zip(keys, vals):
         w = np.zeros_like(w)
         if "pi" in k and k.endswith("dense_2/bias"):
-            w[:] = 0.08 * (v + 1)
+            w[0], w[1:] = 0.08 * (v % 40 + 1), 0.08 * (v // 40 + 1)
         if "pi" in k and k.endswith("dense_3/bias"):
             w[:] = -40.0
         out.append(w)
     return out
 
 
-@pytest.mark.parametrize("n,limit,steps", [(64, 7, 60), (160, 23, 90)])
+def _decode_version(acts):
+    d = [np.rint(np.arctanh(np.clip(acts[:, c], -0.9999, 0.9999)) / 0.08 - 1).astype(int) for c in (0, 1)]
+    assert np.allclose(acts[:, 0], np.tanh(0.08 * (d[0] + 1)), atol=1e-6) and np.allclose(acts[:, 1], np.tanh(0.08 * (d[1] + 1)), atol=1e-6)
+    return d[0] + 40 * d[1]
+
+
+@pytest.mark.parametrize("n,limit,steps", [(64, 7, 60), (160, 23, 90), (4096, 70, 170), (1024, 300, 330)])
 def test_vectorised_rollout_equals_n_reference_workers_in_the_weights_each_env_acts_on(n, limit, steps):
     """Bar (1) for the vectorised rollout: the reference runs one worker per env and each pulls the server's weights at ITS OWN
     episode end (example/dsac.py:127-130: o = env.reset(); weights = ps.pull(keys); agent.set_weights(keys, weights)) and acts on
@@ -484,9 +491,7 @@ def test_vectorised_rollout_equals_n_reference_workers_in_the_weights_each_env_a
     for s in range(steps):
         roll.step()
         acts = rb.rings()["acts_buf"][s * n:(s + 1) * n].cpu().numpy()
-        used = np.rint(np.arctanh(np.clip(acts[:, 0], -0.9999, 0.9999)) / 0.08 - 1).astype(int)
-        assert np.allclose(acts[:, 0], np.tanh(0.08 * (used + 1)), atol=1e-6)
-        np.testing.assert_array_equal(used, holds, err_msg="step %d" % s)
+        np.testing.assert_array_equal(_decode_version(acts), holds, err_msg="step %d" % s)
         epi_after = roll.env.get_state()[EPI].cpu().numpy()
         holds[epi_after > epi_before] = newest               # episode ended in step s: reset, pull what the server holds
         epi_before = epi_after.copy()
@@ -577,9 +582,7 @@ def test_nstep_rollout_weight_adoption_equals_the_reference_workers():
         ro.step()
         learning = learning or rb.get_counts()[1] > opt.start_steps       # what the worker reads at its episode end, after its store (:255)
         if policy_phase:
-            a0 = ro.act[:, 0].cpu().numpy()
-            used = np.rint(np.arctanh(np.clip(a0, -0.9999, 0.9999)) / 0.08 - 1).astype(int)
-            assert np.allclose(a0, np.tanh(0.08 * (used + 1)), atol=1e-6)
+            used = _decode_version(ro.act.cpu().numpy())
             np.testing.assert_array_equal(used, holds, err_msg="step %d" % s)
             seen.update(used.tolist())
         ended = ro.env.ended.cpu().numpy().astype(bool)
