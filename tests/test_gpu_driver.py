@@ -504,14 +504,15 @@ def test_vectorised_rollout_equals_n_reference_workers_in_the_weights_each_env_a
     assert roll.env.stats()[0] >= n * (steps // limit - 1)
 
 
-def test_versioned_rollout_actions_match_each_versions_own_policy():
+@pytest.mark.parametrize("n,limit,steps", [(96, 9, 30), (1024, 37, 64)])
+def test_versioned_rollout_actions_match_each_versions_own_policy(n, limit, steps):
     """The same with real (random) policies: every env's stored action equals Actor.get_action of THAT env's version on the
-    observation it acted on, with the fused step's own noise element — within float32 of the row-major policy kernels."""
+    observation it acted on, with the fused step's own noise element — within float32 of the row-major policy kernels.  (The second
+    case: 32 row tiles' worth of envs spread over up to 33 live versions — mostly partial row tiles.)"""
     import distributed_drl_amd as ddrl
     from distributed_drl_amd import _lib
     from distributed_drl_amd.agent import Actor, HyperParameters, Learner
     from distributed_drl_amd.workers import RolloutDevice
-    n, limit, steps = 96, 9, 30
     opt = HyperParameters()
     opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, limit, 11
     keys, vals = Learner(opt).get_weights()
