@@ -542,3 +542,58 @@ def test_config5_ring_at_its_stated_capacity_of_4m_transitions(ddrl):
     np.testing.assert_array_equal(gg["rews"][:4].cpu().numpy(), r[[399, 0, 400, 599]])
     del buf
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_interleaving_of_stores_and_samples(ddrl, tmp_path, seed):
+    """Seeded fuzz of the ring's whole surface: a random walk of store_batch (1 row .. several capacities, so every wrap position and
+    cursor alignment occurs), single-row store, sample_batch of random sizes (1 .. 700: both gather paths, the index kernel across MT19937
+    state refills) and get_counts, on the SAC shape and on the DQN shape as float32 and compact rings at once — after every operation
+    the sampled indices, the gathered batches, the counters and (every tenth operation) the whole ring equal the oracle's.
+    DDRL_FUZZ_N scales the walk, DDRL_FUZZ_SEED moves it."""
+    import os
+    from oracle.replay_oracle import ReplayBufferOracle
+    seed += 1000 * int(os.environ.get("DDRL_FUZZ_SEED", "0"))
+    rs = np.random.RandomState(seed)
+    n_ops = 40 * max(1, int(os.environ.get("DDRL_FUZZ_N", "6")) // 6)
+    cap = int(rs.choice([5, 64, 1000, 3001]))
+    obs_dim = int(rs.choice([8, 11, 48]))
+    sac, sac_o = ddrl.ReplayBufferSAC1(obs_dim, 2, cap, seed=seed), ReplayBufferOracle(obs_dim, 2, cap, seed=seed)
+    pix = [ddrl.ReplayBufferDQN(_PixOpt(cap, obs_dim, 32, str(tmp_path / k)), 0, seed=seed, compact_obs=(k == "u")) for k in ("f", "u")]
+    pix_o = ReplayBufferOracle(obs_dim, 1, cap, acts_1d=True, seed=seed)
+    dev = lambda xs: tuple(torch.from_numpy(x).cuda() for x in xs)
+    for op in range(n_ops):
+        kind = rs.rand()
+        if kind < 0.45 or sac_o.size == 0:
+            n = int(rs.choice([1, 1, 3, cap - 1 if cap > 1 else 1, cap, cap + 1, 2 * cap + 3, int(rs.randint(1, 2 * cap + 2))]))
+            o, o2 = rs.randn(n, obs_dim).astype(np.float32), rs.randn(n, obs_dim).astype(np.float32)
+            a, r, d = rs.uniform(-1, 1, (n, 2)).astype(np.float32), rs.randn(n).astype(np.float32), (rs.rand(n) < 0.1).astype(np.float32)
+            if n == 1 and rs.rand() < 0.5:
+                sac.store(o[0], a[0], r[0], o2[0], d[0])                   # the reference's own call shape (host values)
+            else:
+                sac.store_batch(*dev((o, a, r, o2, d)))
+            sac_o.store_batch(o, a, r, o2, d)
+            tr = _pixel_transitions(rs, n, obs_dim)
+            for b in pix:
+                b.store_batch(*dev(tr))
+            pix_o.store_batch(*tr)
+        else:
+            B = int(rs.choice([1, 32, 256, 257, int(rs.randint(1, 701))]))
+            got, want = sac.sample_batch_device(B, with_indices=True), sac_o.sample_batch(B)
+            np.testing.assert_array_equal(got["idxs"].cpu().numpy(), sac_o.last_idxs, err_msg="op %d" % op)
+            for k in want:
+                np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg="op %d %s" % (op, k))
+            want = pix_o.sample_batch(B)
+            for b in pix:
+                got = b.sample_batch_device(B, with_indices=True)
+                np.testing.assert_array_equal(got["idxs"].cpu().numpy(), pix_o.last_idxs, err_msg="op %d" % op)
+                for k in want:
+                    np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg="op %d %s" % (op, k))
+        assert sac.get_counts() == sac_o.get_counts() and sac.ptr == sac_o.ptr
+        assert pix[0].get_counts() == pix[1].get_counts() == pix_o.get_counts()
+        if op % 10 == 9 or op == n_ops - 1:
+            for k, t in sac.rings().items():
+                np.testing.assert_array_equal(t.cpu().numpy(), getattr(sac_o, k), err_msg="op %d %s" % (op, k))
+            for b in pix:
+                for k, t in b.rings().items():
+                    np.testing.assert_array_equal(t.cpu().numpy(), getattr(pix_o, k), err_msg="op %d %s" % (op, k))
