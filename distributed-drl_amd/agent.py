@@ -224,8 +224,11 @@ class Learner(_Net):
 
     def _args(self, batch, eps, outs):
         B, a = self.cfg.batch, self.cfg.act_dim
-        x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))
-        ac, r, d = self._dev(batch["acts"], (B, a)), self._dev(batch["rews"], (B,)), self._dev(batch["done"], (B,))
+        if all(isinstance(batch[k], np.ndarray) for k in ("obs1", "obs2", "acts", "rews", "done")):
+            x, x2, ac, r, d = self._host_batch(batch)
+        else:
+            x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))
+            ac, r, d = self._dev(batch["acts"], (B, a)), self._dev(batch["rews"], (B,)), self._dev(batch["done"], (B,))
         if eps is None:
             e = self._normal(3 * B * a).view(3, B, a)
             eps = (e[0], e[1], e[2])
@@ -236,6 +239,24 @@ class Learner(_Net):
             q1, q2, lp = (torch.empty(B, dtype=torch.float32, device=self.device) for _ in range(3))
         ptrs = [_lib.dptr(t) for t in keep] + [_lib.dptr(self.losses), _lib.dptr(q1), _lib.dptr(q2), _lib.dptr(lp)]
         return keep, ptrs, (q1, q2, lp)
+
+    def _host_batch(self, batch):
+        """The reference's feed (five NumPy arrays) crosses PCIe as ONE block out of a page-locked staging buffer (the copy is
+        synchronous: the buffer is free again on return; the device block is reused stream-ordered behind the previous update)."""
+        B, o, a = self.cfg.batch, self.cfg.obs_dim, self.cfg.act_dim
+        st = getattr(self, "_stage_b", None)
+        if st is None:
+            offs = [0]
+            for n in (B * o, B * o, B * a, B, B):
+                offs.append((offs[-1] + n + 3) & ~3)
+            host = torch.empty(offs[5], dtype=torch.float32).pin_memory()
+            st = self._stage_b = (host, host.numpy(), torch.empty(offs[5], dtype=torch.float32, device=self.device), offs)
+        host, hv, dev, offs = st
+        for j, (k, n) in enumerate((("obs1", B * o), ("obs2", B * o), ("acts", B * a), ("rews", B), ("done", B))):
+            hv[offs[j]:offs[j] + n] = np.asarray(batch[k], dtype=np.float32).reshape(n)
+        dev.copy_(host)
+        return (dev[offs[0]:offs[0] + B * o].view(B, o), dev[offs[1]:offs[1] + B * o].view(B, o), dev[offs[2]:offs[2] + B * a].view(B, a),
+                dev[offs[3]:offs[3] + B], dev[offs[4]:offs[4] + B])
 
     def train(self, batch, eps=None, return_outputs=False):
         """One sess.run(step_ops) (actor_learner.py:135-142).  `batch` holds obs1/obs2/acts/rews/done

@@ -55,12 +55,23 @@ class ReplayBuffer:
     def store(self, obs, act, rew, next_obs, done, worker_index=None):
         """One transition (example/dsac.py:29-37).  Values are cast to float32 exactly as the
         NumPy row assignment does (float64 -> f32 round-to-nearest, bool -> 0.0/1.0)."""
-        o = torch.from_numpy(np.asarray(obs, dtype=np.float32).reshape(1, self.obs_dim))
-        o2 = torch.from_numpy(np.asarray(next_obs, dtype=np.float32).reshape(1, self.obs_dim))
-        a = torch.from_numpy(np.asarray(act, dtype=np.float32).reshape(1, self.act_dim))
-        r = torch.from_numpy(np.asarray(rew, dtype=np.float32).reshape(1))
-        d = torch.from_numpy(np.asarray(done, dtype=np.float32).reshape(1))
-        self.store_batch(*(t.to(self.device) for t in (o, a, r, o2, d)))
+        # the five values cross PCIe as ONE block out of a page-locked staging row (five pageable copies were 5 x ~18 us of the
+        # call); the copy is synchronous, so the row is free again when store() returns
+        st = getattr(self, "_stage1", None)
+        if st is None:
+            w = 2 * self.obs_dim + self.act_dim + 2
+            host = torch.empty(w, dtype=torch.float32).pin_memory()
+            st = self._stage1 = (host, host.numpy(), torch.empty(w, dtype=torch.float32, device=self.device))
+        host, hv, dev = st
+        o, a = self.obs_dim, self.act_dim
+        hv[0:o] = np.asarray(obs, dtype=np.float32).reshape(o)
+        hv[o:o + a] = np.asarray(act, dtype=np.float32).reshape(a)
+        hv[o + a] = np.asarray(rew, dtype=np.float32).reshape(())
+        hv[o + a + 1:2 * o + a + 1] = np.asarray(next_obs, dtype=np.float32).reshape(o)
+        hv[2 * o + a + 1] = np.asarray(done, dtype=np.float32).reshape(())
+        dev.copy_(host)
+        self.store_batch(dev[0:o].view(1, o), dev[o:o + a].view(1, a), dev[o + a:o + a + 1], dev[o + a + 1:2 * o + a + 1].view(1, o),
+                         dev[2 * o + a + 1:2 * o + a + 2])
 
     def store_batch(self, obs, act, rew, next_obs, done):
         """n sequential store() calls in row order (device tensors, float32)."""
@@ -74,8 +85,23 @@ class ReplayBuffer:
     def sample_batch(self, batch_size=None):
         """dict(obs1, obs2, acts, rews, done) of fresh float32 NumPy arrays (example/dsac.py:39-45).
         Raises ValueError("high <= 0") on an empty buffer like the reference."""
-        d = self.sample_batch_device(batch_size, fresh=True)
-        return {k: v.cpu().numpy() for k, v in d.items()}
+        # gathered into ONE packed device block and brought down with one copy (five device-to-host copies were most of the call);
+        # the five arrays are disjoint pieces of that fresh host block
+        B = int(self._default_batch if batch_size is None else batch_size)
+        o, a = self.obs_dim, self.act_dim
+        if B * o >= (1 << 22):    # rows of megabytes (config 5): the gather's own aligned per-array buffers
+            d = self.sample_batch_device(B, fresh=True)
+            return {k: v.cpu().numpy() for k, v in d.items()}
+        offs = [0]
+        for n in (B * o, B * o, B * a, B, B):
+            offs.append((offs[-1] + n + 3) & ~3)               # every piece 16-byte aligned
+        flat = torch.empty(offs[5], dtype=torch.float32, device=self.device)
+        p = [flat.data_ptr() + 4 * offs[j] for j in range(5)]
+        _lib.check(self._lib.ddrl_replay_sample(self._h, B, p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
+        h = flat.cpu().numpy()
+        return dict(obs1=h[offs[0]:offs[0] + B * o].reshape(B, o), obs2=h[offs[1]:offs[1] + B * o].reshape(B, o),
+                    acts=h[offs[2]:offs[2] + B * a] if self._acts_1d else h[offs[2]:offs[2] + B * a].reshape(B, a),
+                    rews=h[offs[3]:offs[3] + B], done=h[offs[4]:offs[4] + B])
 
     def sample_batch_device(self, batch_size=None, fresh=False, with_indices=False):
         B = int(self._default_batch if batch_size is None else batch_size)
