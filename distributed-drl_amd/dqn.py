@@ -160,6 +160,38 @@ class Actor(Learner):
             return int(np.argmax(self.q_values(np.asarray(o, np.float32)[np.newaxis, :])[0].cpu().numpy()))
         return int(self._rs.randint(0, self.opt.act_dim))
 
+    def _test_action(self, o):
+        return self.get_action(o)
+
+    def test(self, test_env, n=10):
+        """actor_learner.py:230-251: n episodes to their terminal with the actor's own get_action; (mean return, mean of
+        test_env.rewards[0] at each episode's end — the trading env's score)."""
+        test_rets, scores = [], []
+        for _ in range(n):
+            o, r, d, ep_ret, ep_len = test_env.reset(), 0, False, 0, 0
+            while True:
+                o, r, d, _ = test_env.step(self._test_action(o))
+                ep_ret += r
+                ep_len += 1
+                if d:
+                    test_rets.append(ep_ret)
+                    scores.append(test_env.rewards[0])
+                    break
+        return np.mean(test_rets), np.mean(scores)
+
+    def write_tb(self, ave_test_reward, ave_score, alratio, update_frequency, total_learner_step):
+        """actor_learner.py:203-228: the four test scalars ("Reward", "score", "a_l_ratio", "update_frequency") at step
+        total_learner_step, into the run directory the reference names for job == "test" (actor_learner.py:173-176)."""
+        if getattr(self, "_writer", None) is None:
+            import datetime
+            from .logx import SummaryWriter
+            o = self.opt
+            self._writer = SummaryWriter("%s/%s-%s-%s-workers_num:%s%%%s" % (getattr(o, "summary_dir", "."), datetime.datetime.now(), getattr(o, "env_name", ""),
+                                                                            getattr(o, "exp_name", ""), getattr(o, "num_workers", 1), getattr(o, "a_l_ratio", "")))
+        for tag, v in (("Reward", ave_test_reward), ("score", ave_score), ("a_l_ratio", alratio), ("update_frequency", update_frequency)):
+            self._writer.add_scalar(tag, float(v), int(total_learner_step))
+        self._writer.flush()
+
 
 class LearnerSQN(Learner):
     """algos/sqn/actor_learner.py:19-131 (twin soft-Q networks main/q1, main/q2; step_ops = [q_loss, q1, q2, ...]):
@@ -183,3 +215,8 @@ class ActorSQN(LearnerSQN):
         z = q / float(self.opt.alpha)
         p = np.exp(z - z.max())
         return int(self._rs.choice(len(p), p=p / p.sum()))
+
+    def _test_action(self, o):
+        return self.get_action(o, deterministic=True)     # algos/sqn/actor_learner.py:238
+
+    test, write_tb = Actor.test, Actor.write_tb

@@ -5,6 +5,7 @@ Mirrors:
   example/dsac.py:133-150   worker_train(ps, replay_buffer, args)
   example/dsac.py:153-177   worker_test(ps, start_time)            (here: explicit args)
   algos/sac1/sac1.py:133-154,157-213,216-252   the SAC1 flavours (opt, index; a_l_ratio throttle)
+  algos/dqn/train.py:177-371 (= algos/sqn/train.py)   the DQN / SQN driver: Cache, worker_train, worker_rollout, worker_test, get_al_status
 
 `ps` / `replay_buffer` are actor handles (`remote.py` shim or Ray): methods are invoked as
 `handle.method.remote(...)` and awaited with `get`.  Two execution styles share these semantics:
@@ -248,6 +249,204 @@ def worker_test_sac1(ps, replay_buffer, opt, make_env=None, make_agent=None, log
         if (max_rounds is not None and rounds >= max_rounds) or _stop(opt):
             return max_ret
         sleep(5)
+
+
+# ------------------------------------------------------------------------------------------
+# algos/dqn/train.py flavour (algos/sqn/train.py is the same driver around the soft-Q agent): node_buffer[node][buffer] handles,
+# a random buffer per store, the learner fed by a Cache helper.  The reference reads `opt` and `node_ps` as module globals; here
+# they are arguments.
+# ------------------------------------------------------------------------------------------
+def get_al_status(node_buffer, opt):
+    """algos/dqn/train.py:358-371: (actor_steps, learner_steps, cur_size) of every buffer of every node, as arrays."""
+    import numpy as np
+    learner, actor, size = [], [], []
+    for node_index in range(opt.num_nodes):
+        for i in range(opt.num_buffers):
+            learner_step, actor_step, cur_size = _get(_remote(node_buffer[node_index][i].get_counts))
+            learner.append(learner_step)
+            actor.append(actor_step)
+            size.append(cur_size)
+    return np.array(actor), np.array(learner), np.array(size)
+
+
+class BatchCache:
+    """algos/dqn/train.py:177-210 `Cache`: a helper that keeps up to ten sampled batches waiting in q1 (each from a random buffer of a
+    random node) and forwards the weights the learner leaves in q2 to EVERY node's parameter server.  The reference runs it as a
+    daemon process; device-backed handles cannot cross a process boundary, so this one is a daemon thread over the same two queues."""
+
+    def __init__(self, node_buffer, opt, node_ps, rng=None):
+        import queue
+        import threading
+        self.node_buffer, self.opt, self.node_ps = node_buffer, opt, node_ps
+        self.rng = rng
+        self.q1, self.q2 = queue.Queue(12), queue.Queue(5)
+        self._stop = threading.Event()
+        self.p1 = threading.Thread(target=self.ps_update, args=(self.q1, self.q2, self.node_buffer), daemon=True)
+
+    def _one_batch(self, q1, node_buffer):
+        import numpy as np
+        rng = self.rng if self.rng is not None else np.random
+        node_idx = rng.choice(self.opt.num_nodes, 1)[0]
+        buffer_idx = rng.choice(self.opt.num_buffers, 1)[0]
+        q1.put(_get(_remote(node_buffer[node_idx][buffer_idx].sample_batch)))   # (fresh arrays per call: the reference's deepcopy)
+
+    def ps_update(self, q1, q2, node_buffer):
+        self._one_batch(q1, node_buffer)
+        while not self._stop.is_set():
+            if q1.qsize() < 10:
+                self._one_batch(q1, node_buffer)
+            if not q2.empty():
+                self._forward(q2)
+        while not q2.empty():        # end(): the weights still waiting go out (the reference terminates its helper process: they are lost there)
+            self._forward(q2)
+
+    def _forward(self, q2):
+        keys, values = q2.get()
+        for i in range(self.opt.num_nodes):
+            _remote(self.node_ps[i].push, keys, values)
+
+    def start(self):
+        self.p1.start()
+
+    def end(self):
+        self._stop.set()
+        while True:                  # a helper blocked on a full q1 is let through
+            try:
+                self.q1.get_nowait()
+            except Exception:
+                break
+        self.p1.join(5)
+
+
+def worker_train_dqn(ps, node_buffer, opt, learner_index, node_ps=None, make_agent=None, make_cache=None):
+    """algos/dqn/train.py:213-231."""
+    if make_agent is None:
+        from .dqn import Learner
+        make_agent = lambda o_: Learner(o_, job="learner")
+    if make_cache is None:
+        make_cache = lambda nb: BatchCache(nb, opt, node_ps if node_ps is not None else [ps])
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+    cache = make_cache(node_buffer)
+    cache.start()
+    max_updates = getattr(opt, "max_updates", None)
+    cnt = 1
+    while True:
+        batch = cache.q1.get()
+        agent.train(batch, cnt)
+        if cnt % opt.push_freq == 0:
+            cache.q2.put(agent.get_weights())
+        if (max_updates is not None and cnt >= max_updates) or _stop(opt):
+            end = getattr(cache, "end", None)
+            if end is not None:
+                end()
+            return cnt
+        cnt += 1
+
+
+def worker_rollout_dqn(ps, replay_buffer, opt, worker_index, make_env=None, make_agent=None, rng=None):
+    """algos/dqn/train.py:234-287.  `replay_buffer` is the node's list of buffers: the counters that decide between policy and random
+    actions are read from ONE random buffer at each episode start (and scaled by num_buffers), every transition goes to a random
+    buffer; an episode ends at the env's own terminal only.  `rng`: seed() / choice(n, 1) (default np.random — the reference
+    reseeds from the OS before every choice)."""
+    import numpy as np
+    if rng is None:
+        rng = np.random
+    if make_agent is None:
+        from .dqn import Actor
+        make_agent = lambda o_: Actor(o_, job="worker")
+    if make_env is None:
+        make_env = lambda: _default_env(opt.env_name, opt)
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    rng.seed()
+    env = make_env()
+    while not _stop(opt):
+        o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+        weights = _get(_remote(ps.pull, keys))
+        agent.set_weights(keys, weights)
+        rng.seed()
+        rand_buff = rng.choice(opt.num_buffers, 1)[0]
+        last_learner_steps, last_actor_steps, _size = _get(_remote(replay_buffer[rand_buff].get_counts))
+        while True:
+            if last_actor_steps * opt.num_buffers > opt.start_steps or opt.recover:
+                a = agent.get_action(o)
+            else:
+                a = env.action_space.sample()
+            o2, r, d, _ = env.step(a)
+            ep_ret += r
+            ep_len += 1
+            rng.seed()
+            rand_buff = rng.choice(opt.num_buffers, 1)[0]
+            _remote(replay_buffer[rand_buff].store, o, a, r, o2, d, worker_index)
+            o = o2
+            if d:
+                break
+
+
+def worker_test_dqn(ps, node_buffer, opt, node_ps=None, make_env=None, make_agent=None, clock=time.time, log=print, wait=None,
+                    max_rounds=None):
+    """algos/dqn/train.py:289-355: pull everything, 10 test episodes, actor / learner counters before and after (a_l_ratio and the
+    learner's update frequency over the test's duration), TensorBoard scalars, the whole weight dict pickled every save_interval
+    learner steps, every server and every buffer checkpointed every checkpoint_freq seconds."""
+    import pickle
+    import numpy as np
+    if make_agent is None:
+        from .dqn import Actor
+        make_agent = lambda o_: Actor(o_, job="test")
+    if make_env is None:
+        make_env = lambda: _default_env(opt.env_name, opt)
+    if node_ps is None:
+        node_ps = [ps]
+    if wait is None:
+        wait = lambda ops, num_returns: _ray.wait(ops, num_returns=num_returns)
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    test_env = make_env()
+    init_time = clock()
+    save_times = checkpoint_times = rounds = 0
+    while True:
+        weights_all = _get(_remote(ps.get_weights))     # all of them: saved to disk below
+        agent.set_weights(keys, [weights_all[key] for key in keys])
+        start_actor_step, start_learner_step, _ = get_al_status(node_buffer, opt)
+        start_time = clock()
+        ave_test_reward, ave_score = agent.test(test_env, 10)
+        last_actor_step, last_learner_step, _ = get_al_status(node_buffer, opt)
+        actor_step = np.sum(last_actor_step) - np.sum(start_actor_step)
+        learner_step = np.sum(last_learner_step) - np.sum(start_learner_step)
+        alratio = actor_step / (learner_step + 1)
+        update_frequency = int(learner_step / (clock() - start_time))
+        total_learner_step = np.sum(last_learner_step)
+        log("---------------------------------------------------")
+        log("average test reward: %s" % ave_test_reward)
+        log("average test score: %s" % ave_score)
+        log("frame freq: %s" % np.round((last_actor_step - start_actor_step) / (clock() - start_time)))
+        log("actor_steps: %s learner_step: %s" % (np.sum(last_actor_step), total_learner_step))
+        log("actor leaner ratio: %.2f" % alratio)
+        log("learner freq: %s" % update_frequency)
+        log("---------------------------------------------------")
+        if learner_step < 100:
+            alratio = 0
+        agent.write_tb(ave_test_reward, ave_score, alratio, update_frequency, total_learner_step)
+        total_time = clock() - init_time
+        if total_learner_step // opt.save_interval > save_times:
+            with open(opt.save_dir + "/" + str(total_learner_step / 1e6) + "M_" + str(ave_test_reward) + "_weights.pickle", "wb") as pickle_out:
+                pickle.dump(weights_all, pickle_out)
+                log("****** Weights saved by time! ******")
+            save_times = total_learner_step // opt.save_interval
+        if total_time // opt.checkpoint_freq > checkpoint_times:
+            log("save everything!")
+            save_start_time = clock()
+            ps_save_op = [_remote(node_ps[i].save_weights) for i in range(opt.num_nodes)]
+            buffer_save_op = [_remote(node_buffer[node_index][i].save) for i in range(opt.num_buffers) for node_index in range(opt.num_nodes)]
+            wait(buffer_save_op + ps_save_op, opt.num_nodes * opt.num_buffers + 1)
+            log("total time for saving : %s" % (clock() - save_start_time))
+            checkpoint_times = total_time // opt.checkpoint_freq
+        rounds += 1
+        if (max_rounds is not None and rounds >= max_rounds) or _stop(opt):
+            return ave_test_reward
 
 
 # ------------------------------------------------------------------------------------------

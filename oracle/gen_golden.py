@@ -335,6 +335,266 @@ def gen_worker_traces(dsac, sac1):
         json.dump(out, f, indent=0)
 
 
+
+class _NpProxy:
+    """numpy as algos/dqn/train.py sees it, with np.random.seed() / np.random.choice(n, 1) scripted and recorded (the reference
+    reseeds from the OS before every buffer choice: the choice is random BY DESIGN — the trace pins what is done with it)."""
+
+    def __init__(self, ev, choices):
+        self._ev, self._choices = ev, list(choices)
+        self.random = self
+
+    def seed(self, *a):
+        self._ev.append(["np_seed"])
+
+    def choice(self, n, k):
+        v = self._choices.pop(0) if self._choices else 0
+        self._ev.append(["choice", int(n), int(v)])
+        return np.array([v])
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+def gen_dqn_driver_traces(dqn):
+    """algos/dqn/train.py: worker_rollout (234-287), worker_train (213-231), Cache.ps_update (188-205), worker_test + get_al_status
+    (289-371) — the event order of each, recorded by running the reference's own functions on scripted fakes."""
+    ev = []
+
+    class Remote:
+        def __init__(self, fn):
+            self.remote = fn
+
+    class Args:
+        pass
+
+    class FakeSpace:
+        def sample(self):
+            ev.append(["sample_random"])
+            return 2
+
+    class FakeEnv:
+        lens = [3, 2, 4]
+        rewards = [7.5]
+
+        def __init__(self, *a, **k):
+            self.action_space = FakeSpace()
+            self.ep, self.k = -1, 0
+
+        def reset(self):
+            self.ep += 1
+            if self.ep >= len(self.lens):
+                raise _Stop()
+            self.k = 0
+            ev.append(["reset"])
+            return np.full(4, float(self.ep), np.float64)
+
+        def step(self, a):
+            self.k += 1
+            ev.append(["env_step", int(a)])
+            return np.full(4, self.ep + 0.01 * self.k, np.float64), 0.5 * self.k, self.k >= self.lens[self.ep], {}
+
+    class FakeAgent:
+        n_train = 0
+
+        def __init__(self, opt, job):
+            ev.append(["agent", job])
+
+        def get_weights(self):
+            return ["main/q/w"], [np.zeros(1, np.float32)]
+
+        def set_weights(self, keys, w):
+            ev.append(["set_weights", list(keys)])
+
+        def get_action(self, o):
+            ev.append(["get_action", float(np.asarray(o).ravel()[0])])
+            return 1
+
+        def train(self, batch, cnt):
+            ev.append(["train", int(batch["id"]), int(cnt)])
+            if cnt >= 7:
+                raise _Stop()
+
+    class FakePS:
+        def __init__(self, idx=0):
+            self.pull = Remote(lambda keys: (ev.append(["pull", list(keys)]), [np.zeros(1, np.float32)])[1])
+            self.push = Remote(lambda keys, vals: ev.append(["push", idx, list(keys)]))
+            self.get_weights = Remote(lambda: (ev.append(["ps_get_weights"]), {"main/q/w": np.zeros(1, np.float32), "target/q/w": np.ones(1, np.float32)})[1])
+            self.save_weights = Remote(lambda: (ev.append(["ps_save_weights", idx]), "psop")[1])
+
+    class FakeRB:
+        def __init__(self, name, counts):
+            self.name, self.counts = name, list(counts)
+            self.store = Remote(lambda o, a, r, o2, d, wi: ev.append(
+                ["store", name, float(np.asarray(o).ravel()[0]), int(a), float(r), float(np.asarray(o2).ravel()[0]), bool(d), int(wi)]))
+            self.get_counts = Remote(self._counts)
+            self.sample_batch = Remote(lambda: (ev.append(["sample_batch", name]), {"id": 0})[1])
+            self.save = Remote(lambda: (ev.append(["rb_save", name]), "rbop")[1])
+
+        def _counts(self):
+            c = self.counts.pop(0) if len(self.counts) > 1 else self.counts[0]
+            ev.append(["get_counts", self.name, list(c)])
+            return tuple(c)
+
+    out = {}
+    fake_env_mod = types.ModuleType("trading_env")
+    fake_env_mod.TradingEnv, fake_env_mod.FrameStack = FakeEnv, None
+    sys.modules["trading_env"] = fake_env_mod
+    real_np = dqn.np
+    # ---- worker_rollout: two buffers; episode 1 below start_steps (random actions), episodes 2-3 above it
+    opt = Args()
+    opt.num_buffers, opt.start_steps, opt.recover = 2, 10, False
+    choices = [1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 1]
+    dqn.np = _NpProxy(ev, choices)
+    dqn.Actor = FakeAgent
+    rbs = [FakeRB("b0", [[0, 4, 4], [5, 9, 9]]), FakeRB("b1", [[0, 3, 3], [2, 6, 6], [4, 8, 8]])]
+    try:
+        dqn.worker_rollout(FakePS(), rbs, opt, 3)
+    except _Stop:
+        pass
+    out["rollout"] = {"args": {"num_buffers": 2, "start_steps": 10, "recover": False, "worker_index": 3, "episode_lens": FakeEnv.lens,
+                               "choices": choices, "counts": {"b0": [[0, 4, 4], [5, 9, 9]], "b1": [[0, 3, 3], [2, 6, 6], [4, 8, 8]]}},
+                      "events": list(ev)}
+    # ---- the same with opt.recover: the policy acts from the first step whatever the counters say
+    ev.clear()
+    opt.recover = True
+    dqn.np = _NpProxy(ev, [0, 0, 0, 0])
+    FakeEnv.lens = [2]
+    try:
+        dqn.worker_rollout(FakePS(), [FakeRB("b0", [[0, 0, 0]])], opt, 0)
+    except _Stop:
+        pass
+    out["rollout_recover"] = {"events": list(ev)}
+    FakeEnv.lens = [3, 2, 4]
+    dqn.np = real_np
+    # ---- worker_train: pull, set, cache.start(), then train(batch, cnt) on what q1 hands out, weights into q2 every push_freq
+    ev.clear()
+
+    class FakeQueue:
+        def __init__(self, name):
+            self.name, self.n = name, 0
+
+        def get(self):
+            self.n += 1
+            return {"id": self.n}
+
+        def put(self, x):
+            ev.append(["%s_put" % self.name, list(x[0])])
+
+    class FakeCache:
+        def __init__(self, node_buffer):
+            ev.append(["cache_init"])
+            self.q1, self.q2 = FakeQueue("q1"), FakeQueue("q2")
+
+        def start(self):
+            ev.append(["cache_start"])
+
+    opt = Args()
+    opt.push_freq = 3
+    real_cache = dqn.Cache
+    dqn.Learner, dqn.Cache = FakeAgent, FakeCache
+    try:
+        dqn.worker_train(FakePS(), [[None]], opt, 0)
+    except _Stop:
+        pass
+    out["train"] = {"args": {"push_freq": 3, "stop_at_cnt": 7}, "events": list(ev)}
+    # ---- Cache.ps_update (the helper process): one batch up front, then a batch whenever fewer than 10 wait, pushes to EVERY node's server
+    ev.clear()
+    opt = Args()
+    opt.num_nodes, opt.num_buffers = 2, 2
+    dqn.opt = opt
+    dqn.node_ps = [FakePS(0), FakePS(1)]
+    choices = [1, 0, 0, 1, 1, 1, 0, 0]
+    dqn.np = _NpProxy(ev, choices)
+    sizes, empties = [1, 10, 12, 9, 10], [True, False, True, True, False]
+
+    class ScriptQ1:
+        def qsize(self):
+            if not sizes:
+                raise _Stop()
+            v = sizes.pop(0)
+            ev.append(["q1_qsize", v])
+            return v
+
+        def put(self, b):
+            ev.append(["q1_put"])
+
+    class ScriptQ2:
+        def empty(self):
+            v = empties.pop(0)
+            ev.append(["q2_empty", v])
+            return v
+
+        def get(self):
+            ev.append(["q2_get"])
+            return ["main/q/w"], [np.zeros(1, np.float32)]
+
+    nb = [[FakeRB("n0b0", [[0, 0, 0]]), FakeRB("n0b1", [[0, 0, 0]])], [FakeRB("n1b0", [[0, 0, 0]]), FakeRB("n1b1", [[0, 0, 0]])]]
+    try:
+        real_cache.ps_update(None, ScriptQ1(), ScriptQ2(), nb)
+    except _Stop:
+        pass
+    dqn.np = real_np
+    out["cache"] = {"args": {"num_nodes": 2, "num_buffers": 2, "choices": choices, "q1_sizes": [1, 10, 12, 9, 10],
+                             "q2_empty": [True, False, True, True, False]}, "events": list(ev)}
+    # ---- worker_test: two rounds; scripted counters and clock
+    ev.clear()
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    opt = Args()
+    opt.num_nodes, opt.num_buffers, opt.save_interval, opt.checkpoint_freq, opt.save_dir = 1, 2, 1000, 100.0, tmp
+    dqn.opt = opt
+    dqn.node_ps = [FakePS(0)]
+    results = [(1.5, 7.5), (2.5, 8.5)]
+
+    class FakeTester(FakeAgent):
+        def test(self, env, n):
+            if not results:
+                raise _Stop()
+            ev.append(["agent_test", int(n)])
+            return results.pop(0)
+
+        def write_tb(self, ave_test_reward, ave_score, alratio, update_frequency, total_learner_step):
+            ev.append(["write_tb", float(ave_test_reward), float(ave_score), float(alratio), int(update_frequency), int(total_learner_step)])
+
+    clock = [0.0, 10.0, 12.0, 12.0, 12.0, 50.0, 60.0, 62.0, 130.0, 130.0, 131.0]
+
+    class TimeProxy:
+        @staticmethod
+        def time():
+            v = clock.pop(0) if len(clock) > 1 else clock[0]
+            ev.append(["time", v])
+            return v
+
+    real_time, real_wait = dqn.time, dqn.ray.wait
+    dqn.time = TimeProxy
+    dqn.ray.wait = lambda ops, num_returns=1: (ev.append(["ray_wait", len(ops), int(num_returns)]), (ops, []))[1]
+    dqn.ray.cluster_resources = lambda: {}
+    dqn.ray.available_resources = lambda: {}
+    dqn.Actor = FakeTester
+    # (learner_steps, actor_steps, size) per buffer and call: round 1: 40 -> 1250 learner steps over both buffers; round 2: -> 2600
+    nb = [[FakeRB("b0", [[20, 100, 100], [600, 300, 300], [600, 300, 300], [1300, 500, 500]]),
+           FakeRB("b1", [[20, 100, 100], [650, 320, 320], [650, 320, 320], [1300, 520, 520]])]]
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        dqn.worker_test(FakePS(0), nb, opt)
+    except _Stop:
+        pass
+    finally:
+        builtins.print = real_print
+        dqn.time, dqn.ray.wait = real_time, real_wait
+    saved = sorted(os.listdir(tmp))
+    out["test"] = {"args": {"num_nodes": 1, "num_buffers": 2, "save_interval": 1000, "checkpoint_freq": 100.0,
+                            "clock": [0.0, 10.0, 12.0, 12.0, 12.0, 50.0, 60.0, 62.0, 130.0, 130.0, 131.0],
+                            "results": [[1.5, 7.5], [2.5, 8.5]]},
+                   "events": list(ev), "files": saved}
+    with open(os.path.join(OUT, "dqn_driver_traces.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    sys.modules.pop("trading_env", None)
+
+
 def nstep_windows(n_store, Ln=4, obs_dim=115):
     """The deque contents a sac_ray-style rollout hands to store(): yields (o_queue, a_r_d_queue)
     snapshots (deques of (o,) tuples / (a, r, d) tuples), scalar actions (act_shape == ())."""
@@ -402,6 +662,7 @@ def main():
     gen_ring_and_gather(dsac, sac1, dqn)
     gen_ps(dsac)
     gen_worker_traces(dsac, sac1)
+    gen_dqn_driver_traces(dqn)
     sys.path.remove(os.path.join(REF, "algos", "dqn"))
     for m in ("core", "hyperparams", "actor_learner", "trading_env"):
         sys.modules.pop(m, None)

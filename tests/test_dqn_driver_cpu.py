@@ -1,0 +1,283 @@
+"""Host logic (no GPU): the DQN / SQN driver's workers (algos/dqn/train.py:177-371) against traces recorded from the reference's OWN
+functions on scripted fakes (tests/golden/dqn_driver_traces.json, oracle/gen_golden.py::gen_dqn_driver_traces): event order of
+worker_rollout (random buffer per store, counters of one random buffer per episode, policy / random switch, recover),
+worker_train (Cache hand-off, push cadence), the Cache helper's loop, worker_test (counters, a_l_ratio, update frequency, TensorBoard
+values, weight pickles, checkpoint fan-out)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from distributed_drl_amd import workers
+
+
+class _Stop(Exception):
+    pass
+
+
+class _Args:
+    pass
+
+
+@pytest.fixture(scope="module")
+def traces(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "dqn_driver_traces.json")))
+
+
+class _Rng:
+    """np.random as the reference's worker sees it: seed() and choice(n, 1), scripted."""
+
+    def __init__(self, ev, choices):
+        self.ev, self.choices = ev, list(choices)
+
+    def seed(self, *a):
+        self.ev.append(["np_seed"])
+
+    def choice(self, n, k):
+        v = self.choices.pop(0) if self.choices else 0
+        self.ev.append(["choice", int(n), int(v)])
+        return np.array([v])
+
+
+def _fakes(ev, lens):
+    class FakeSpace:
+        def sample(self):
+            ev.append(["sample_random"])
+            return 2
+
+    class FakeEnv:
+        rewards = [7.5]
+
+        def __init__(self):
+            self.action_space = FakeSpace()
+            self.ep, self.k = -1, 0
+
+        def reset(self):
+            self.ep += 1
+            if self.ep >= len(lens):
+                raise _Stop()
+            self.k = 0
+            ev.append(["reset"])
+            return np.full(4, float(self.ep), np.float64)
+
+        def step(self, a):
+            self.k += 1
+            ev.append(["env_step", int(a)])
+            return np.full(4, self.ep + 0.01 * self.k, np.float64), 0.5 * self.k, self.k >= lens[self.ep], {}
+
+    class FakeAgent:
+        def __init__(self, job):
+            ev.append(["agent", job])
+
+        def get_weights(self):
+            return ["main/q/w"], [np.zeros(1, np.float32)]
+
+        def set_weights(self, keys, w):
+            ev.append(["set_weights", list(keys)])
+
+        def get_action(self, o):
+            ev.append(["get_action", float(np.asarray(o).ravel()[0])])
+            return 1
+
+        def train(self, batch, cnt):
+            ev.append(["train", int(batch["id"]), int(cnt)])
+            if cnt >= 7:
+                raise _Stop()
+
+    class FakePS:
+        def __init__(self, idx=0):
+            self.idx = idx
+
+        def pull(self, keys):
+            ev.append(["pull", list(keys)])
+            return [np.zeros(1, np.float32)]
+
+        def push(self, keys, vals):
+            ev.append(["push", self.idx, list(keys)])
+
+        def get_weights(self):
+            ev.append(["ps_get_weights"])
+            return {"main/q/w": np.zeros(1, np.float32), "target/q/w": np.ones(1, np.float32)}
+
+        def save_weights(self):
+            ev.append(["ps_save_weights", self.idx])
+            return "psop"
+
+    class FakeRB:
+        def __init__(self, name, counts):
+            self.name, self.counts = name, [list(c) for c in counts]
+
+        def store(self, o, a, r, o2, d, wi):
+            ev.append(["store", self.name, float(np.asarray(o).ravel()[0]), int(a), float(r), float(np.asarray(o2).ravel()[0]), bool(d), int(wi)])
+
+        def get_counts(self):
+            c = self.counts.pop(0) if len(self.counts) > 1 else self.counts[0]
+            ev.append(["get_counts", self.name, list(c)])
+            return tuple(c)
+
+        def sample_batch(self):
+            ev.append(["sample_batch", self.name])
+            return {"id": 0}
+
+        def save(self):
+            ev.append(["rb_save", self.name])
+            return "rbop"
+
+    return FakeEnv, FakeAgent, FakePS, FakeRB
+
+
+def test_worker_rollout_dqn_event_order_matches_reference(traces):
+    t = traces["rollout"]
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, t["args"]["episode_lens"])
+    opt = _Args()
+    opt.num_buffers, opt.start_steps, opt.recover = t["args"]["num_buffers"], t["args"]["start_steps"], t["args"]["recover"]
+    rbs = [RB(k, t["args"]["counts"][k]) for k in ("b0", "b1")]
+    with pytest.raises(_Stop):
+        workers.worker_rollout_dqn(PS(), rbs, opt, t["args"]["worker_index"], make_env=Env, make_agent=lambda o: Agent("worker"),
+                                   rng=_Rng(ev, t["args"]["choices"]))
+    assert ev == t["events"]
+    # the switch reads ONE random buffer's actor_steps, scaled by num_buffers, once per episode: episode 2 (4 * 2 = 8 <= 10) is still random
+    assert sum(1 for e in ev if e[0] == "sample_random") == 5 and sum(1 for e in ev if e[0] == "get_action") == 4
+    # ... and with opt.recover the policy acts from the first step whatever the counters say
+    ev.clear()
+    Env, Agent, PS, RB = _fakes(ev, [2])
+    opt.recover = True
+    with pytest.raises(_Stop):
+        workers.worker_rollout_dqn(PS(), [RB("b0", [[0, 0, 0]])], opt, 0, make_env=Env, make_agent=lambda o: Agent("worker"), rng=_Rng(ev, [0, 0, 0, 0]))
+    assert ev == traces["rollout_recover"]["events"]
+
+
+def test_worker_train_dqn_hands_weights_to_the_cache_every_push_freq(traces):
+    t = traces["train"]
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, [1])
+
+    class Q:
+        def __init__(self, name):
+            self.name, self.n = name, 0
+
+        def get(self):
+            self.n += 1
+            return {"id": self.n}
+
+        def put(self, x):
+            ev.append(["%s_put" % self.name, list(x[0])])
+
+    class Cache:
+        def __init__(self, nb):
+            ev.append(["cache_init"])
+            self.q1, self.q2 = Q("q1"), Q("q2")
+
+        def start(self):
+            ev.append(["cache_start"])
+
+    opt = _Args()
+    opt.push_freq = t["args"]["push_freq"]
+    with pytest.raises(_Stop):
+        workers.worker_train_dqn(PS(), [[None]], opt, 0, make_agent=lambda o: Agent("learner"), make_cache=Cache)
+    assert ev == t["events"]
+
+
+def test_batch_cache_loop_matches_the_reference_helper(traces):
+    t = traces["cache"]
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, [1])
+    opt = _Args()
+    opt.num_nodes, opt.num_buffers = t["args"]["num_nodes"], t["args"]["num_buffers"]
+    sizes, empties = list(t["args"]["q1_sizes"]), list(t["args"]["q2_empty"])
+
+    class Q1:
+        def qsize(self):
+            if not sizes:
+                raise _Stop()
+            v = sizes.pop(0)
+            ev.append(["q1_qsize", v])
+            return v
+
+        def put(self, b):
+            ev.append(["q1_put"])
+
+    class Q2:
+        def empty(self):
+            v = empties.pop(0)
+            ev.append(["q2_empty", v])
+            return v
+
+        def get(self):
+            ev.append(["q2_get"])
+            return ["main/q/w"], [np.zeros(1, np.float32)]
+
+    nb = [[RB("n%db%d" % (n, b), [[0, 0, 0]]) for b in range(2)] for n in range(2)]
+    cache = workers.BatchCache(nb, opt, [PS(0), PS(1)], rng=_Rng(ev, t["args"]["choices"]))
+    with pytest.raises(_Stop):
+        cache.ps_update(Q1(), Q2(), nb)
+    assert ev == t["events"]
+
+
+def test_batch_cache_thread_feeds_a_real_learner_loop():
+    """The thread form end to end on plain objects: batches arrive, pushes reach every node's server, end() stops the helper."""
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, [1])
+    opt = _Args()
+    opt.num_nodes, opt.num_buffers, opt.push_freq, opt.max_updates = 2, 2, 2, 6
+    nb = [[RB("n%db%d" % (n, b), [[0, 0, 0]]) for b in range(2)] for n in range(2)]
+    pss = [PS(0), PS(1)]
+
+    class Learner(Agent):
+        def train(self, batch, cnt):
+            pass
+    n = workers.worker_train_dqn(pss[0], nb, opt, 0, node_ps=pss, make_agent=lambda o: Learner("learner"))
+    assert n == 6
+    pushes = [e for e in ev if e[0] == "push"]
+    assert len(pushes) == 6 and [e[1] for e in pushes] == [0, 1] * 3   # three hand-offs, each to both servers; end() lets the last ones out
+    assert sum(1 for e in ev if e[0] == "sample_batch") >= 6
+
+
+def test_worker_test_dqn_matches_reference(traces, tmp_path):
+    t = traces["test"]
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, [1])
+    results = [tuple(r) for r in t["args"]["results"]]
+
+    class Tester(Agent):
+        def test(self, env, n):
+            if not results:
+                raise _Stop()
+            ev.append(["agent_test", int(n)])
+            return results.pop(0)
+
+        def write_tb(self, ave_test_reward, ave_score, alratio, update_frequency, total_learner_step):
+            ev.append(["write_tb", float(ave_test_reward), float(ave_score), float(alratio), int(update_frequency), int(total_learner_step)])
+
+    clock = list(t["args"]["clock"])
+
+    def now():
+        v = clock.pop(0) if len(clock) > 1 else clock[0]
+        ev.append(["time", v])
+        return v
+    opt = _Args()
+    opt.num_nodes, opt.num_buffers, opt.save_interval = t["args"]["num_nodes"], t["args"]["num_buffers"], t["args"]["save_interval"]
+    opt.checkpoint_freq, opt.save_dir = t["args"]["checkpoint_freq"], str(tmp_path)
+    nb = [[RB("b0", [[20, 100, 100], [600, 300, 300], [600, 300, 300], [1300, 500, 500]]),
+           RB("b1", [[20, 100, 100], [650, 320, 320], [650, 320, 320], [1300, 520, 520]])]]
+    ps = PS(0)
+    with pytest.raises(_Stop):
+        workers.worker_test_dqn(ps, nb, opt, node_ps=[ps], make_env=Env, make_agent=lambda o: Tester("test"), clock=now, log=lambda s: None,
+                                wait=lambda ops, num_returns: ev.append(["ray_wait", len(ops), int(num_returns)]))
+    assert ev == t["events"]
+    assert sorted(os.listdir(tmp_path)) == t["files"]
+    import pickle
+    w = pickle.load(open(tmp_path / t["files"][0], "rb"))
+    assert sorted(w) == ["main/q/w", "target/q/w"]                    # the WHOLE weight dict, not only the actor's keys
+
+
+def test_get_al_status_orders_like_the_reference():
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, [1])
+    opt = _Args()
+    opt.num_nodes, opt.num_buffers = 2, 2
+    nb = [[RB("n0b0", [[1, 2, 3]]), RB("n0b1", [[4, 5, 6]])], [RB("n1b0", [[7, 8, 9]]), RB("n1b1", [[10, 11, 12]])]]
+    actor, learner, size = workers.get_al_status(nb, opt)
+    assert actor.tolist() == [2, 5, 8, 11] and learner.tolist() == [1, 4, 7, 10] and size.tolist() == [3, 6, 9, 12]

@@ -1,5 +1,6 @@
 """End-to-end on the GPU: a driver with the structure of example/dsac.py:218-238 running the
 reference-style workers through the remote shim, and the device-style workers."""
+import os
 import threading
 import time
 
@@ -645,3 +646,87 @@ def test_new_entry_points_refuse_what_they_cannot_do():
     assert lib.ddrl_dqn_step_ring(ln._h, ring._h, None, None, None, None) == _lib.DDRL_ERR_UNSUPPORTED
     with pytest.raises(ValueError, match="high <= 0"):
         ln.train_from(ring)                        # the fallback's sample_batch on an empty ring: the reference's ValueError
+
+
+@pytest.mark.parametrize("variant", ["ddqn", "sqn"])
+def test_dqn_shaped_driver_end_to_end(tmp_path, variant):
+    """algos/dqn/train.py's __main__ (374-462) in small: a node's parameter server and two buffers, rollout workers storing into random
+    buffers, the learner fed by the Cache helper, the tester's round (TensorBoard scalars, weight pickle, checkpoint of server and
+    buffers) — real classes on the GPU, a scripted host env in place of TradingEnv.  Also algos/sqn/train.py (the same driver)."""
+    import pickle
+    import threading
+    import distributed_drl_amd as ddrl
+    from distributed_drl_amd import dqn, workers
+    from distributed_drl_amd.logx import read_scalars
+
+    class Opt:
+        pass
+    opt = Opt()
+    opt.obs_dim, opt.act_dim, opt.hidden_size, opt.gamma, opt.lr, opt.polyak, opt.batch_size, opt.seed, opt.alpha = 6, 3, [32, 24], 0.99, 1e-3, 0.995, 16, 1, 0.1
+    opt.buffer_size, opt.num_buffers, opt.num_nodes, opt.start_steps, opt.recover, opt.push_freq = 500, 2, 1, 40, False, 5
+    opt.save_dir, opt.summary_dir, opt.save_interval, opt.checkpoint_freq = str(tmp_path), str(tmp_path / "tb"), 10, 1e-3
+    opt.env_name, opt.exp_name, opt.num_workers, opt.a_l_ratio, opt.max_updates = "Scripted", "t", 2, 10, 25
+    L, A = (dqn.LearnerSQN, dqn.ActorSQN) if variant == "sqn" else (dqn.Learner, dqn.Actor)
+
+    class Env:
+        """Episodes of 7 steps; reward = 1 when the action equals the step's parity class."""
+
+        class _Space:
+            def __init__(self, rs):
+                self.rs = rs
+
+            def sample(self):
+                return int(self.rs.randint(0, 3))
+
+        def __init__(self, seed=0):
+            self.rs = np.random.RandomState(seed)
+            self.action_space = Env._Space(self.rs)
+            self.rewards = [0.0]
+
+        def reset(self):
+            self.k, self.rewards = 0, [0.0]
+            return self.rs.rand(6)
+
+        def step(self, a):
+            self.k += 1
+            r = 1.0 if int(a) == self.k % 3 else 0.0
+            self.rewards[0] += r
+            return self.rs.rand(6), r, self.k >= 7, {}
+
+    keys, values = L(opt, "ps").get_weights()
+    ps = ddrl.ParameterServerNode(opt, keys=keys, values=values)
+    bufs = [ddrl.ReplayBufferDQN(opt, i, seed=i) for i in range(opt.num_buffers)]
+    node_buffer = [bufs]
+    # ---- rollouts: two workers, stopped once the buffers hold enough
+    opt.stop_event = threading.Event()
+    threads = [threading.Thread(target=workers.worker_rollout_dqn, args=(ps, bufs, opt, i),
+                                kwargs=dict(make_env=lambda i=i: Env(i), make_agent=lambda o: A(o, "worker")), daemon=True) for i in range(2)]
+    for t in threads:
+        t.start()
+    t0 = time.time()
+    while sum(b.get_counts()[1] for b in bufs) < 150 and time.time() - t0 < 60:
+        time.sleep(0.01)
+    opt.stop_event.set()
+    for t in threads:
+        t.join(30)
+    opt.stop_event = None
+    _, actor_steps, sizes = workers.get_al_status(node_buffer, opt)[0], [b.get_counts()[1] for b in bufs], [b.get_counts()[2] for b in bufs]
+    assert sum(actor_steps) >= 150 and min(actor_steps) > 20          # both buffers were stored into (a random one per transition)
+    # ---- learner: 25 updates through the Cache helper, weights to the server every 5
+    v0 = ps.get_weights()[keys[0]].copy()
+    n = workers.worker_train_dqn(ps, node_buffer, opt, 0, node_ps=[ps], make_agent=lambda o: L(o, "learner"))
+    assert n == 25 and ps.learner_step == 25 and np.abs(ps.get_weights()[keys[0]] - v0).max() > 0
+    assert sum(b.get_counts()[0] for b in bufs) >= 25                   # sample_batch counts as the reference's learner_steps
+    # ---- tester: one round
+    ret = workers.worker_test_dqn(ps, node_buffer, opt, node_ps=[ps], make_env=lambda: Env(9), make_agent=lambda o: A(o, "test"), log=lambda s: None,
+                                  wait=lambda ops, num_returns: None, max_rounds=1)
+    assert 0.0 <= ret <= 7.0
+    saved = [f for f in os.listdir(tmp_path) if f.endswith("_weights.pickle")]
+    assert len(saved) == 1 and sorted(pickle.load(open(tmp_path / saved[0], "rb"))) == sorted(ps.get_weights())
+    assert os.path.exists(tmp_path / "checkpoint" / "checkpoint_weights.pickle") and os.path.exists(tmp_path / "checkpoint" / "obs1_buf-1.npy")
+    runs = os.listdir(tmp_path / "tb")
+    assert len(runs) == 1 and "Scripted-t-workers_num:2%10" in runs[0]
+    run = tmp_path / "tb" / runs[0]
+    sc = read_scalars(str(run / os.listdir(run)[0]))
+    assert sorted(t for _, t, _ in sc) == ["Reward", "a_l_ratio", "score", "update_frequency"]
+    assert [v for _, t, v in sc if t == "Reward"][0] == pytest.approx(ret) and {st for st, _, _ in sc} == {sum(b.get_counts()[0] for b in bufs)}
