@@ -129,6 +129,44 @@ class LunarLander:
         return o2[0].cpu().numpy().astype(np.float64), float(r[0].item()), ended, {}
 
 
+class Wrapper(object):
+    """algos/sac1/hyperparams.py:107-134 on a host env: uniform action noise added IN PLACE to the caller's action (`action +=`),
+    the action repeated `action_repeat` times with the rewards summed and scaled — except that a terminal inside the repeat returns
+    reward 0.0, and action_repeat == 1 returns the first step's raw reward and un-noised observation (the reference's branches, kept
+    as they are).  The reference hard-codes BipedalWalker's sizes (24 observations, 4 actions) for the noise; here they follow the
+    arrays.  `rng`: np.random (the reference) or a seeded RandomState."""
+
+    def __init__(self, env, obs_noise, act_noise, reward_scale, action_repeat=3, rng=None):
+        self._env = env
+        self.action_repeat = action_repeat
+        self.act_noise = act_noise
+        self.obs_noise = obs_noise
+        self.reward_scale = reward_scale
+        self._rng = np.random if rng is None else rng
+
+    def __getattr__(self, name):
+        return getattr(self._env, name)
+
+    def _noisy(self, obs):
+        obs = np.asarray(obs)
+        return obs + self.obs_noise * (-2 * self._rng.random_sample(obs.shape[-1]) + 1)
+
+    def reset(self):
+        return self._noisy(self._env.reset())
+
+    def step(self, action):
+        action += self.act_noise * (-2 * self._rng.random_sample(np.asarray(action).shape[-1]) + 1)
+        r = 0.0
+        for _ in range(self.action_repeat):
+            obs_, reward_, done_, info_ = self._env.step(action)
+            r = r + reward_
+            if done_ and self.action_repeat != 1:
+                return self._noisy(obs_), 0.0, done_, info_
+            if self.action_repeat == 1:
+                return obs_, r, done_, info_
+        return self._noisy(obs_), self.reward_scale * r, done_, info_
+
+
 def make(env_name="LunarLanderContinuous-v2", **kw):
     """gym.make stand-in (example/dsac.py:78)."""
     if "LunarLander" not in env_name:

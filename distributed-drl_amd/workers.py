@@ -6,6 +6,7 @@ Mirrors:
   example/dsac.py:153-177   worker_test(ps, start_time)            (here: explicit args)
   algos/sac1/sac1.py:133-154,157-213,216-252   the SAC1 flavours (opt, index; a_l_ratio throttle)
   algos/dqn/train.py:177-371 (= algos/sqn/train.py)   the DQN / SQN driver: Cache, worker_train, worker_rollout, worker_test, get_al_status
+  algos/sac1/sac_ray.py:123-274                        the n-step driver: Cache (single server), worker_train, worker_rollout (window deques)
 
 `ps` / `replay_buffer` are actor handles (`remote.py` shim or Ray): methods are invoked as
 `handle.method.remote(...)` and awaited with `get`.  Two execution styles share these semantics:
@@ -274,18 +275,23 @@ class BatchCache:
     random node) and forwards the weights the learner leaves in q2 to EVERY node's parameter server.  The reference runs it as a
     daemon process; device-backed handles cannot cross a process boundary, so this one is a daemon thread over the same two queues."""
 
-    def __init__(self, node_buffer, opt, node_ps, rng=None):
+    def __init__(self, node_buffer, opt, node_ps, rng=None, nodes=True):
+        """nodes=False: the single-server form of algos/sac1/sac_ray.py:123-153 (and algos/sac1/sac1.py:103-130) — `node_buffer` is
+        one flat list of buffers, the weights go to node_ps[0], q1 holds ten."""
         import queue
         import threading
-        self.node_buffer, self.opt, self.node_ps = node_buffer, opt, node_ps
+        self.node_buffer, self.opt, self.node_ps, self.nodes = node_buffer, opt, node_ps, nodes
         self.rng = rng
-        self.q1, self.q2 = queue.Queue(12), queue.Queue(5)
+        self.q1, self.q2 = queue.Queue(12 if nodes else 10), queue.Queue(5)
         self._stop = threading.Event()
         self.p1 = threading.Thread(target=self.ps_update, args=(self.q1, self.q2, self.node_buffer), daemon=True)
 
     def _one_batch(self, q1, node_buffer):
         import numpy as np
         rng = self.rng if self.rng is not None else np.random
+        if not self.nodes:
+            q1.put(_get(_remote(node_buffer[rng.choice(self.opt.num_buffers, 1)[0]].sample_batch)))
+            return
         node_idx = rng.choice(self.opt.num_nodes, 1)[0]
         buffer_idx = rng.choice(self.opt.num_buffers, 1)[0]
         q1.put(_get(_remote(node_buffer[node_idx][buffer_idx].sample_batch)))   # (fresh arrays per call: the reference's deepcopy)
@@ -302,7 +308,7 @@ class BatchCache:
 
     def _forward(self, q2):
         keys, values = q2.get()
-        for i in range(self.opt.num_nodes):
+        for i in range(self.opt.num_nodes if self.nodes else 1):
             _remote(self.node_ps[i].push, keys, values)
 
     def start(self):
@@ -447,6 +453,88 @@ def worker_test_dqn(ps, node_buffer, opt, node_ps=None, make_env=None, make_agen
         rounds += 1
         if (max_rounds is not None and rounds >= max_rounds) or _stop(opt):
             return ave_test_reward
+
+
+# ------------------------------------------------------------------------------------------
+# algos/sac1/sac_ray.py flavour: the n-step driver (windows of Ln + 1 observations / Ln (a, r, d) triples out of per-worker deques)
+# ------------------------------------------------------------------------------------------
+def worker_rollout_nstep(ps, replay_buffer, opt, worker_index, make_env=None, make_agent=None, rng=None):
+    """algos/sac1/sac_ray.py:178-274 (opt.model != "cnn").  Random actions until `filling_steps` (counted on random actions only)
+    exceeds start_steps, or at once with opt.weights_file; a window goes to a random buffer whenever t_queue >= Ln and t_queue %
+    save_freq == 0; an episode ends at d or ep_len * action_repeat >= max_ep_len; the worker pulls at an episode end only once
+    buffer 0's `steps` exceed start_steps.  The deques live across episodes (t_queue restarts at 1, so no window spans a reset)."""
+    from collections import deque
+    import numpy as np
+    if rng is None:
+        rng = np.random
+    if make_agent is None:
+        from .agent import Actor
+        make_agent = lambda o_: Actor(o_, job="worker")
+    if make_env is None:
+        from . import env as _env
+        make_env = lambda: _env.Wrapper(_default_env(opt.env_name, opt), opt.obs_noise, opt.act_noise, opt.reward_scale, 3)
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    filling_steps = 0
+    env = make_env()
+    o_queue = deque([], maxlen=opt.Ln + 1)
+    a_r_d_queue = deque([], maxlen=opt.Ln)
+    o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+    t_queue = 1
+    o_queue.append((o,))
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+    while not _stop(opt):
+        if filling_steps > opt.start_steps or opt.weights_file:
+            a = agent.get_action(o, deterministic=False)
+        else:
+            a = env.action_space.sample()
+            filling_steps += 1
+        o2, r, d, _ = env.step(a)
+        ep_ret += r
+        ep_len += 1
+        o = o2
+        a_r_d_queue.append((a, r, d,))
+        o_queue.append((o2,))
+        if t_queue >= opt.Ln and t_queue % opt.save_freq == 0:
+            _remote(replay_buffer[rng.choice(opt.num_buffers, 1)[0]].store, o_queue, a_r_d_queue, worker_index)
+        t_queue += 1
+        if d or (ep_len * opt.action_repeat >= opt.max_ep_len):
+            sample_times, steps, _ = _get(_remote(replay_buffer[0].get_counts))
+            if steps > opt.start_steps:
+                weights = _get(_remote(ps.pull, keys))
+                agent.set_weights(keys, weights)
+            o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
+            t_queue = 1
+            o_queue.append((o,))
+
+
+def worker_train_nstep(ps, replay_buffer, opt, learner_index, make_agent=None, make_cache=None, push_every=100):
+    """algos/sac1/sac_ray.py:155-175: the learner behind the Cache helper, weights into its q2 every 100 updates (the literal at :173)."""
+    if make_agent is None:
+        from .agent import Learner
+        make_agent = lambda o_: Learner(o_, job="learner")
+    if make_cache is None:
+        make_cache = lambda rb: BatchCache(rb, opt, [ps], nodes=False)
+    agent = make_agent(opt)
+    keys = agent.get_weights()[0]
+    weights = _get(_remote(ps.pull, keys))
+    agent.set_weights(keys, weights)
+    cache = make_cache(replay_buffer)
+    cache.start()
+    max_updates = getattr(opt, "max_updates", None)
+    cnt = 1
+    while True:
+        batch = cache.q1.get()
+        agent.train(batch, cnt)
+        if cnt % push_every == 0:
+            cache.q2.put(agent.get_weights())
+        if (max_updates is not None and cnt >= max_updates) or _stop(opt):
+            end = getattr(cache, "end", None)
+            if end is not None:
+                end()
+            return cnt
+        cnt += 1
 
 
 # ------------------------------------------------------------------------------------------

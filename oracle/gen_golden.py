@@ -595,6 +595,176 @@ def gen_dqn_driver_traces(dqn):
     sys.modules.pop("trading_env", None)
 
 
+
+def gen_nstep_driver_traces(sac_ray):
+    """algos/sac1/sac_ray.py: worker_rollout (178-274: the window deques, the random-action budget, store cadence, the pull that waits
+    for the buffer's start_steps), worker_train (155-175: push every 100 through the Cache), Cache.ps_update (135-147)."""
+    ev = []
+
+    class Remote:
+        def __init__(self, fn):
+            self.remote = fn
+
+    class Args:
+        pass
+
+    class FakeSpace:
+        def sample(self):
+            ev.append(["sample_random"])
+            return np.array([0.5, -0.5], np.float32)
+
+    class FakeEnv:
+        lens = [6, 99, 3]
+
+        def __init__(self, *a, **k):
+            self.action_space = FakeSpace()
+            self.ep, self.k = -1, 0
+
+        def reset(self):
+            self.ep += 1
+            if self.ep >= len(self.lens):
+                raise _Stop()
+            self.k = 0
+            ev.append(["reset"])
+            return np.full(3, float(self.ep), np.float64)
+
+        def step(self, a):
+            self.k += 1
+            ev.append(["env_step", [float(x) for x in np.asarray(a).ravel()]])
+            return np.full(3, self.ep + 0.01 * self.k, np.float64), 0.25 * self.k, self.k >= self.lens[self.ep], {}
+
+    class FakeAgent:
+        def __init__(self, opt, job):
+            ev.append(["agent", job])
+
+        def get_weights(self):
+            return ["main/pi/w"], [np.zeros(1, np.float32)]
+
+        def set_weights(self, keys, w):
+            ev.append(["set_weights", list(keys)])
+
+        def get_action(self, o, deterministic=False):
+            ev.append(["get_action", float(np.asarray(o).ravel()[0]), bool(deterministic)])
+            return np.array([0.1, 0.2], np.float32)
+
+        def train(self, batch, cnt):
+            if cnt % 100 == 0 or cnt == 1:
+                ev.append(["train", int(batch["id"]), int(cnt)])
+            if cnt >= 201:
+                raise _Stop()
+
+    class FakePS:
+        def __init__(self):
+            self.pull = Remote(lambda keys: (ev.append(["pull", list(keys)]), [np.zeros(1, np.float32)])[1])
+            self.push = Remote(lambda keys, vals: ev.append(["push", list(keys)]))
+
+    class FakeRB:
+        def __init__(self, name, counts):
+            self.name, self.counts = name, [list(c) for c in counts]
+            self.store = Remote(lambda oq, aq, wi: ev.append(
+                ["store", name, [float(np.asarray(q[0]).ravel()[0]) for q in oq], [[float(q[0][0]), float(q[1]), bool(q[2])] for q in aq], int(wi)]))
+            self.get_counts = Remote(self._counts)
+            self.sample_batch = Remote(lambda: (ev.append(["sample_batch", name]), {"id": 0})[1])
+
+        def _counts(self):
+            c = self.counts.pop(0) if len(self.counts) > 1 else self.counts[0]
+            ev.append(["get_counts", self.name, list(c)])
+            return tuple(c)
+
+    out = {}
+    real_np = sac_ray.np
+    opt = Args()
+    opt.env_name, opt.obs_noise, opt.act_noise, opt.reward_scale, opt.model = "fake", 0, 0, 1, "mlp"
+    opt.Ln, opt.save_freq, opt.num_buffers, opt.start_steps, opt.weights_file, opt.action_repeat, opt.max_ep_len = 3, 2, 2, 4, "", 2, 10
+    sac_ray.Wrapper = lambda env, *a: env
+    sac_ray.gym.make = lambda name: FakeEnv()
+    sac_ray.Actor = FakeAgent
+    choices = [1, 0, 1, 1, 0]
+    sac_ray.np = _NpProxy(ev, choices)
+    counts0 = [[0, 3, 3], [1, 9, 9], [2, 12, 12]]
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        sac_ray.worker_rollout(FakePS(), [FakeRB("b0", counts0), FakeRB("b1", [[0, 0, 0]])], opt, 5)
+    except _Stop:
+        pass
+    finally:
+        builtins.print = real_print
+    out["rollout"] = {"args": {"Ln": 3, "save_freq": 2, "num_buffers": 2, "start_steps": 4, "action_repeat": 2, "max_ep_len": 10, "worker_index": 5,
+                               "episode_lens": FakeEnv.lens, "choices": choices, "counts_b0": counts0}, "events": list(ev)}
+    # ---- worker_train: push every 100 updates through the Cache's q2
+    ev.clear()
+    sac_ray.np = real_np
+
+    class FakeQueue:
+        def __init__(self, name):
+            self.name, self.n = name, 0
+
+        def get(self):
+            self.n += 1
+            return {"id": self.n}
+
+        def put(self, x):
+            ev.append(["%s_put" % self.name, list(x[0])])
+
+    class FakeCache:
+        def __init__(self, replay_buffer):
+            ev.append(["cache_init"])
+            self.q1, self.q2 = FakeQueue("q1"), FakeQueue("q2")
+
+        def start(self):
+            ev.append(["cache_start"])
+
+    real_cache = sac_ray.Cache
+    sac_ray.Learner, sac_ray.Cache = FakeAgent, FakeCache
+    try:
+        sac_ray.worker_train(FakePS(), [None], opt, 0)
+    except _Stop:
+        pass
+    out["train"] = {"events": list(ev)}
+    # ---- Cache.ps_update: the single-server form (global `ps`, global `opt`)
+    ev.clear()
+    sac_ray.opt = opt
+    sac_ray.ps = FakePS()
+    choices = [1, 0, 1]
+    sac_ray.np = _NpProxy(ev, choices)
+    sizes, empties = [2, 10, 9], [False, True, True]
+
+    class ScriptQ1:
+        def qsize(self):
+            if not sizes:
+                raise _Stop()
+            v = sizes.pop(0)
+            ev.append(["q1_qsize", v])
+            return v
+
+        def put(self, b):
+            ev.append(["q1_put"])
+
+    class ScriptQ2:
+        def empty(self):
+            v = empties.pop(0)
+            ev.append(["q2_empty", v])
+            return v
+
+        def get(self):
+            ev.append(["q2_get"])
+            return ["main/pi/w"], [np.zeros(1, np.float32)]
+
+    builtins.print = lambda *a, **k: None
+    try:
+        real_cache.ps_update(None, ScriptQ1(), ScriptQ2(), [FakeRB("b0", [[0, 0, 0]]), FakeRB("b1", [[0, 0, 0]])])
+    except _Stop:
+        pass
+    finally:
+        builtins.print = real_print
+    sac_ray.np = real_np
+    out["cache"] = {"args": {"num_buffers": 2, "choices": choices, "q1_sizes": [2, 10, 9], "q2_empty": [False, True, True]}, "events": list(ev)}
+    with open(os.path.join(OUT, "nstep_driver_traces.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 def nstep_windows(n_store, Ln=4, obs_dim=115):
     """The deque contents a sac_ray-style rollout hands to store(): yields (o_queue, a_r_d_queue)
     snapshots (deques of (o,) tuples / (a, r, d) tuples), scalar actions (act_shape == ())."""
@@ -668,6 +838,7 @@ def main():
         sys.modules.pop(m, None)
     sac_ray = _load(os.path.join(REF, "algos", "sac1", "sac_ray.py"), "ref_sac_ray", os.path.join(REF, "algos", "sac1"))
     gen_nstep(sac_ray)
+    gen_nstep_driver_traces(sac_ray)
     import subprocess
     subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen_golden_math.py")])
     print("golden fixtures written to", OUT)

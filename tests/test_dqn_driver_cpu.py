@@ -281,3 +281,194 @@ def test_get_al_status_orders_like_the_reference():
     nb = [[RB("n0b0", [[1, 2, 3]]), RB("n0b1", [[4, 5, 6]])], [RB("n1b0", [[7, 8, 9]]), RB("n1b1", [[10, 11, 12]])]]
     actor, learner, size = workers.get_al_status(nb, opt)
     assert actor.tolist() == [2, 5, 8, 11] and learner.tolist() == [1, 4, 7, 10] and size.tolist() == [3, 6, 9, 12]
+
+
+# ---- the n-step driver (algos/sac1/sac_ray.py:123-274) -------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ntraces(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "nstep_driver_traces.json")))
+
+
+def _nstep_fakes(ev, lens):
+    class FakeSpace:
+        def sample(self):
+            ev.append(["sample_random"])
+            return np.array([0.5, -0.5], np.float32)
+
+    class FakeEnv:
+        def __init__(self):
+            self.action_space = FakeSpace()
+            self.ep, self.k = -1, 0
+
+        def reset(self):
+            self.ep += 1
+            if self.ep >= len(lens):
+                raise _Stop()
+            self.k = 0
+            ev.append(["reset"])
+            return np.full(3, float(self.ep), np.float64)
+
+        def step(self, a):
+            self.k += 1
+            ev.append(["env_step", [float(x) for x in np.asarray(a).ravel()]])
+            return np.full(3, self.ep + 0.01 * self.k, np.float64), 0.25 * self.k, self.k >= lens[self.ep], {}
+
+    class FakeAgent:
+        def __init__(self, job):
+            ev.append(["agent", job])
+
+        def get_weights(self):
+            return ["main/pi/w"], [np.zeros(1, np.float32)]
+
+        def set_weights(self, keys, w):
+            ev.append(["set_weights", list(keys)])
+
+        def get_action(self, o, deterministic=False):
+            ev.append(["get_action", float(np.asarray(o).ravel()[0]), bool(deterministic)])
+            return np.array([0.1, 0.2], np.float32)
+
+        def train(self, batch, cnt):
+            if cnt % 100 == 0 or cnt == 1:
+                ev.append(["train", int(batch["id"]), int(cnt)])
+            if cnt >= 201:
+                raise _Stop()
+
+    class FakePS:
+        def pull(self, keys):
+            ev.append(["pull", list(keys)])
+            return [np.zeros(1, np.float32)]
+
+        def push(self, keys, vals):
+            ev.append(["push", list(keys)])
+
+    class FakeRB:
+        def __init__(self, name, counts):
+            self.name, self.counts = name, [list(c) for c in counts]
+
+        def store(self, oq, aq, wi):
+            ev.append(["store", self.name, [float(np.asarray(q[0]).ravel()[0]) for q in oq], [[float(q[0][0]), float(q[1]), bool(q[2])] for q in aq], int(wi)])
+
+        def get_counts(self):
+            c = self.counts.pop(0) if len(self.counts) > 1 else self.counts[0]
+            ev.append(["get_counts", self.name, list(c)])
+            return tuple(c)
+
+        def sample_batch(self):
+            ev.append(["sample_batch", self.name])
+            return {"id": 0}
+
+    return FakeEnv, FakeAgent, FakePS, FakeRB
+
+
+def test_worker_rollout_nstep_event_order_matches_reference(ntraces):
+    t = ntraces["rollout"]
+    a = t["args"]
+    ev = []
+    Env, Agent, PS, RB = _nstep_fakes(ev, a["episode_lens"])
+    opt = _Args()
+    opt.Ln, opt.save_freq, opt.num_buffers, opt.start_steps, opt.weights_file = a["Ln"], a["save_freq"], a["num_buffers"], a["start_steps"], ""
+    opt.action_repeat, opt.max_ep_len = a["action_repeat"], a["max_ep_len"]
+    with pytest.raises(_Stop):
+        workers.worker_rollout_nstep(PS(), [RB("b0", a["counts_b0"]), RB("b1", [[0, 0, 0]])], opt, a["worker_index"], make_env=Env,
+                                     make_agent=lambda o: Agent("worker"), rng=_Rng(ev, a["choices"]))
+    assert ev == t["events"]
+    # start_steps + 1 random actions (the budget counts random actions only); the first episode's end does not pull (buffer 0 at 3 <= 4 steps)
+    assert sum(1 for e in ev if e[0] == "sample_random") == a["start_steps"] + 1
+    first_counts = ev.index(["get_counts", "b0", [0, 3, 3]])
+    assert ev[first_counts + 1] == ["reset"]
+
+
+def test_worker_train_nstep_pushes_every_hundred(ntraces):
+    ev = []
+    Env, Agent, PS, RB = _nstep_fakes(ev, [1])
+
+    class Q:
+        def __init__(self, name):
+            self.name, self.n = name, 0
+
+        def get(self):
+            self.n += 1
+            return {"id": self.n}
+
+        def put(self, x):
+            ev.append(["%s_put" % self.name, list(x[0])])
+
+    class Cache:
+        def __init__(self, rb):
+            ev.append(["cache_init"])
+            self.q1, self.q2 = Q("q1"), Q("q2")
+
+        def start(self):
+            ev.append(["cache_start"])
+
+    with pytest.raises(_Stop):
+        workers.worker_train_nstep(PS(), [None], _Args(), 0, make_agent=lambda o: Agent("learner"), make_cache=Cache)
+    assert ev == ntraces["train"]["events"]
+
+
+def test_batch_cache_single_server_form_matches_reference(ntraces):
+    t = ntraces["cache"]
+    ev = []
+    Env, Agent, PS, RB = _nstep_fakes(ev, [1])
+    opt = _Args()
+    opt.num_buffers = t["args"]["num_buffers"]
+    sizes, empties = list(t["args"]["q1_sizes"]), list(t["args"]["q2_empty"])
+
+    class Q1:
+        def qsize(self):
+            if not sizes:
+                raise _Stop()
+            v = sizes.pop(0)
+            ev.append(["q1_qsize", v])
+            return v
+
+        def put(self, b):
+            ev.append(["q1_put"])
+
+    class Q2:
+        def empty(self):
+            v = empties.pop(0)
+            ev.append(["q2_empty", v])
+            return v
+
+        def get(self):
+            ev.append(["q2_get"])
+            return ["main/pi/w"], [np.zeros(1, np.float32)]
+
+    rbs = [RB("b0", [[0, 0, 0]]), RB("b1", [[0, 0, 0]])]
+    cache = workers.BatchCache(rbs, opt, [PS()], rng=_Rng(ev, t["args"]["choices"]), nodes=False)
+    assert cache.q1.maxsize == 10 and cache.q2.maxsize == 5
+    with pytest.raises(_Stop):
+        cache.ps_update(Q1(), Q2(), rbs)
+    assert ev == t["events"]
+
+
+def test_host_wrapper_branches():
+    """algos/sac1/hyperparams.py:107-134 as written: in-place action noise, summed and scaled reward over the repeat, reward 0.0 at a
+    terminal inside the repeat, raw first-step reward and un-noised observation for action_repeat == 1."""
+    from distributed_drl_amd.env import Wrapper
+
+    class E:
+        def __init__(self, end_at):
+            self.k, self.end_at = 0, end_at
+
+        def reset(self):
+            self.k = 0
+            return np.zeros(3)
+
+        def step(self, a):
+            self.k += 1
+            return np.full(3, float(self.k)), 2.0, self.k >= self.end_at, {}
+
+    rs = np.random.RandomState(0)
+    w = Wrapper(E(100), 0.0, 0.5, 5.0, 3, rng=rs)
+    a = np.zeros(2)
+    o, r, d, _ = w.step(a)
+    assert np.abs(a).max() > 0 and np.abs(a).max() <= 0.5 and r == 5.0 * 6.0 and not d and o[0] == 3.0   # the caller's array carries the noise
+    w = Wrapper(E(2), 0.0, 0.0, 5.0, 3, rng=rs)
+    o, r, d, _ = w.step(np.zeros(2))
+    assert d and r == 0.0 and o[0] == 2.0
+    w = Wrapper(E(100), 0.3, 0.0, 5.0, 1, rng=rs)
+    o, r, d, _ = w.step(np.zeros(2))
+    assert r == 2.0 and (o == 1.0).all()                                 # neither scaled nor noised
+    assert np.abs(w.reset()).max() <= 0.3 and np.abs(w.reset()).max() > 0

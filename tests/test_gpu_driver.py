@@ -730,3 +730,64 @@ def test_dqn_shaped_driver_end_to_end(tmp_path, variant):
     sc = read_scalars(str(run / os.listdir(run)[0]))
     assert sorted(t for _, t, _ in sc) == ["Reward", "a_l_ratio", "score", "update_frequency"]
     assert [v for _, t, v in sc if t == "Reward"][0] == pytest.approx(ret) and {st for st, _, _ in sc} == {sum(b.get_counts()[0] for b in bufs)}
+
+
+def test_reference_style_nstep_rollout_stores_the_deque_windows():
+    """worker_rollout_nstep (algos/sac1/sac_ray.py:178-274) with the real Actor, parameter server, host lander behind the host
+    `Wrapper`, and a real n-step ring: every window in the ring is what the worker's two deques held at that store — rebuilt here
+    from a recording of the env's steps — and the counters advance as the reference's (num_buffers per store)."""
+    from collections import deque
+    import distributed_drl_amd as d
+    from distributed_drl_amd import workers
+    from distributed_drl_amd.agent import Actor, HyperParameters
+    from distributed_drl_amd.env import LunarLander, Wrapper
+    opt = HyperParameters()
+    opt.seed, opt.Ln, opt.max_ep_len, opt.action_repeat, opt.save_freq, opt.start_steps = 3, 4, 30, 2, 1, 12
+    opt.buffer_size, opt.batch_size, opt.num_buffers, opt.weights_file = 400, 8, 1, ""
+    opt.obs_noise, opt.act_noise, opt.reward_scale = 0.01, 0.2, 5
+    rb = d.ReplayBufferNStep(opt)
+    ps = d.ParameterServer(*Actor(opt, job="worker").get_weights())
+    log = []
+
+    class Rec:
+        """The wrapped env as the worker sees it, with every reset / step recorded."""
+
+        def __init__(self):
+            self._w = Wrapper(LunarLander(seed=5, max_ep_len=1000), opt.obs_noise, opt.act_noise, opt.reward_scale, 3, rng=np.random.RandomState(1))
+            self.action_space = self._w.action_space
+            self.n = 0
+
+        def reset(self):
+            o = self._w.reset()
+            log.append(("reset", o.copy()))
+            return o
+
+        def step(self, a):
+            o2, r, dd, info = self._w.step(a)
+            log.append(("step", np.array(a, np.float32).copy(), float(r), bool(dd), o2.copy()))   # `a` AFTER the in-place noise: what is queued
+            self.n += 1
+            if self.n >= 90:
+                opt.stop_event.set()
+            return o2, r, dd, info
+
+    import threading
+    opt.stop_event = threading.Event()
+    workers.worker_rollout_nstep(ps, [rb], opt, 0, make_env=Rec)
+    # ---- the reference's loop over the recording
+    oq, aq, want, tq, ep_len = deque([], maxlen=opt.Ln + 1), deque([], maxlen=opt.Ln), [], 1, 0
+    for e in log:
+        if e[0] == "reset":
+            oq.append(e[1]); tq, ep_len = 1, 0
+            continue
+        _, a, r, dd, o2 = e
+        aq.append((a, r, dd)); oq.append(o2)
+        if tq >= opt.Ln and tq % opt.save_freq == 0:
+            want.append((np.stack(list(oq)), np.stack([x[0] for x in aq]), np.array([x[1] for x in aq]), np.array([x[2] for x in aq], np.float32)))
+        tq += 1
+        ep_len += 1
+    assert len(want) > 40 and sum(1 for e in log if e[0] == "reset") >= 3
+    rings = rb.rings()
+    for k, j in (("buffer_o", 0), ("buffer_a", 1), ("buffer_r", 2), ("buffer_d", 3)):
+        got = rings[k][:len(want)].cpu().numpy()
+        np.testing.assert_array_equal(got, np.stack([w[j] for w in want]).astype(np.float32).reshape(got.shape), err_msg=k)
+    assert rb.get_counts() == (0, len(want) * opt.num_buffers, len(want))
