@@ -13,6 +13,15 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 opt = HyperParameters()
 opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = 4096, 5, 1000, 0
 opt.lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-4
+if len(sys.argv) > 3:
+    opt.alpha = float(sys.argv[3])
+if len(sys.argv) > 4:
+    opt.gamma = float(sys.argv[4])
+if len(sys.argv) > 5:
+    opt.num_envs = int(sys.argv[5])
+if len(sys.argv) > 6:
+    opt.start_steps = int(sys.argv[6])
+print("lr %g alpha %g gamma %g envs %d start_steps %d" % (opt.lr, opt.alpha, opt.gamma, opt.num_envs, opt.start_steps), flush=True)
 rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 10 ** 6, seed=0)
 ps = d.ParameterServer(*Learner(opt).get_weights())
 ro = d.RolloutDevice(ps, rb, opt)
@@ -23,7 +32,7 @@ win = 0
 while time.time() - t0 < seconds:
     loop.run(10)
     torch.cuda.synchronize()
-    if time.time() - t0 > (win + 1) * seconds / 8:
+    if time.time() - t0 > (win + 1) * seconds / 12:
         win += 1
         ep, ret, ln = ro.env.stats()
         print("t=%5.1fs  env-steps %9d  updates %8d  episodes %6d  mean return %9.2f  mean len %6.1f" %
