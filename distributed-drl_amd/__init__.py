@@ -29,7 +29,7 @@ def __getattr__(name):
         "worker_rollout_sac1": "workers", "worker_train_sac1": "workers", "worker_test_sac1": "workers",
         "worker_rollout_dqn": "workers", "worker_train_dqn": "workers", "worker_test_dqn": "workers", "BatchCache": "workers", "get_al_status": "workers",
         "worker_rollout_nstep": "workers", "worker_train_nstep": "workers",
-        "RolloutDevice": "workers", "TrainDevice": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers", "ActorLearnerLoop": "workers",
+        "RolloutDevice": "workers", "TrainDevice": "workers", "TrainDeviceDQN": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers", "ActorLearnerLoop": "workers",
     }
     if name in table:
         return getattr(importlib.import_module("." + table[name], __name__), name)

@@ -805,6 +805,39 @@ class TrainDevice:
         self.run(1)
 
 
+class TrainDeviceDQN:
+    """Device-resident form of algos/dqn/train.py:213-231 + its Cache (177-210): every update draws from a random buffer of a random
+    node (`np.random.choice`, the Cache's draw) — `agent.train_from(buffer)`: the indices come from that buffer's own sampler, the
+    layer-1 forward reads the rows where they lie (ddrl_dqn_step_ring) — and the weights go to EVERY node's parameter server after each
+    push_freq-th update.  No helper thread: with the buffers in the learner's HBM there is no sample latency left to hide.
+    `node_buffer[node][buffer]` and `node_ps[node]` are plain (same-process) objects."""
+
+    def __init__(self, node_ps, node_buffer, opt, learner_index=0, make_agent=None, rng=None):
+        import numpy as np
+        if make_agent is None:
+            from .dqn import Learner
+            make_agent = lambda o_: Learner(o_, job="learner")
+        self.node_ps, self.node_buffer, self.opt = node_ps, node_buffer, opt
+        self.agent = make_agent(opt)
+        self.keys = self.agent.get_weights()[0]
+        self.agent.set_weights(self.keys, node_ps[0].pull(self.keys))
+        self.rng = np.random if rng is None else rng
+        self.cnt = 1
+
+    def run(self, n_updates):
+        opt = self.opt
+        for _ in range(int(n_updates)):
+            node_idx = self.rng.choice(opt.num_nodes, 1)[0]
+            buffer_idx = self.rng.choice(opt.num_buffers, 1)[0]
+            self.agent.train_from(self.node_buffer[node_idx][buffer_idx], self.cnt)
+            if self.cnt % opt.push_freq == 0:
+                keys, values = self.agent.get_weights()
+                for ps in self.node_ps:
+                    ps.push(keys, values)
+            self.cnt += 1
+        return self.cnt - 1
+
+
 class ActorLearnerLoop:
     """The actor/learner ratio gate of algos/sac1/sac1.py:203-207 (`while steps / sample_times > a_l_ratio:
     sleep`) and the `Cache` prefetch of sac1.py:103-130 for the device-resident workers.  The reference

@@ -717,6 +717,23 @@ def test_dqn_shaped_driver_end_to_end(tmp_path, variant):
     n = workers.worker_train_dqn(ps, node_buffer, opt, 0, node_ps=[ps], make_agent=lambda o: L(o, "learner"))
     assert n == 25 and ps.learner_step == 25 and np.abs(ps.get_weights()[keys[0]] - v0).max() > 0
     assert sum(b.get_counts()[0] for b in bufs) >= 25                   # sample_batch counts as the reference's learner_steps
+    # ---- the device-resident learner (no Cache): the same schedule of buffers as the Cache's draws, every update out of that buffer's sampler
+    class Rng:
+        def __init__(self):
+            self.rs, self.picks = np.random.RandomState(4), []
+
+        def choice(self, n, k):
+            v = self.rs.choice(n, k)
+            self.picks.append(int(v[0]))
+            return v
+    before = [b.get_counts()[0] for b in bufs]
+    rng = Rng()
+    td = workers.TrainDeviceDQN([ps], node_buffer, opt, make_agent=lambda o: L(o, "learner"), rng=rng)
+    step0 = ps.learner_step
+    assert td.run(10) == 10 and ps.learner_step == step0 + 10
+    drawn = [b.get_counts()[0] - x for b, x in zip(bufs, before)]
+    assert drawn == [rng.picks[1::2].count(0), rng.picks[1::2].count(1)] and sum(drawn) == 10
+    np.testing.assert_array_equal(ps.get_weights()[keys[0]], td.agent.get_weights()[1][0])    # the push after update 10 is what the server holds
     # ---- tester: one round
     ret = workers.worker_test_dqn(ps, node_buffer, opt, node_ps=[ps], make_env=lambda: Env(9), make_agent=lambda o: A(o, "test"), log=lambda s: None,
                                   wait=lambda ops, num_returns: None, max_rounds=1)
