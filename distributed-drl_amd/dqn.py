@@ -12,6 +12,38 @@ import torch
 from . import _lib
 
 
+class HyperParameters:
+    """Value bag of algos/dqn/hyperparams.py:10-75 (algos/sqn/hyperparams.py adds `alpha`): what the DQN / SQN driver, buffers, server and
+    agents read.  `env` (anything with observation_space.shape and action_space.n) or explicit obs_dim / act_dim."""
+
+    def __init__(self, env=None, env_name="Trading", exp_name="ddqn-trading", num_nodes=1, num_workers=6, a_l_ratio=10, weights_file="",
+                 obs_dim=None, act_dim=None):
+        import datetime
+        import os
+        self.exp_name, self.env_name, self.model = exp_name, env_name, "mlp"
+        self.num_nodes, self.num_workers, self.num_learners = num_nodes, num_workers, 1
+        self.push_freq = 100
+        self.gamma = 0.99
+        self.alpha = 0.1                  # sqn: the softmax policy's temperature (must be > 0)
+        self.a_l_ratio, self.weights_file = a_l_ratio, weights_file
+        self.recover = False
+        self.checkpoint_freq = 21600      # seconds (6 h)
+        self.hidden_size = [400, 300]
+        self.obs_dim = int(env.observation_space.shape[0] if obs_dim is None else obs_dim)
+        self.act_dim = int(env.action_space.n if act_dim is None else act_dim)
+        self.obs_shape, self.act_shape = (self.obs_dim,), ()
+        self.num_buffers = self.num_workers // 25 + 1
+        self.buffer_size = int(1e6) // self.num_buffers
+        self.start_steps = int(1e4) // self.num_buffers
+        if self.weights_file:
+            self.start_steps = self.buffer_size
+        self.lr, self.polyak, self.batch_size = 1e-3, 0.995, 128
+        self.Ln, self.save_freq, self.seed = 1, 1, 0
+        root = os.getcwd()                # (the reference: the directory above its own source file)
+        self.summary_dir, self.save_dir, self.save_interval = root + "/tboard_ray", root + "/" + exp_name, int(5e5)
+        self.log_dir = "%s/%s-workers_num:%s%%%s%s-%s" % (self.summary_dir, datetime.datetime.now(), num_workers, a_l_ratio, env_name, exp_name)
+
+
 def param_specs(obs_dim, n_actions, hidden_size, nets=("q1",)):
     """(name, shape) in TF variable-creation order: tf.make_template('q1', vf_mlp) [, 'q2'] under scope 'main'."""
     h1, h2 = hidden_size

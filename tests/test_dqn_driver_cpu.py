@@ -472,3 +472,20 @@ def test_host_wrapper_branches():
     o, r, d, _ = w.step(np.zeros(2))
     assert r == 2.0 and (o == 1.0).all()                                 # neither scaled nor noised
     assert np.abs(w.reset()).max() <= 0.3 and np.abs(w.reset()).max() > 0
+
+
+def test_dqn_hyperparameters_mirror_the_reference_defaults():
+    """algos/dqn/hyperparams.py:10-75: the derived entries (buffers per 25 workers, buffer_size and start_steps split over them,
+    start_steps = buffer_size when weights are loaded)."""
+    from distributed_drl_amd.dqn import HyperParameters
+
+    class Env:
+        class observation_space:
+            shape = (38,)
+
+        class action_space:
+            n = 3
+    o = HyperParameters(Env, num_workers=60)
+    assert (o.obs_dim, o.act_dim, o.num_buffers, o.buffer_size, o.start_steps) == (38, 3, 3, 333333, 3333)
+    assert (o.push_freq, o.gamma, o.lr, o.polyak, o.batch_size, o.hidden_size, o.checkpoint_freq, o.save_interval) == (100, 0.99, 1e-3, 0.995, 128, [400, 300], 21600, 500000)
+    assert HyperParameters(Env, weights_file="w.pickle").start_steps == 1000000 and HyperParameters(obs_dim=84 * 84 * 4, act_dim=4).obs_dim == 28224
