@@ -196,6 +196,11 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) k_sample(RingState *st, RingPt
     sample_block(st, ring, out, B, idx_out, fuse_gather);
 }
 
+// large draws that are gathered by a launch of their own: the 640-thread form of the sampler (>= 624: a whole state block per pass)
+__global__ void __launch_bounds__(640) k_sample_wide(RingState *st, RingPtrs ring, BatchPtrs out, int B, long long *idx_out) {
+    sample_block<640>(st, ring, out, B, idx_out, 0);
+}
+
 // Stand-alone gather for large rows (the dqn pixel shape: 2 x 112 896 B per index): one
 // workgroup per (row, array) so that >= B * n_arr workgroups fill the chip; each lane keeps four
 // independent 16-B loads in flight (HBM-bound random-row gather).
@@ -554,7 +559,8 @@ int ddrl_replay_sample_ex(ddrl_replay_t *h, int64_t batch, float *const *out_h, 
         }
         idx = h->idx_buf;
     }
-    k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, out, (int)batch, idx, fuse);
+    if (!fuse && batch >= 2048) k_sample_wide<<<1, 640, 0, s>>>(h->state, h->ring, out, (int)batch, idx);
+    else k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, out, (int)batch, idx, fuse);
     DDRL_LAUNCH_CHECK();
     h->h_samples += h->ring.samples_inc;
     if (!fuse) return launch_gather(h, idx, batch, out, s);
@@ -576,7 +582,8 @@ int ddrl_replay_sample_indices(ddrl_replay_t *h, int64_t batch, int64_t *idx_d, 
         }
     }
     BatchPtrs none{};
-    k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, none, (int)batch, reinterpret_cast<long long *>(idx_d), 0);
+    if (batch >= 2048) k_sample_wide<<<1, 640, 0, s>>>(h->state, h->ring, none, (int)batch, reinterpret_cast<long long *>(idx_d));
+    else k_sample<<<1, SAMPLE_THREADS, 0, s>>>(h->state, h->ring, none, (int)batch, reinterpret_cast<long long *>(idx_d), 0);
     DDRL_LAUNCH_CHECK();
     h->h_samples += h->ring.samples_inc;
     return DDRL_OK;

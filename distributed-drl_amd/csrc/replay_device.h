@@ -71,25 +71,19 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t cur, uint32_t nxt, uint32_t 
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// Regenerate all 624 words in LDS.  The recurrence mt[k] <- f(mt[k], mt[k+1], mt[(k+397)%624])
-// has lag 397, so it splits into three segments whose inputs are all available in parallel:
-// [0,227) reads only old words; [227,454) reads new words of segment 1; [454,624) reads new
-// words of segment 2 (and new mt[0] for k = 623).
-__device__ __forceinline__ void mt_twist_lds(uint32_t *mt, int tid) {
-    uint32_t v = 0;
-    if (tid < MT_N - MT_M) v = mt_mix(mt[tid], mt[tid + 1], mt[tid + MT_M]);
+// Regenerate all 624 words: `mt` -> `nw` (a second LDS array: no barrier between a segment's reads and its writes).  The recurrence
+// mt[k] <- f(mt[k], mt[k+1], mt[(k+397)%624]) has lag 397, so it splits into three segments whose inputs are all available in parallel:
+// [0,227) reads only old words; [227,454) reads new words of segment 1; [454,624) reads new words of segment 2 (and new mt[0]
+// for k = 623).  Three barriers; the caller swaps the two arrays.
+__device__ __forceinline__ void mt_twist_lds(const uint32_t *mt, uint32_t *nw, int tid) {
+    constexpr int S = MT_N - MT_M;   // 227
+    if (tid < S) nw[tid] = mt_mix(mt[tid], mt[tid + 1], mt[tid + MT_M]);
     __syncthreads();
-    if (tid < MT_N - MT_M) mt[tid] = v;
+    const int k2 = S + tid;          // 227..453
+    if (tid < S) nw[k2] = mt_mix(mt[k2], mt[k2 + 1], nw[k2 - S]);
     __syncthreads();
-    const int k2 = (MT_N - MT_M) + tid;  // 227..453
-    if (tid < MT_N - MT_M) v = mt_mix(mt[k2], mt[k2 + 1], mt[k2 - (MT_N - MT_M)]);
-    __syncthreads();
-    if (tid < MT_N - MT_M) mt[k2] = v;
-    __syncthreads();
-    const int k3 = 2 * (MT_N - MT_M) + tid;  // 454..623
-    if (k3 < MT_N) v = mt_mix(mt[k3], mt[k3 == MT_N - 1 ? 0 : k3 + 1], mt[k3 - (MT_N - MT_M)]);
-    __syncthreads();
-    if (k3 < MT_N) mt[k3] = v;
+    const int k3 = 2 * S + tid;      // 454..623
+    if (k3 < MT_N) nw[k3] = mt_mix(mt[k3], k3 == MT_N - 1 ? nw[0] : mt[k3 + 1], nw[k3 - S]);
     __syncthreads();
 }
 
@@ -127,9 +121,16 @@ __device__ __forceinline__ void gather_rows(const float *__restrict__ ring, floa
 // the five gathers when the batch is small (the SAC1 shape: 256 x 80 B).  One workgroup: the
 // accept/reject compaction is a wave ballot + prefix count, the stream position advances by
 // exactly the number of words NumPy would have consumed.
+// NT = threads of the workgroup: SAMPLE_THREADS where the sampler rides in another kernel's launch and for batches that are
+// gathered in the same workgroup; 640 for large stand-alone draws (a shard owner's block of batches): a whole 624-word state
+// block per pass — one accept / compact pass and one regeneration per block instead of three passes (the pass, not the words, is
+// what a one-workgroup draw pays for: 0.60 -> 0.2 ms for 262 144 indices).
+template <int NT = SAMPLE_THREADS>
 __device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring, const BatchPtrs &out, int B,
                                              long long *idx_out, int fuse_gather) {
-    __shared__ uint32_t mt[MT_N];
+    constexpr int SAMPLE_THREADS = NT;   // (shadows the namespace constant inside this function)
+    __shared__ uint32_t mt_a[MT_N], mt_b[MT_N];
+    uint32_t *mt = mt_a, *mt_other = mt_b;   // (block-uniform pointers: the regeneration writes the other array, then they swap)
     __shared__ int s_wave_tot[SAMPLE_THREADS / 64];
     __shared__ int s_consumed;
     __shared__ unsigned s_idx[MAX_FUSED_BATCH];
@@ -185,7 +186,8 @@ __device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring
         __syncthreads();
         while (produced < B) {
             if (pos >= MT_N) {
-                mt_twist_lds(mt, tid);
+                mt_twist_lds(mt, mt_other, tid);
+                uint32_t *t = mt; mt = mt_other; mt_other = t;
                 pos = 0;
                 dirty = true;
             }
