@@ -172,6 +172,21 @@ class Learner:
                                                  _lib.stream_ptr()))
         return [float(v) for v in ms]
 
+    def _q_row(self, o):
+        """q of ONE host observation as a NumPy row: page-locked staging both ways, one stream synchronisation."""
+        st = getattr(self, "_stage_q", None)
+        if st is None:
+            hi, ho = torch.empty(1, self.cfg.obs_dim, dtype=torch.float32).pin_memory(), torch.empty(1, self.cfg.n_actions, dtype=torch.float32).pin_memory()
+            st = self._stage_q = (hi, hi.numpy(), torch.empty(1, self.cfg.obs_dim, dtype=torch.float32, device=self.device),
+                                  ho, ho.numpy(), torch.empty(1, self.cfg.n_actions, dtype=torch.float32, device=self.device))
+        hi, hiv, di, ho, hov, do = st
+        hiv[0, :] = np.asarray(o, np.float32).reshape(-1)
+        di.copy_(hi, non_blocking=True)
+        _lib.check(self._lib.ddrl_dqn_q(self._h, _lib.dptr(di), 1, _lib.dptr(do), _lib.stream_ptr()))
+        ho.copy_(do, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return hov[0]
+
     def q_values(self, obs):
         obs = self._dev(obs, (-1, self.cfg.obs_dim))
         q = torch.empty(obs.shape[0], self.cfg.n_actions, dtype=torch.float32, device=self.device)
@@ -189,7 +204,7 @@ class Actor(Learner):
 
     def get_action(self, o):
         if self._rs.uniform() < 0.97:
-            return int(np.argmax(self.q_values(np.asarray(o, np.float32)[np.newaxis, :])[0].cpu().numpy()))
+            return int(np.argmax(self._q_row(o)))
         return int(self._rs.randint(0, self.opt.act_dim))
 
     def _test_action(self, o):
@@ -241,7 +256,7 @@ class ActorSQN(LearnerSQN):
         self._rs = np.random.RandomState(getattr(opt, "seed", 0))
 
     def get_action(self, o, deterministic=False):
-        q = self.q_values(np.asarray(o, np.float32)[np.newaxis, :])[0].cpu().numpy().astype(np.float64)
+        q = self._q_row(o).astype(np.float64)
         if deterministic:
             return int(np.argmax(q))
         z = q / float(self.opt.alpha)

@@ -23,3 +23,25 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(300): lh.train(rbh.sample_batch(B))
 torch.cuda.synchronize(); t_iter = (time.perf_counter() - t0) / 300
 print("store %.1f us  sample_batch %.1f us  sample+train %.1f us" % (t_store * 1e6, t_samp * 1e6, t_iter * 1e6))
+# per-step policy calls of the reference-style rollout workers (one observation up, one action down)
+from distributed_drl_amd.agent import Actor
+from distributed_drl_amd import dqn
+act = Actor(opt, job="worker")
+o = rs.randn(8)
+for _ in range(50): act.get_action(o)
+t0 = time.perf_counter()
+for _ in range(1000): act.get_action(o)
+t_sac = (time.perf_counter() - t0) / 1000
+
+
+class O5:
+    obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed, alpha = 38, 3, [400, 300], 0.99, 1e-3, 0.995, 128, 0, 0.1
+
+
+da = dqn.Actor(O5, "worker")
+o38 = rs.randn(38)
+for _ in range(50): da.get_action(o38)
+t0 = time.perf_counter()
+for _ in range(1000): da.get_action(o38)
+t_dqn = (time.perf_counter() - t0) / 1000
+print("Actor.get_action %.1f us   dqn.Actor.get_action %.1f us" % (t_sac * 1e6, t_dqn * 1e6))
