@@ -81,7 +81,14 @@ class ParameterServer(object):
                 continue
             off, n, shape = self._table[k]
             src = self._dev(v)
-            assert src.numel() == n, "shape of %r changed" % k
+            if src.numel() != n:
+                # the reference's dict takes a value of any shape under an old key: the key leaves the flat buffer (its run stays
+                # unused) and lives with the late-comers from here on
+                del self._table[k]
+                self._extra[k] = src.clone().view(tuple(v.shape))
+                continue
+            if tuple(v.shape) != shape:
+                self._table[k] = (off, n, tuple(v.shape))
             _lib.check(self._lib.ddrl_ps_push(self._h, _lib.dptr(src), off, n, s))
 
     def push_flat(self, flat, offset=0):
@@ -115,6 +122,8 @@ class ParameterServer(object):
 
     def span(self, keys):
         """(offset, count) when `keys` occupy one contiguous run of the flat buffer, else None."""
+        if any(k not in self._table for k in keys):
+            return None
         offs = sorted(self._table[k][:2] for k in keys)
         for (o0, n0), (o1, _) in zip(offs, offs[1:]):
             if o0 + n0 != o1:

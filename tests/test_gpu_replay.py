@@ -597,3 +597,47 @@ def test_random_interleaving_of_stores_and_samples(ddrl, tmp_path, seed):
             for b in pix:
                 for k, t in b.rings().items():
                     np.testing.assert_array_equal(t.cpu().numpy(), getattr(pix_o, k), err_msg="op %d %s" % (op, k))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_parameter_server_random_walk(ddrl, seed):
+    """Seeded fuzz of the server's surface against the oracle (example/dsac.py:51-73): pushes of random key subsets in random order —
+    new keys, changed shapes, float64 / int values, the flat device path — interleaved with pulls and get_weights; values, dtypes of
+    what comes back, key order and the snapshot-by-copy rule after every operation."""
+    from oracle.replay_oracle import ParameterServerOracle
+    rs = np.random.RandomState(seed)
+    names = ["main/pi/dense/kernel", "main/pi/dense/bias", "main/q1/dense/kernel", "main/q1/dense/bias", "main/q2/dense_2/kernel"]
+    shapes = [(8, 5), (5,), (10, 5), (5,), (5, 1)]
+    vals = [rs.randn(*s).astype(np.float32) for s in shapes]
+    ps, ora = ddrl.ParameterServer(names, vals), ParameterServerOracle(names, vals)
+    known = list(names)
+    for op in range(60):
+        r = rs.rand()
+        if r < 0.45:
+            ks = [known[i] for i in rs.permutation(len(known))[:rs.randint(1, len(known) + 1)]]
+            if rs.rand() < 0.2:
+                ks.append("extra/%d" % op)
+                known.append(ks[-1])
+            new = []
+            for k in ks:
+                shape = ora.weights[k].shape if k in ora.weights and rs.rand() < 0.9 else (int(rs.randint(1, 7)),)
+                v = rs.randn(*shape)
+                new.append(v.astype(np.float32) if rs.rand() < 0.8 else v)          # float64 comes in now and then (cast like the NumPy assignment)
+            ps.push(ks, new)
+            ora.push(ks, [np.asarray(v, np.float32) for v in new])
+            for v in new:
+                v += 1.0                                                           # the caller's arrays may change afterwards: push snapshots by copy
+        elif r < 0.9:
+            ks = [known[i] for i in rs.permutation(len(known))[:rs.randint(1, len(known) + 1)]]
+            got, want = ps.pull(ks), ora.pull(ks)
+            assert len(got) == len(want)
+            for g, w, k in zip(got, want, ks):
+                assert g.dtype == np.float32 and g.shape == w.shape, k
+                np.testing.assert_array_equal(g, w, err_msg="op %d %s" % (op, k))
+            got[0][...] = -7.0                                                     # ... and pull hands out copies
+            np.testing.assert_array_equal(ps.pull(ks[:1])[0], want[0])
+        else:
+            w = ps.get_weights()
+            assert list(w.keys()) == list(ora.get_weights().keys())
+            for k in w:
+                np.testing.assert_array_equal(w[k], ora.weights[k], err_msg="op %d %s" % (op, k))
