@@ -641,3 +641,53 @@ def test_parameter_server_random_walk(ddrl, seed):
             assert list(w.keys()) == list(ora.get_weights().keys())
             for k in w:
                 np.testing.assert_array_equal(w[k], ora.weights[k], err_msg="op %d %s" % (op, k))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_nstep_ring_random_walk(ddrl, seed):
+    """Seeded fuzz of the n-step window ring (algos/sac1/sac_ray.py:34-82) against the oracle: single-window stores out of deques,
+    batched stores (wrap inside the batch, more windows than slots), masked stores (the vectorised rollout's form: rows with mask != 0,
+    in row order), sample_batch and get_counts interleaved; several buffers' worth of counter increments (num_buffers)."""
+    from oracle.replay_oracle import NStepReplayOracle
+    rs = np.random.RandomState(seed)
+
+    class Opt:
+        obs_shape, act_shape = (int(rs.choice([3, 8])),), (int(rs.choice([1, 2])),)
+        Ln, buffer_size, batch_size, num_buffers = int(rs.choice([1, 4, 8])), int(rs.choice([7, 50, 333])), int(rs.choice([1, 16, 40])), int(rs.choice([1, 3]))
+    buf, ora = ddrl.ReplayBufferNStep(Opt, seed=seed), NStepReplayOracle(Opt, seed=seed)
+    Ln, od, ad = Opt.Ln, Opt.obs_shape[0], Opt.act_shape[0]
+
+    def windows(n):
+        return (rs.randn(n, Ln + 1, od).astype(np.float32), rs.uniform(-1, 1, (n, Ln, ad)).astype(np.float32), rs.randn(n, Ln).astype(np.float32),
+                (rs.rand(n, Ln) < 0.1).astype(np.float32))
+
+    def ora_store(o, a, r, d, rows):
+        for i in rows:
+            ora.store([(o[i, k],) for k in range(Ln + 1)], [(a[i, k], r[i, k], d[i, k]) for k in range(Ln)], 0)
+
+    for op in range(60):
+        kind = rs.rand()
+        if kind < 0.2 or ora.size == 0:
+            o, a, r, d = windows(1)
+            buf.store([(o[0, k],) for k in range(Ln + 1)], [(a[0, k], r[0, k], bool(d[0, k])) for k in range(Ln)], 0)
+            ora_store(o, a, r, d, [0])
+        elif kind < 0.45:
+            n = int(rs.choice([1, 2, Opt.buffer_size - 1 if Opt.buffer_size > 1 else 1, Opt.buffer_size + 3, int(rs.randint(1, 2 * Opt.buffer_size))]))
+            o, a, r, d = windows(n)
+            buf.store_batch(*(torch.from_numpy(x).cuda() for x in (o, a, r, d)))
+            ora_store(o, a, r, d, range(n))
+        elif kind < 0.65:
+            n = int(rs.randint(1, 100))
+            o, a, r, d = windows(n)
+            mask = (rs.rand(n) < 0.4).astype(np.uint8)
+            buf.store_masked(*(torch.from_numpy(x).cuda() for x in (o, a, r, d)), torch.from_numpy(mask).cuda())
+            ora_store(o, a, r, d, np.nonzero(mask)[0])
+        else:
+            got, want = buf.sample_batch(), ora.sample_batch()
+            for k in want:
+                np.testing.assert_array_equal(got[k], want[k], err_msg="op %d %s" % (op, k))
+        assert buf.get_counts() == ora.get_counts(), op
+        if op % 10 == 9:
+            rings = buf.rings()
+            for k in ("buffer_o", "buffer_a", "buffer_r", "buffer_d"):
+                np.testing.assert_array_equal(rings[k].cpu().numpy().reshape(getattr(ora, k).shape), getattr(ora, k), err_msg="op %d %s" % (op, k))
