@@ -569,7 +569,17 @@ def test_random_interleaving_of_stores_and_samples(ddrl, tmp_path, seed):
             o, o2 = rs.randn(n, obs_dim).astype(np.float32), rs.randn(n, obs_dim).astype(np.float32)
             a, r, d = rs.uniform(-1, 1, (n, 2)).astype(np.float32), rs.randn(n).astype(np.float32), (rs.rand(n) < 0.1).astype(np.float32)
             if n == 1 and rs.rand() < 0.5:
-                sac.store(o[0], a[0], r[0], o2[0], d[0])                   # the reference's own call shape (host values)
+                # the reference's own call shape (host values) in the guises a worker hands them over: arrays, float64, lists, Python /
+                # NumPy scalars and bools — everything lands as the float32 the NumPy row assignment makes of it
+                form = rs.randint(0, 4)
+                if form == 0:
+                    sac.store(o[0], a[0], r[0], o2[0], d[0])
+                elif form == 1:
+                    sac.store(o[0].astype(np.float64), a[0].astype(np.float64), float(r[0]), o2[0].astype(np.float64), bool(d[0]))
+                elif form == 2:
+                    sac.store(o[0].tolist(), a[0].tolist(), np.float64(r[0]), tuple(o2[0].tolist()), np.bool_(d[0]))
+                else:
+                    sac.store(o[0], a[0], np.float32(r[0]), o2[0], int(d[0]))
             else:
                 sac.store_batch(*dev((o, a, r, o2, d)))
             sac_o.store_batch(o, a, r, o2, d)
