@@ -1,4 +1,5 @@
 // Discrete-action learners on the shared GEMM core: Double-DQN (algos/dqn) and soft-Q (algos/sqn).
+#include <mutex>
 #include "gemm_core.h"
 #include "wide_l1.h"
 
@@ -489,12 +490,24 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
     h->ad = AdamArgs{h->main_p, h->target_p, h->m, h->v, h->grad, h->opt, h->opt + 1, h->total_int, 0, 0,
                      (float)cfg->lr, (float)cfg->beta1, (float)cfg->beta2, (float)cfg->adam_eps,
                      (float)cfg->polyak, (float)(1.0 - cfg->polyak), nullptr, 0, 0, 0, 0, 0u};
-    DDRL_REQUIRE(head_lds_bytes(h->head) <= 150 * 1024, "hidden2 too wide for the head kernel's LDS staging");
+    // every exit below this point owns the slab and the stream-K buffers: failures go through ddrl_dqn_destroy
+    if (head_lds_bytes(h->head) > 150 * 1024) {
+        ddrl::set_error("hidden2 too wide for the head kernel's LDS staging");
+        ddrl_dqn_destroy(h);
+        return DDRL_ERR_BAD_ARG;
+    }
     {   // the attribute belongs to the function on this device, not to the handle: it only ever grows
         static size_t granted[64] = {0};
+        static std::mutex granted_mu;
+        std::lock_guard<std::mutex> lk(granted_mu);
         const size_t need = head_lds_bytes(h->head);
         if (device >= 0 && device < 64 && need > granted[device]) {
-            DDRL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (ea != hipSuccess) {
+                ddrl::set_error("hipFuncSetAttribute(k_dqn_head, %zu bytes of LDS): %s", need, hipGetErrorString(ea));
+                ddrl_dqn_destroy(h);
+                return DDRL_ERR_HIP;
+            }
             granted[device] = need;
         }
     }
@@ -628,6 +641,7 @@ int ddrl_dqn_step_ring(ddrl_dqn_t *h, ddrl_replay_t *replay, float *loss_d, floa
     DDRL_REQUIRE(h != nullptr && replay != nullptr, "NULL handle");
     const int B = h->cfg.batch, o = h->cfg.obs_dim;
     const ddrl_replay_dev::SamplerView rv = ddrl_replay_sampler_view(replay);
+    DDRL_REQUIRE(rv.device == h->device, "the replay ring lives on another device than the learner");
     if (!h->wide) {
         ddrl::set_error("ddrl_dqn_step_ring needs the wide layer-1 path (obs_dim >= 1024): use ddrl_replay_sample + ddrl_dqn_step");
         return DDRL_ERR_UNSUPPORTED;

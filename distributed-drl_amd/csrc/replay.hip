@@ -351,7 +351,7 @@ static int refresh_counts(ddrl_replay *h, hipStream_t s) {
     return DDRL_OK;
 }
 
-ddrl_replay_dev::SamplerView ddrl_replay_sampler_view(ddrl_replay_t *h) { return ddrl_replay_dev::SamplerView{h->state, h->ring}; }
+ddrl_replay_dev::SamplerView ddrl_replay_sampler_view(ddrl_replay_t *h) { return ddrl_replay_dev::SamplerView{h->state, h->ring, h->device}; }
 static long long row_floats(const ddrl_replay *h) {
     long long t = 0;
     for (int j = 0; j < h->ring.n_arr; ++j) t += h->ring.w[j];

@@ -241,6 +241,7 @@ __device__ __forceinline__ void sample_block(RingState *st, const RingPtrs &ring
 struct SamplerView {
     RingState *state;
     RingPtrs ring;
+    int device;
 };
 
 }  // namespace ddrl_replay_dev

@@ -37,6 +37,9 @@ class ParameterServer(object):
         self._capacity = 0
         self._h = None
         self._extra = {}  # keys pushed later that do not fit the flat buffer's table
+        self._extra_pushes = 0   # writes that never reach the device buffer count as versions too (RolloutDevice.pull compares versions)
+        self._retired = {}       # key -> (offset, count, shape) of the flat run it held before a push of another shape moved it to _extra
+        self.layout = 0          # bumped whenever a key enters or leaves the flat table: holders of a cached span() look again
         total = sum(int(np.asarray(v).size) if not torch.is_tensor(v) else int(v.numel()) for v in values)
         self._alloc(max(total, 1))
         off = 0
@@ -76,6 +79,7 @@ class ParameterServer(object):
             if k not in self._table:
                 # a new key: the reference just adds it to the dict
                 self._extra[k] = self._dev(v).clone().view(tuple(v.shape))
+                self._extra_pushes += 1
                 if k not in self._order:
                     self._order.append(k)
                 continue
@@ -84,8 +88,10 @@ class ParameterServer(object):
             if src.numel() != n:
                 # the reference's dict takes a value of any shape under an old key: the key leaves the flat buffer (its run stays
                 # unused) and lives with the late-comers from here on
-                del self._table[k]
+                self._retired[k] = self._table.pop(k)
                 self._extra[k] = src.clone().view(tuple(v.shape))
+                self._extra_pushes += 1
+                self.layout += 1
                 continue
             if tuple(v.shape) != shape:
                 self._table[k] = (off, n, tuple(v.shape))
@@ -96,6 +102,14 @@ class ParameterServer(object):
         flat = self._dev(flat)
         _lib.check(self._lib.ddrl_ps_push(self._h, _lib.dptr(flat), int(offset), int(flat.numel()),
                                           _lib.stream_ptr()))
+        # a key that had left the table for another shape: the flat push writes its old run, i.e. gives it a value of the old shape
+        # again — key-wise overwrite, so the run is the key's value from here on (not the stale late-comer tensor)
+        for k, (off, n, shape) in list(self._retired.items()):
+            if int(offset) <= off and off + n <= int(offset) + int(flat.numel()):
+                self._table[k] = (off, n, shape)
+                del self._retired[k]
+                self._extra.pop(k, None)
+                self.layout += 1
 
     def pull(self, keys):
         """The listed subset, in the given order, as host float32 arrays (example/dsac.py:64-65;
@@ -140,7 +154,7 @@ class ParameterServer(object):
 
     @property
     def version(self):
-        return int(self._lib.ddrl_ps_version(self._h))
+        return int(self._lib.ddrl_ps_version(self._h)) + self._extra_pushes
 
 
 class ParameterServerNode(ParameterServer):

@@ -282,8 +282,23 @@ class BatchCache:
         import threading
         self.node_buffer, self.opt, self.node_ps, self.nodes = node_buffer, opt, node_ps, nodes
         self.rng = rng
-        self.q1, self.q2 = queue.Queue(12 if nodes else 10), queue.Queue(5)
-        self._stop = threading.Event()
+        self._stop, self._wake = threading.Event(), threading.Event()
+        wake = self._wake
+
+        class _Q(queue.Queue):
+            """queue.Queue whose get / put wake the helper: the reference's helper is a PROCESS that spins on qsize() / empty()
+            (algos/dqn/train.py:195-203); a thread doing that holds the GIL against the learner, so this one sleeps until a queue moves."""
+
+            def get(self, block=True, timeout=None):
+                item = queue.Queue.get(self, block, timeout)
+                wake.set()
+                return item
+
+            def put(self, item, block=True, timeout=None):
+                queue.Queue.put(self, item, block, timeout)
+                wake.set()
+
+        self.q1, self.q2 = _Q(12 if nodes else 10), _Q(5)
         self.p1 = threading.Thread(target=self.ps_update, args=(self.q1, self.q2, self.node_buffer), daemon=True)
 
     def _one_batch(self, q1, node_buffer):
@@ -299,10 +314,16 @@ class BatchCache:
     def ps_update(self, q1, q2, node_buffer):
         self._one_batch(q1, node_buffer)
         while not self._stop.is_set():
+            self._wake.clear()
+            idle = True
             if q1.qsize() < 10:
                 self._one_batch(q1, node_buffer)
+                idle = False
             if not q2.empty():
                 self._forward(q2)
+                idle = False
+            if idle:                 # ten batches waiting, no weights to forward: sleep until the learner takes a batch or leaves weights
+                self._wake.wait(0.05)
         while not q2.empty():        # end(): the weights still waiting go out (the reference terminates its helper process: they are lost there)
             self._forward(q2)
 
@@ -316,6 +337,7 @@ class BatchCache:
 
     def end(self):
         self._stop.set()
+        self._wake.set()
         while True:                  # a helper blocked on a full q1 is let through
             try:
                 self.q1.get_nowait()
@@ -497,7 +519,9 @@ def worker_rollout_nstep(ps, replay_buffer, opt, worker_index, make_env=None, ma
         a_r_d_queue.append((a, r, d,))
         o_queue.append((o2,))
         if t_queue >= opt.Ln and t_queue % opt.save_freq == 0:
-            _remote(replay_buffer[rng.choice(opt.num_buffers, 1)[0]].store, o_queue, a_r_d_queue, worker_index)
+            # Ray pickles the arguments at .remote() time; an in-process actor handle would iterate the live deques later, while this
+            # loop keeps appending — so the call takes snapshots
+            _remote(replay_buffer[rng.choice(opt.num_buffers, 1)[0]].store, tuple(o_queue), tuple(a_r_d_queue), worker_index)
         t_queue += 1
         if d or (ep_len * opt.action_repeat >= opt.max_ep_len):
             sample_times, steps, _ = _get(_remote(replay_buffer[0].get_counts))
@@ -560,6 +584,7 @@ class RolloutDevice:
                                   max_ep_len=opt.max_ep_len)
         self.actor = Actor(opt, job="worker", max_rows=opt.num_envs, index=worker_index)
         self.span = ps.span(self.actor.keys) if ps is not None else None
+        self._layout = getattr(ps, "layout", 0)
         self.version = -1
         self.t = 0
         self.o = torch.empty_like(self.env.obs)
@@ -578,6 +603,9 @@ class RolloutDevice:
         if self.ps is None or self.ps.version == self.version:
             return False
         self.version = self.ps.version
+        layout = getattr(self.ps, "layout", 0)
+        if layout != self._layout:          # a key entered or left the server's flat table since the span was looked up
+            self.span, self._layout = self.ps.span(self.actor.keys), layout
         if self.span is not None:
             self.actor.set_weights_flat(self.ps.pull_flat(*self.span))
         else:
@@ -698,6 +726,7 @@ class RolloutDeviceNStep:
         self.limit_steps = -(-int(opt.max_ep_len) // int(opt.action_repeat))   # ep_len * action_repeat >= max_ep_len (sac_ray.py:252)
         self.actor = Actor(opt, job="worker", max_rows=n, index=worker_index) if ps is not None else None
         self.span = ps.span(self.actor.keys) if ps is not None else None
+        self._layout = getattr(ps, "layout", 0)
         self.version = -1
         self.filling_steps = 0
         self.winq = WindowQueue(n, opt.Ln, opt.obs_dim, opt.act_dim, getattr(opt, "save_freq", 1), device=self.env.device.index)

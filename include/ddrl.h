@@ -487,8 +487,9 @@ int ddrl_dqn_step(ddrl_dqn_t *h, const float *obs1_d, const float *obs2_d, const
  * the ring through the index list (the LDS-DMA loads take per-lane source addresses), and only obs1 — which the layer-1 weight gradient
  * contracts over the batch — is gathered (58 MB of config 5's 231 MB).  Results are bit-identical to ddrl_replay_sample + ddrl_dqn_step.
  * Needs the wide layer-1 path (obs_dim >= 1024) and a float32 five-array ring of this observation width on the same device; else
- * DDRL_ERR_UNSUPPORTED (use the two calls).  idx_out_d[batch] (nullable) receives the indices.  The ring rows must stay unchanged until
- * `stream` has passed the call. */
+ * DDRL_ERR_UNSUPPORTED (use the two calls; a ring on another device: DDRL_ERR_BAD_ARG).  idx_out_d[batch] (nullable) receives the
+ * indices.  The forward and the weight gradient read the ring at two different points of the call, so the ring rows must stay unchanged
+ * until `stream` has passed the call: stores into this ring must be ordered with it on `stream` (or by an event), never concurrent. */
 int ddrl_dqn_step_ring(ddrl_dqn_t *h, ddrl_replay_t *replay, float *loss_d, float *q_d, int64_t *idx_out_d, void *stream);
 /* `reps` updates (each exactly ddrl_dqn_step) with a HIP event between the launch groups on `stream`; stage_ms_h[DDRL_DQN_STAGES] receives
  * the mean milliseconds of: 0 input staging (nothing when the rows are read in place), 1 layer-1 forward of all evaluations (+ split-K

@@ -489,3 +489,81 @@ def test_dqn_hyperparameters_mirror_the_reference_defaults():
     assert (o.obs_dim, o.act_dim, o.num_buffers, o.buffer_size, o.start_steps) == (38, 3, 3, 333333, 3333)
     assert (o.push_freq, o.gamma, o.lr, o.polyak, o.batch_size, o.hidden_size, o.checkpoint_freq, o.save_interval) == (100, 0.99, 1e-3, 0.995, 128, [400, 300], 21600, 500000)
     assert HyperParameters(Env, weights_file="w.pickle").start_steps == 1000000 and HyperParameters(obs_dim=84 * 84 * 4, act_dim=4).obs_dim == 28224
+
+
+def test_nstep_rollout_through_actor_handles_stores_the_windows_of_the_call_moment():
+    """Ray pickles the arguments when .remote() is called; the in-process actor handle runs the call later, on its
+    mailbox thread, while the worker keeps appending to its deques.  Behind a SLOW store the stored windows must still be the ones a
+    synchronous run stores (plain buffer objects: the form test_worker_rollout_nstep_event_order_matches_reference pins against the
+    reference's own function), in the same order."""
+    import time as _time
+    from distributed_drl_amd import remote
+    lens, choices = [12, 9, 15], [i % 2 for i in range(64)]
+
+    def run(make_buffers, drain):
+        got = []
+
+        class Buffer:
+            def __init__(self, name, delay):
+                self.name, self.delay = name, delay
+
+            def store(self, oq, aq, wi):
+                _time.sleep(self.delay)      # the worker runs many env steps ahead of a slow mailbox
+                got.append(["store", self.name, [float(np.asarray(q[0]).ravel()[0]) for q in oq],
+                            [[float(q[0][0]), float(q[1]), bool(q[2])] for q in aq], int(wi)])
+
+            def get_counts(self):
+                return (0, 100, 100)
+
+        ev = []
+        Env, Agent, PS, RB = _nstep_fakes(ev, lens)
+        opt = _Args()
+        opt.Ln, opt.save_freq, opt.num_buffers, opt.start_steps, opt.weights_file = 3, 1, 2, 4, ""
+        opt.action_repeat, opt.max_ep_len = 1, 1000
+        bufs = make_buffers(Buffer)
+        with pytest.raises(_Stop):
+            workers.worker_rollout_nstep(PS(), bufs, opt, 5, make_env=Env, make_agent=lambda o: Agent("worker"), rng=_Rng(ev, list(choices)))
+        drain(bufs)
+        return got
+
+    want = run(lambda B: [B("b0", 0.0), B("b1", 0.0)], lambda bufs: None)
+    got = run(lambda B: [remote.remote(B).remote("b0", 0.01), remote.remote(B).remote("b1", 0.01)],
+              lambda bufs: [remote.get(h.get_counts.remote()) for h in bufs])
+    assert len(want) == sum(n - 2 for n in lens) and want[0][2] == [0.0, 0.01, 0.02, 0.03]
+    for name in ("b0", "b1"):              # per buffer in the order of the calls, with the windows of the call moment
+        assert [e for e in got if e[1] == name] == [e for e in want if e[1] == name]
+
+
+def test_batch_cache_helper_sleeps_when_idle():
+    """with ten batches waiting and no weights to forward the helper thread must not spin on the GIL."""
+    import time as _time
+    ev = []
+    Env, Agent, PS, RB = _fakes(ev, [1])
+    opt = _Args()
+    opt.num_nodes, opt.num_buffers = 1, 1
+    calls = [0]
+
+    class CountingRB:
+        def sample_batch(self):
+            calls[0] += 1
+            return {"id": calls[0]}
+
+    cache = workers.BatchCache([[CountingRB()]], opt, [PS(0)])
+    polls = [0]
+    real_qsize = cache.q1.qsize
+
+    def qsize():
+        polls[0] += 1
+        return real_qsize()
+    cache.q1.qsize = qsize
+    cache.start()
+    _time.sleep(0.5)
+    assert calls[0] == 10 and polls[0] < 60          # a spinning helper polls millions of times in half a second
+    t0 = _time.perf_counter()
+    assert cache.q1.get()["id"] == 1                 # taking a batch wakes it at once
+    for _ in range(200):
+        if calls[0] == 11:
+            break
+        _time.sleep(0.001)
+    assert calls[0] == 11 and _time.perf_counter() - t0 < 0.04
+    cache.end()

@@ -651,6 +651,38 @@ def test_parameter_server_random_walk(ddrl, seed):
             assert list(w.keys()) == list(ora.get_weights().keys())
             for k in w:
                 np.testing.assert_array_equal(w[k], ora.weights[k], err_msg="op %d %s" % (op, k))
+        if op % 7 == 6:
+            # the learner's one-copy path (TrainDevice.push): the whole vector of the ORIGINAL layout lands on the flat buffer = a push of
+            # every original key at its original shape (a key that had changed shape in between must come back with it)
+            flat = rs.randn(sum(int(np.prod(s_)) for s_ in shapes)).astype(np.float32)
+            v0 = ps.version
+            ps.push_flat(torch.from_numpy(flat).cuda())
+            assert ps.version > v0
+            off = 0
+            for k, s_ in zip(names, shapes):
+                n = int(np.prod(s_))
+                cur = ora.weights[k].shape                     # a same-size reshape pushed earlier keeps its shape on both sides
+                ora.push([k], [flat[off:off + n].reshape(cur if int(np.prod(cur)) == n else s_)])
+                off += n
+            assert ps.span(names) == (0, flat.size)
+
+
+def test_parameter_server_versions_cover_late_keys_and_reshaped_keys(ddrl):
+    """a push that only touches late-comer keys / keys whose shape changed is still a new version (RolloutDevice.pull looks at
+    the version), a reshaped key leaves the contiguous span (layout bump) and comes back with the learner's next flat push."""
+    names, shapes = ["main/pi/dense/kernel", "main/pi/dense/bias"], [(8, 5), (5,)]
+    ps = ddrl.ParameterServer(names, [np.ones(s, np.float32) for s in shapes])
+    v, lay = ps.version, ps.layout
+    ps.push(["late/key"], [np.arange(3, dtype=np.float32)])
+    assert ps.version == v + 1 and ps.layout == lay
+    ps.push(["main/pi/dense/bias"], [np.arange(7, dtype=np.float32)])          # another shape under an old key
+    assert ps.version == v + 2 and ps.layout == lay + 1 and ps.span(names) is None
+    np.testing.assert_array_equal(ps.pull(["main/pi/dense/bias"])[0], np.arange(7, dtype=np.float32))
+    flat = np.arange(45, dtype=np.float32)
+    ps.push_flat(torch.from_numpy(flat).cuda())
+    assert ps.span(names) == (0, 45) and ps.layout == lay + 2
+    np.testing.assert_array_equal(ps.pull(["main/pi/dense/bias"])[0], flat[40:])
+    assert list(ps.get_weights().keys()) == names + ["late/key"]
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
