@@ -11,26 +11,8 @@ Package contents (only what the path needs):
   remote        the slice of Ray's API the drivers use (remote/get/wait)
   comm          torch.distributed (RCCL) plumbing for ps.push/pull and replay shards
 """
-__version__ = "0.1.0"
-
+from ._exports import __version__, make_getattr  # noqa: F401
 from . import _lib  # noqa: F401
 from . import remote  # noqa: F401
 
-
-def __getattr__(name):
-    # heavy submodules import torch; load them on first use
-    import importlib
-    table = {
-        "ReplayBuffer": "replay", "ReplayBufferSAC1": "replay", "ReplayBufferDQN": "replay", "ReplayBufferNStep": "replay",
-        "ParameterServer": "ps", "ParameterServerNode": "ps",
-        "Learner": "agent", "Actor": "agent", "Model": "agent", "HyperParameters": "agent",
-        "VecLunarLander": "env",
-        "worker_rollout": "workers", "worker_train": "workers", "worker_test": "workers",
-        "worker_rollout_sac1": "workers", "worker_train_sac1": "workers", "worker_test_sac1": "workers",
-        "worker_rollout_dqn": "workers", "worker_train_dqn": "workers", "worker_test_dqn": "workers", "BatchCache": "workers", "get_al_status": "workers",
-        "worker_rollout_nstep": "workers", "worker_train_nstep": "workers",
-        "RolloutDevice": "workers", "TrainDevice": "workers", "TrainDeviceDQN": "workers", "RolloutDeviceNStep": "workers", "WindowQueue": "workers", "ActorLearnerLoop": "workers",
-    }
-    if name in table:
-        return getattr(importlib.import_module("." + table[name], __name__), name)
-    raise AttributeError(name)
+__getattr__ = make_getattr(__name__)

@@ -745,6 +745,10 @@ struct ddrl_sac1 {
     DFHead fh_a[2], fh_b[2];
     DFArgs f_a[2], f_b[2];
     DGJobs dg_bq[2], dg_mid, dg_pi;
+    // cross-update deferral (the learner's graph loop only, ddrl_sac1_internal_defer): launch "mid" without the Q layer-2 / head wgrads
+    // (dg_mid_nd) and those tiles riding in the NEXT update's phase-0 launch (k_f0x) or in a flush launch of their own (dg_qw)
+    DGJobs dg_mid_nd, dg_qw;
+    bool defer_ok, defer_on, qw_pending;
     // direct-path activations (x4 images, see sac1_direct.h) and the dgrad images of the main layer-2 kernels
     int Lp1, Lp2;
     float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq, *w3snap, *xp_r4;
@@ -1351,6 +1355,15 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 dg_add(M, j);
             }
             for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
+            // the same launch split for the deferred form: jobs 0, 1 stay (dg_mid_nd), jobs 2..5 — nothing reads the Q layer-2 / head
+            // kernels, their optimizer state or their dgrad images before phase 1 of the NEXT update — move (dg_qw)
+            DGJobs &N = h->dg_mid_nd, &W = h->dg_qw;
+            N = DGJobs{}; N.B = B; N.Bv = Bv; N.ad = ctx;
+            W = DGJobs{}; W.B = B; W.Bv = Bv; W.ad = ctx;
+            for (int i = 0; i < M.njobs; ++i) dg_add(i < 2 ? N : W, M.job[i]);
+            const int nfwd0 = 3 * (B / 32) * nt2;
+            h->defer_ok = cfg->variant == DDRL_SAC1 && M.njobs == 6 && W.njobs == 4 && W.total_tiles < 0xffff && nfwd0 % 8 == 0 && B <= 320 &&
+                          h->f_a[0].njobs == 3;   // (phase 0 = the three policy evaluations: nothing in it reads a Q network)
         }
         {   // ---- backward launch 3: the wgrads that need launch 2's outputs — policy layer 2 / heads / layer 1, Q layer 1 —, loss means,
             // optimizer bookkeeping.  No hand-off inside the launch any more: every tile is a plain GEMM tile with its Adam epilogue.
@@ -1398,6 +1411,8 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                      h->fused_l1_wgrad ? (B + 31) / 32 : 0, 0u};
     h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
     h->fuse_apply = false; h->sample_armed = false;
+    h->defer_on = false; h->qw_pending = false;
+    if (!h->fused) h->defer_ok = false;
     *out = h;
     return DDRL_OK;
 }
@@ -1558,7 +1573,18 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
     if (h->fused) {
         switch (stage) {
-            case 2: h->f_a[st].opt = h->opt + h->opt_cur; launch_dfwd<0>(h->fh_a[st], h->f_a[st], s); break;
+            case 2:
+                h->f_a[st].opt = h->opt + h->opt_cur;
+                if (h->qw_pending) {   // the previous update's deferred Q wgrad + Adam + polyak tiles ride here, on ITS optimizer state
+                    DGJobs &W = h->dg_qw;
+                    W.ad.on = 1;
+                    W.ad.opt = h->opt + (h->opt_cur ^ 1);
+                    launch_f0x(h->fh_a[st], h->f_a[st], W, s);
+                    h->qw_pending = false;
+                } else {
+                    launch_dfwd<0>(h->fh_a[st], h->f_a[st], s);
+                }
+                break;
             case 5: {
                 DFArgs &F = h->f_b[st];
                 F.do_sample = h->sample_armed ? 1 : 0;
@@ -1572,7 +1598,9 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
             }
             case 7: launch_dg(h->dg_bq[st], s, 2); break;
             case 8: {
-                DGJobs &J = h->dg_mid;
+                const bool defer = h->defer_on && h->defer_ok && h->fuse_apply;
+                DGJobs &J = defer ? h->dg_mid_nd : h->dg_mid;
+                if (defer) h->qw_pending = true;
                 J.ad.on = h->fuse_apply ? 1 : 0;
                 J.ad.opt = h->opt + h->opt_cur;
                 J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image of the policy's layer-2 kernel ...
@@ -1785,6 +1813,28 @@ int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, con
 }  // extern "C"
 
 __global__ void k_opt_copy(const OptState *src, OptState *dst) { *dst = *src; }
+
+// Internal (loop.hip).  defer(1): from the next step on, launch "mid" leaves the Q layer-2 / head wgrads (+ Adam + polyak) to the
+// following step's phase-0 launch; flush(): the tiles still pending run as a launch of their own (before anything else may look at the
+// parameters); defer(0) requires a flushed learner.  Same arithmetic per element in the same order: results are bit-identical.
+int ddrl_sac1_internal_defer(ddrl_sac1 *h, int on) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(on || !h->qw_pending, "deferred optimizer tiles pending: flush first");
+    h->defer_on = on != 0;
+    return (h->defer_on && !h->defer_ok) ? 1 : DDRL_OK;   // 1: accepted, but this learner's shape / variant never defers
+}
+int ddrl_sac1_internal_flush(ddrl_sac1 *h, void *stream) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    if (!h->qw_pending) return DDRL_OK;
+    ddrl::DeviceGuard g(h->device);
+    DGJobs &W = h->dg_qw;
+    W.ad.on = 1;
+    W.ad.opt = h->opt + (h->opt_cur ^ 1);
+    launch_dg(W, ddrl::as_stream(stream), 3);
+    DDRL_LAUNCH_CHECK();
+    h->qw_pending = false;
+    return DDRL_OK;
+}
 
 // Internal (loop.hip): make copy 0 of the double-buffered optimizer state the current one, so that a
 // captured graph starts and ends on the same copy whatever the number of updates it holds.

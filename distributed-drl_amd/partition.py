@@ -306,6 +306,9 @@ class PartitionedRun:
             r.wait()
         self.stats["local_batches"] += owners.count(me)
         self.stats["remote_batches"] += n - owners.count(me)
+        by = self.stats.setdefault("remote_by_owner", {})
+        for o in remote:
+            by[o] = by.get(o, 0) + count[o]
         self.last_plan = plan
 
     def _capture_dp(self):

@@ -1,0 +1,61 @@
+"""Long-horizon agreement of the HIP SAC1 learner with the CPU oracles: N sequential updates on one seeded batch
+stream, the float32 AND the float64 oracle (oracle/sac1_oracle.py: torch CPU, autograd, TF1-Adam) stepped beside the HIP learner.
+
+The float32 oracle is an independent float32 implementation of the same update, so its own separation from the float64 trajectory is the
+yardstick: rounding differences feed back through Adam and the targets, two float32 trajectories drift apart like a random walk, and a
+systematic error (a beta^t product, a polyak image, a stale operand) would make the HIP learner leave the float64 oracle FASTER than the
+float32 oracle does.  Used by tests/test_gpu_sac1.py and tools/long_horizon.py."""
+import numpy as np
+import torch
+
+from oracle import sac1_oracle as so
+
+LOSSES = ("pi_loss", "q1_loss", "q2_loss")
+
+
+def run(learner, cfg, params, n_updates, seed0=5000, checkpoints=(1, 10, 100, 500, 1000, 1500, 2000)):
+    from distributed_drl_amd import _lib
+    learner.set_weights(list(params.keys()), list(params.values()))
+    o32, o64 = so.Sac1Oracle(cfg, params, torch.float32), so.Sac1Oracle(cfg, params, torch.float64)
+    rel_hip, rel_32 = np.zeros((n_updates, 3)), np.zeros((n_updates, 3))   # signed relative deviation from the float64 oracle
+    curve = np.zeros((n_updates, 3))
+    table = []
+    for it in range(n_updates):
+        batch, eps = so.synthetic_batch(cfg, seed=seed0 + it)
+        w32, w64 = o32.step(batch, *eps), o64.step(batch, *eps)
+        got = learner.train(batch, eps=eps, return_outputs=True)[0].cpu().numpy()
+        for i, k in enumerate(LOSSES):
+            ref = float(w64[k])
+            curve[it, i] = ref
+            rel_hip[it, i] = (float(got[i]) - ref) / abs(ref)
+            rel_32[it, i] = (float(w32[k]) - ref) / abs(ref)
+        if it + 1 in checkpoints:
+            row = {"update": it + 1}
+            for which, name in ((_lib.SAC1_MAIN, "main"), (_lib.SAC1_TARGET, "target"), (_lib.SAC1_ADAM_M, "m"), (_lib.SAC1_ADAM_V, "v")):
+                ref = o64.flat(name)
+                a, b = learner.export(which).cpu().numpy().astype(np.float64), o32.flat(name).astype(np.float64)
+                scale = np.abs(ref).max()
+                row[name] = (float(np.abs(a - ref).max() / scale), float(np.abs(b - ref).max() / scale),   # max deviation / max |value|
+                             float(np.sqrt(np.mean((a - ref) ** 2)) / scale), float(np.sqrt(np.mean((b - ref) ** 2)) / scale),
+                             float(np.mean(a - ref) / scale), float(np.mean(b - ref) / scale))             # signed mean: a bias shows here
+            table.append(row)
+    return {"rel_hip": rel_hip, "rel_32": rel_32, "curve": curve, "table": table}
+
+
+def report(res, out=print):
+    rh, r32, cv = res["rel_hip"], res["rel_32"], res["curve"]
+    n = rh.shape[0]
+    out("losses vs the float64 oracle, |relative deviation| per window of updates (median / max):  HIP | float32 oracle")
+    w = max(1, n // 10)
+    for s in range(0, n, w):
+        e = min(n, s + w)
+        line = "  updates %5d-%5d  losses(f64) %8.4f %8.4f %8.4f " % (s + 1, e, *cv[s:e].mean(0))
+        for i, k in enumerate(LOSSES):
+            line += " %s %.1e/%.1e | %.1e/%.1e " % (k[:2], np.median(np.abs(rh[s:e, i])), np.abs(rh[s:e, i]).max(),
+                                                    np.median(np.abs(r32[s:e, i])), np.abs(r32[s:e, i]).max())
+        out(line)
+    out("signed mean of the relative deviation over all updates:  HIP %s | float32 oracle %s" %
+        (["%.2e" % v for v in rh.mean(0)], ["%.2e" % v for v in r32.mean(0)]))
+    out("parameters vs the float64 oracle, relative to max |value|: max dev HIP / f32 oracle, rms HIP / f32 oracle, signed mean HIP / f32 oracle")
+    for row in res["table"]:
+        out("  update %5d  " % row["update"] + "  ".join("%s %.1e/%.1e %.1e/%.1e %+.1e/%+.1e" % ((k,) + row[k]) for k in ("main", "target", "m", "v")))

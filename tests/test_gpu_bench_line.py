@@ -1,6 +1,7 @@
 """bench.py's contract, checked on the GPU box: the one JSON line of a short single-GPU run (metric string, roofline and config
-blocks, both gate figures, a fresh traffic file) and of a functional 2-rank run on the one GPU at config 3's real sizes (4096 envs per
-rank, batch 256, 500 k-transition shards) — which must say that it is not a scaling point."""
+blocks, both gate figures, the three series of the N-GPU readout, a fresh traffic file), of a functional 2-rank run on the one GPU at
+config 3's real sizes (4096 envs per rank, batch 256, 500 k-transition shards) and of a functional 8-rank run at config 4's real sizes
+(2 learner ranks + 6 rollout ranks x 8192 envs, 10^6 transitions over 6 shards) — which must say that they are not scaling points."""
 import json
 import os
 import subprocess
@@ -40,7 +41,13 @@ def test_single_gpu_line():
     # profiles/traffic.json was taken on THESE kernels (tools/prof_round.sh + tools/make_traffic.py after any change under csrc/)
     assert r["traffic"] and r["traffic_stale"] is False, "csrc/ changed since the PMC passes behind profiles/traffic.json: re-run tools/prof_round.sh"
     c = j["config"]
-    assert "workload" in c and "model" not in c and c["weak_scaling_read_against"] == "value_ungated" and c["distinct_devices"] == 1
+    assert "workload" in c and "model" not in c and c["weak_scaling_read_against"].startswith("series.rollout_capacity") and c["distinct_devices"] == 1
+    # the three series of the N-GPU readout, at N = 1: one optimizer step per batch, the rollout rank alone far above the gated rate
+    se = j["series"]
+    assert se["learner_ranks"] == se["rollout_ranks"] == 1 and se["functional_only"] is False
+    assert abs(j["optimizer_steps_per_s"] - j["updates_per_s"]) < 1e-9 * j["updates_per_s"]
+    assert 0.9 * j["updates_per_s"] < se["learner_group_optimizer_steps_per_s"] < 1.2 * j["updates_per_s"]
+    assert se["rollout_capacity_env_steps_per_s"] > 100 * j["value"] and se["gated_env_steps_per_s"] == j["value"]
     assert c["rank_devices"][0]["rank"] == 0 and c["rank_devices"][0]["uuid"]
 
 
@@ -57,3 +64,32 @@ def test_two_ranks_on_one_gpu_is_functional_only():
     tot = ps["local_batches"] + ps["remote_batches"]
     assert tot > 0 and 0.4 < ps["remote_batches"] / tot < 0.6 and ps["pushes"] >= 1
     assert j["scaling_readout"]["roles"] == ["learner+rollout", "rollout"]
+
+
+def test_eight_ranks_on_one_gpu_config4_sizes_is_functional_only():
+    """BASELINE config 4 as stated (algos/sac1/sac_ray.py:137-141,246,316-324; example/dsac.py:229-233): `bench.py --gpus 8` puts 2
+    data-parallel learner ranks and 6 rollout ranks x 8192 envs with a 166 666-transition shard each on the one GPU over gloo.  Roles,
+    the updates the gate owes per step under both settings, where the batches came from, pushes, and learner 0 == learner 1 bit for bit."""
+    j = run_bench("--gpus", "8", "--steps", "1", "--warmup", "0", "--gpu-seconds", "0", "--no-stages", "--no-cpu-baseline", timeout=1500)
+    assert j["n_gpus"] == 8 and j["functional_only"] is True and j["value"] == 0.0 and "value_ungated" not in j
+    c = j["config"]
+    assert c["backend"] == "gloo" and c["world_size"] == 8 and c["distinct_devices"] == 1 and len(c["rank_devices"]) == 8
+    assert c["num_envs"] == 8192 and c["batch"] == 256 and c["replay_capacity"] == 10 ** 6
+    assert c["learner_ranks"] == [0, 1] and c["rollout_ranks"] == [2, 3, 4, 5, 6, 7]
+    assert j["scaling_readout"]["roles"] == ["learner"] * 2 + ["rollout"] * 6
+    # hold: 6 x 8192 env steps / a_l_ratio 2 = 24 576 batches per step, shared by the two learners; free: config 2's 2048 per learner rank
+    assert c["gate"] == "hold" and c["updates_per_step"] == 12288 and c["env_steps_per_sample"] == 2.0
+    assert j["other_gate"]["gate"] == "free" and j["other_gate"]["updates_per_step"] == 2048
+    f = j["functional_value"]
+    assert f["value"] > 0 and f["updates_per_s"] > 0 and "NOT an N-GPU measurement" in f["note"]
+    # one optimizer step of the learner GROUP consumes two batches
+    assert abs(j["series"]["learner_group_batches_per_s"] / j["series"]["learner_group_optimizer_steps_per_s"] - 2.0) < 1e-9
+    ps = j["partition_stats"]                          # rank 0's: a dedicated learner owns no shard, every batch is remote ...
+    assert ps["local_batches"] == 0 and ps["remote_batches"] >= 12288 + 2048 and ps["pushes"] >= 1 + (12288 + 2048) // 300
+    by = {int(k): v for k, v in ps["remote_by_owner"].items()}
+    assert sorted(by) == [2, 3, 4, 5, 6, 7] and sum(by.values()) == ps["remote_batches"]
+    for o, n in by.items():                            # ... one sixth from each owner (np.random.choice(6) per batch)
+        assert abs(n / ps["remote_batches"] - 1 / 6) < 0.02, by
+    assert ps["learners_identical"] is True and len(ps["learner_weight_crc32"]) == 2
+    cap = j["series"]["rollout_capacity"]["per_rank_env_steps_per_s"]
+    assert cap[:2] == [None, None] and all(v and v > 0 for v in cap[2:])

@@ -193,13 +193,16 @@ def test_actor_matches_oracle(ddrl):
     np.testing.assert_array_equal(a1, actor.get_actions(obs[:1], eps=eps[:1]).cpu().numpy()[0])
 
 
-@pytest.mark.parametrize("per_graph", [4, 3])
-def test_graph_loop_equals_eager_sample_noise_train(ddrl, per_graph):
+@pytest.mark.parametrize("per_graph,defer", [(4, "0"), (3, "0"), (4, "1"), (3, "1"), (7, "1")])
+def test_graph_loop_equals_eager_sample_noise_train(ddrl, per_graph, defer, monkeypatch):
     """ddrl_loop_run (hipGraph: the fused step with the optimizer in the wgrad epilogues, the next batch's
     sampler riding in a forward launch into the alternate input set, noise generated from the device counter,
     double-buffered optimizer state — an odd number of updates per graph ends on a copy node) == the same
-    updates issued one by one through the public surface with ddrl_normal_fill noise — bit for bit."""
+    updates issued one by one through the public surface with ddrl_normal_fill noise — bit for bit.
+    defer = "1": inside the graph the Q layer-2 / head wgrad + Adam + polyak tiles of update i run in the phase-0 launch of update
+    i + 1 (k_f0x) and the last update's in a flush launch — the same arithmetic, so still bit for bit."""
     import ctypes
+    monkeypatch.setenv("DDRL_DEFER_QW", defer)   # read when the loop captures its graph (inside td.run below)
     from distributed_drl_amd import _lib
     from distributed_drl_amd.agent import HyperParameters, Learner
     from distributed_drl_amd.workers import TrainDevice

@@ -66,11 +66,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _prefilled_shard(d, opt, r):
-    """Shard r with 500 rows whose reward 1000 r + i shows the ring and row a sampled transition came from."""
-    rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 4096, seed=100 + r)
+def _prefilled_shard(d, opt, r, cap=4096, n=500):
+    """Shard r with n rows whose reward 1000 r + i shows the ring and row a sampled transition came from."""
+    rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, cap, seed=100 + r)
     rs = np.random.RandomState(r)
-    n = 500
     rb.store_batch(*(torch.from_numpy(x).cuda() for x in (
         rs.randn(n, 8).astype(np.float32), rs.uniform(-1, 1, (n, 2)).astype(np.float32),
         (1000.0 * r + np.arange(n)).astype(np.float32), rs.randn(n, 8).astype(np.float32), np.zeros(n, np.float32))))
@@ -83,8 +82,15 @@ def _rows(rb, idx):
     return np.concatenate([g[k][torch.from_numpy(idx).cuda()].reshape(-1).cpu().numpy() for k in ("obs1_buf", "obs2_buf", "acts_buf", "rews_buf", "done_buf")])
 
 
-def _gpu_worker(rank, world, port, q, num_learners):
+# (envs per rollout rank, batch, shard capacity, rows pre-filled, updates) — the toy the first tests run, and BASELINE config 4's own sizes:
+# 6 x 8192 envs, batch 256, 10^6 transitions over 6 shards (bench.py: capacity // shards), pre-filled so that the rings WRAP within the run
+TOY = (64, 32, 4096, 500, 14)
+CONFIG4 = (8192, 256, 10 ** 6 // 6, 120000, 10)
+
+
+def _gpu_worker(rank, world, port, q, num_learners, sizes=TOY):
     try:
+        n_envs, batch, cap, prefill, n_upd = sizes
         sys.path.insert(0, ROOT)
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           DDRL_DIST_BACKEND="gloo")
@@ -97,20 +103,19 @@ def _gpu_worker(rank, world, port, q, num_learners):
         torch.cuda.set_device(0)
         _lib.require_gpu()
         opt = HyperParameters()
-        opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = 64, 32, 5, -1, 50, 6
+        opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = n_envs, batch, 5, -1, 50, 6
         B = opt.batch_size
         roles = partition.Roles(w, r, num_learners=num_learners)
-        run = partition.PartitionedRun(opt, roles, lambda: _prefilled_shard(d, opt, r), lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
+        run = partition.PartitionedRun(opt, roles, lambda: _prefilled_shard(d, opt, r, cap, prefill), lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
                                        lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=0)
         pi0 = run.bcast.buf[: 8 * 400 + 400 + 400 * 300 + 300 + 2 * (300 * 2 + 2)].clone()
         if run.roll is not None:   # the learner's initial weights reached every rollout rank's actor
             assert torch.equal(run.roll.actor.get_weights_flat(), pi0)
         sched = partition.Schedule(roles, seed=9)
-        n_upd = 14
         plans = [sched.next() for _ in range(n_upd)]
         # What every ring must hand out, from NumPy's own legacy stream: the ring's sampler is np.random.seed(100 + r);
-        # at step u it holds 500 + 64 (u + 1) rows (the env step of the step is stored before its updates) and serves
-        # learner 0's batch before learner 1's.
+        # at step u it holds min(capacity, prefill + n_envs (u + 1)) rows (the env step of the step is stored before its updates) and
+        # serves learner 0's batch before learner 1's.
         rs = np.random.RandomState(100 + r)
         handed, trained = [], []
         for u in range(n_upd):   # one update per step() call so that the batch of every update can be inspected
@@ -119,7 +124,7 @@ def _gpu_worker(rank, world, port, q, num_learners):
             if run.rb is not None:
                 for l, owner in plans[u]:
                     if owner == r:
-                        handed.append((u, l, _rows(run.rb, rs.randint(0, 500 + opt.num_envs * (u + 1), B))))
+                        handed.append((u, l, _rows(run.rb, rs.randint(0, min(cap, prefill + opt.num_envs * (u + 1)), B))))
             if run.loop is not None:   # single learner: the device loop gathered update u's batch into input set u & 1
                 v = run.learner.input_batch(u & 1)
                 trained.append(torch.cat([v[k].reshape(-1) for k in ("obs1", "obs2", "acts", "rews", "done")]).cpu().numpy().copy())
@@ -140,10 +145,10 @@ def _gpu_worker(rank, world, port, q, num_learners):
             # the shard's sampler advanced once per batch it served, the ring took its local stores
             served = sum(1 for p in plans for _, owner in p if owner == r)
             samples, steps, size = run.rb.get_counts()
-            assert samples == served and steps == 500 + n_upd * opt.num_envs == size
+            assert samples == served and steps == prefill + n_upd * opt.num_envs and size == min(cap, steps)
             assert run.stats["sent_batches"] == sum(1 for p in plans for l, owner in p if owner == r and l != r)
-        # two pushes (updates 6 and 12) + the initial one: the rollout ranks run the learner's pushed policy
-        assert run.stats["pushes"] == 3
+        # a push every 6 updates + the initial one: the rollout ranks run the learner's pushed policy
+        assert run.stats["pushes"] == 1 + n_upd // 6
         flat = run.bcast.buf.clone()
         if roles.is_learner:
             assert not torch.equal(flat[: pi0.numel()], pi0)
@@ -247,14 +252,14 @@ def _gpu_worker_async(rank, world, port, q, num_learners):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def _spawn(world, num_learners, target=None):
+def _spawn(world, num_learners, target=None, extra=(), timeout=300):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target or _gpu_worker, args=(r, world, port, q, num_learners)) for r in range(world)]
+    procs = [ctx.Process(target=target or _gpu_worker, args=(r, world, port, q, num_learners) + tuple(extra)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
@@ -272,6 +277,16 @@ def test_config4_roles_three_ranks_on_one_gpu_two_learners_one_shard():
     """Config 4's roles at the smallest size (2 data-parallel learner ranks + 1 rollout rank with the shard): the owner
     serves both learners' blocks, the learners all-reduce their gradients and stay bit-identical."""
     _spawn(3, 2)
+
+
+@pytest.mark.gpu
+def test_config4_at_its_own_sizes_eight_ranks_on_one_gpu():
+    """BASELINE config 4 as it is stated — 8 ranks: 2 data-parallel learner ranks + 6 rollout ranks x 8192 envs, batch 256, 10^6
+    transitions over 6 shards (algos/sac1/sac_ray.py:137-141,246,316-324; example/dsac.py:229-233) — on the ranks of the one GPU over
+    gloo: every update's TWO batches (one per learner) are bit for bit what NumPy's own stream says the scheduled owner's ring hands out
+    (the rings wrap during the run), every batch is remote (dedicated learners own no shard), each owner's sampler advanced once per
+    batch it served, pushes reach all six rollout ranks' actors, and the two learners hold identical parameters at the end."""
+    _spawn(8, 2, extra=(CONFIG4,), timeout=600)
 
 
 @pytest.mark.gpu
