@@ -642,6 +642,7 @@ int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay,
         if (v.act <= 2) k_env_step_pi<4><<<(unsigned)((h->n + 63) / 64), 64, 0, ddrl::as_stream(stream)>>>(a);
         else k_env_step_pi<8><<<(unsigned)((h->n + 63) / 64), 64, 0, ddrl::as_stream(stream)>>>(a);
         DDRL_LAUNCH_CHECK();
+        if (versioned) *v.plan_fresh = false;   // episode ends of this step moved envs to the newest version
         ddrl_replay_note_store(replay, h->n);
     }
     return DDRL_OK;

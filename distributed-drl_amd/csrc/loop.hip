@@ -17,9 +17,6 @@
 
 // internal (sac1.hip): put the learner's double-buffered optimizer state on copy 0
 int ddrl_sac1_internal_opt_sync(ddrl_sac1_t *h, void *stream);
-// internal (sac1.hip): cross-update deferral of the Q layer-2 / head optimizer tiles inside a captured sequence of updates
-int ddrl_sac1_internal_defer(ddrl_sac1_t *h, int on);
-int ddrl_sac1_internal_flush(ddrl_sac1_t *h, void *stream);
 
 struct ddrl_loop {
     ddrl_sac1_t *learner;
@@ -93,11 +90,7 @@ static int capture(ddrl_loop *h, hipStream_t main_s) {
     if (mode == 0) {
         // sample(0) as a kernel; sample(i+1) rides inside the Adam kernel of update i.  No store can
         // interleave inside one graph, so this equals the sequential sample -> update order.
-        // DDRL_DEFER_QW=1: inside the graph the Q layer-2 / head wgrad + Adam + polyak tiles of update i run beside phase 0 of update
-        // i + 1 (sac1_direct.h: k_f0x); the last update's run as one more launch at the end of the graph.  Bit-identical results.
-        const bool defer = getenv("DDRL_DEFER_QW") && atoi(getenv("DDRL_DEFER_QW")) != 0;   // (read at capture time)
         RC(sample_into(h, 0, (void *)main_s));
-        if (defer && rc == DDRL_OK && e == hipSuccess) (void)ddrl_sac1_internal_defer(h->learner, 1);
         for (int i = 0; i < n; ++i) {
             RC(ddrl_sac1_fill_noise(h->learner, h->seed, (void *)main_s));
             if (i + 1 < n) {
@@ -107,11 +100,6 @@ static int capture(ddrl_loop *h, hipStream_t main_s) {
                 RC(ddrl_sac1_step(h->learner, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr, nullptr, nullptr, nullptr,
                                   (void *)main_s));
             }
-        }
-        if (defer) {
-            const int rf = ddrl_sac1_internal_flush(h->learner, (void *)main_s);
-            if (rc == DDRL_OK) rc = rf;
-            (void)ddrl_sac1_internal_defer(h->learner, 0);
         }
     } else if (mode == 2) {
         HE(hipEventRecord(e_fork, main_s));

@@ -67,6 +67,7 @@ struct ddrl_actor_rollout_view {
     long long vstride;
     const float *vbmu, *vbls;
     long long *steps_since_install;
+    bool *plan_fresh;   // host flag of the actor: the forward's tile table matches the slots (cleared behind every launch that moves an env)
 };
 int ddrl_actor_internal_forward(ddrl_actor_t *h, long long n, void *stream, int versioned);
 ddrl_actor_rollout_view ddrl_actor_internal_view(ddrl_actor_t *h);

@@ -745,10 +745,8 @@ struct ddrl_sac1 {
     DFHead fh_a[2], fh_b[2];
     DFArgs f_a[2], f_b[2];
     DGJobs dg_bq[2], dg_mid, dg_pi;
-    // cross-update deferral (the learner's graph loop only, ddrl_sac1_internal_defer): launch "mid" without the Q layer-2 / head wgrads
-    // (dg_mid_nd) and those tiles riding in the NEXT update's phase-0 launch (k_f0x) or in a flush launch of their own (dg_qw)
-    DGJobs dg_mid_nd, dg_qw;
-    bool defer_ok, defer_on, qw_pending;
+    int bq_cols;         // column tiles of the q2(x, a) dgrad that run in launch "bq" (the rest: bq_rest, a job of launch "mid")
+    DGJob bq_rest;
     // direct-path activations (x4 images, see sac1_direct.h) and the dgrad images of the main layer-2 kernels
     int Lp1, Lp2;
     float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq, *w3snap, *xp_r4;
@@ -1313,7 +1311,37 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
             }
             // (the W3 snapshots for the next launch's generated wgrad operands)
             { DGJob j = dq_job(0, 1, 0, h->dZ1r4); j.gw_snap = h->w3snap; dg_add(Q, j); }
-            { DGJob j = dq_job(1, 2, 1, h->dZ1r4 + H1I); j.gw_snap = h->w3snap + 512; dg_add(Q, j); }
+            // Tile counts against the 256 CUs (profiles/r05_update_experiments.txt: a launch pays +1.2 ... +2.1 us where its tile count
+            // crosses a multiple of 256 and is flat in between): the three Q dgrads are 3 x 104 = 312 tiles at config 2 — 56 over.  Only the
+            // last launch reads the dZ1 of the stored-action dgrads (the Q layer-1 wgrads), so the q2(x, a) dgrad is cut by COLUMN tiles: the
+            // first `bq_cols` stay here (launch = 256 tiles), the rest run in launch "mid" (which the two Q-head wgrads leave for launch
+            // "pi": 464 - 20 + 56 = 500 <= 512; "pi": 190 + 20 = 210 <= 256).  A column sub-range of a dgrad is a job of its own — operand B,
+            // the relu mask and the output image start n_off columns further — with the same arithmetic per tile: bit-identical results.
+            {
+                const int tm = B / 32, ct = (h1 + 31) / 32, T = tm * ct, ncu = 256;
+                static const int want = getenv("DDRL_BQ_SPLIT") ? atoi(getenv("DDRL_BQ_SPLIT")) : 1;
+                int keep = ct;   // column tiles of the q2(x, a) dgrad that stay in this launch
+                const int rm_tiles = 2 * ((h2 + 1 + 31) / 32);                                  // the two Q-head wgrads (one column tile each)
+                const int mid_now = T + tm * ((h2 + 31) / 32) + 2 * ((h1 + 1 + 31) / 32) * ((h2 + 31) / 32) + rm_tiles;
+                const int pi_now = ((h1 + 1 + 31) / 32) * ((h2 + 31) / 32) + rm_tiles + 3 * ct + 1;
+                if (want && 3 * T > ncu && 2 * T < ncu) {
+                    const int k = (ncu - 2 * T) / tm, moved = (ct - k) * tm;
+                    if (k >= 1 && k < ct && mid_now - rm_tiles + moved <= 2 * ncu && pi_now + rm_tiles <= ncu) keep = k;
+                }
+                h->bq_cols = keep;
+                DGJob j = dq_job(1, 2, 1, h->dZ1r4 + H1I);
+                j.gw_snap = h->w3snap + 512;
+                if (keep < ct) j.N = keep * 32;
+                dg_add(Q, j);
+                if (keep < ct && st == 0) {   // the rest of the columns: a job of launch "mid" (rew / done of the input set patched at launch)
+                    const long long noff = (long long)keep * 32 * 4;
+                    DGJob r = dq_job(1, 2, 1, h->dZ1r4 + H1I + noff);
+                    r.N = h1 - keep * 32;
+                    r.B = h->c4_q[1] + noff;
+                    r.mask = h->H1r4 + 2 * H1I + noff;
+                    h->bq_rest = r;
+                }
+            }
         }
         float *G = h->grad;
         const AdamCtx ctx{0, h->main_p, h->target_p, h->m, h->v, G, h->opt, nullptr, L.n_pi_int,
@@ -1354,16 +1382,19 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 j.bgen = 1; j.gw = h->w3snap + 512 * q; j.gdq = h->dq + (long long)q * B;   // (W3 as the previous launch saw it)
                 dg_add(M, j);
             }
-            for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
-            // the same launch split for the deferred form: jobs 0, 1 stay (dg_mid_nd), jobs 2..5 — nothing reads the Q layer-2 / head
-            // kernels, their optimizer state or their dgrad images before phase 1 of the NEXT update — move (dg_qw)
-            DGJobs &N = h->dg_mid_nd, &W = h->dg_qw;
-            N = DGJobs{}; N.B = B; N.Bv = Bv; N.ad = ctx;
-            W = DGJobs{}; W.B = B; W.Bv = Bv; W.ad = ctx;
-            for (int i = 0; i < M.njobs; ++i) dg_add(i < 2 ? N : W, M.job[i]);
-            const int nfwd0 = 3 * (B / 32) * nt2;
-            h->defer_ok = cfg->variant == DDRL_SAC1 && M.njobs == 6 && W.njobs == 4 && W.total_tiles < 0xffff && nfwd0 % 8 == 0 && B <= 320 &&
-                          h->f_a[0].njobs == 3;   // (phase 0 = the three policy evaluations: nothing in it reads a Q network)
+            const bool split = h->bq_cols < (h1 + 31) / 32;
+            if (!split) {
+                for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
+            } else {
+                // the remaining column tiles of the q2(x, a) dgrad (see launch 1): its prologue needs the launch header of the Q dgrads
+                const DGJobs &Q0 = h->dg_bq[0];
+                M.hp = Q0.hp; M.sacv = 0; M.q_ev0 = Q0.q_ev0; M.q_nev = Q0.q_nev;
+                M.b3q1 = Q0.b3q1; M.b3q2 = Q0.b3q2; M.b3q1t = Q0.b3q1t; M.b3q2t = Q0.b3q2t;
+                M.rew = Q0.rew; M.done = Q0.done; M.logp0 = Q0.logp0; M.logp1 = Q0.logp1;   // (rew / done: launch_stage sets the input set's)
+                M.q1o = Q0.q1o; M.q2o = Q0.q2o; M.dq = Q0.dq; M.loss_part = Q0.loss_part;
+                M.alpha = Q0.alpha; M.gamma = Q0.gamma;
+                dg_add(M, h->bq_rest);
+            }
         }
         {   // ---- backward launch 3: the wgrads that need launch 2's outputs — policy layer 2 / heads / layer 1, Q layer 1 —, loss means,
             // optimizer bookkeeping.  No hand-off inside the launch any more: every tile is a plain GEMM tile with its Adam epilogue.
@@ -1383,6 +1414,9 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 j.type = DG_WGRAD_W1Y;
                 dg_add(P, j);
             }
+            if (h->bq_cols < (h1 + 31) / 32)   // the Q-head wgrads (+ Adam + polyak of W3, b3), moved here from launch "mid": nothing reads the head
+                                               // kernels between the two launches (the Q layer-2 wgrads of "mid" use the W3 snapshot)
+                for (int q = 0; q < 2; ++q) dg_add(P, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
             DGJob ls{};
             ls.type = DG_LOSS; ls.M = 1; ls.N = 1; ls.K = 0; ls.adam_off = -1; ls.loss_part = h->loss_part; ls.losses = h->losses; ls.nl = 3;
             ls.nparts = -1;   // + the optimizer's books
@@ -1411,8 +1445,6 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                      h->fused_l1_wgrad ? (B + 31) / 32 : 0, 0u};
     h->noise_armed = false; h->noise_seed = 0; h->noise_pending = 0; h->grad_imported = false;
     h->fuse_apply = false; h->sample_armed = false;
-    h->defer_on = false; h->qw_pending = false;
-    if (!h->fused) h->defer_ok = false;
     *out = h;
     return DDRL_OK;
 }
@@ -1573,18 +1605,7 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
     const dim3 l1grid((c.hidden1 + 255) / 256, (B + L1_ROWS - 1) / L1_ROWS, 1);
     if (h->fused) {
         switch (stage) {
-            case 2:
-                h->f_a[st].opt = h->opt + h->opt_cur;
-                if (h->qw_pending) {   // the previous update's deferred Q wgrad + Adam + polyak tiles ride here, on ITS optimizer state
-                    DGJobs &W = h->dg_qw;
-                    W.ad.on = 1;
-                    W.ad.opt = h->opt + (h->opt_cur ^ 1);
-                    launch_f0x(h->fh_a[st], h->f_a[st], W, s);
-                    h->qw_pending = false;
-                } else {
-                    launch_dfwd<0>(h->fh_a[st], h->f_a[st], s);
-                }
-                break;
+            case 2: h->f_a[st].opt = h->opt + h->opt_cur; launch_dfwd<0>(h->fh_a[st], h->f_a[st], s); break;
             case 5: {
                 DFArgs &F = h->f_b[st];
                 F.do_sample = h->sample_armed ? 1 : 0;
@@ -1598,12 +1619,11 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
             }
             case 7: launch_dg(h->dg_bq[st], s, 2); break;
             case 8: {
-                const bool defer = h->defer_on && h->defer_ok && h->fuse_apply;
-                DGJobs &J = defer ? h->dg_mid_nd : h->dg_mid;
-                if (defer) h->qw_pending = true;
+                DGJobs &J = h->dg_mid;
                 J.ad.on = h->fuse_apply ? 1 : 0;
                 J.ad.opt = h->opt + h->opt_cur;
                 J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image of the policy's layer-2 kernel ...
+                J.rew = h->dg_bq[st].rew; J.done = h->dg_bq[st].done;   // (read by the Q dgrad columns that run here, if any)
                 launch_dg(J, s, 3);
                 break;
             }
@@ -1814,28 +1834,6 @@ int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, con
 
 __global__ void k_opt_copy(const OptState *src, OptState *dst) { *dst = *src; }
 
-// Internal (loop.hip).  defer(1): from the next step on, launch "mid" leaves the Q layer-2 / head wgrads (+ Adam + polyak) to the
-// following step's phase-0 launch; flush(): the tiles still pending run as a launch of their own (before anything else may look at the
-// parameters); defer(0) requires a flushed learner.  Same arithmetic per element in the same order: results are bit-identical.
-int ddrl_sac1_internal_defer(ddrl_sac1 *h, int on) {
-    DDRL_REQUIRE(h != nullptr, "handle is NULL");
-    DDRL_REQUIRE(on || !h->qw_pending, "deferred optimizer tiles pending: flush first");
-    h->defer_on = on != 0;
-    return (h->defer_on && !h->defer_ok) ? 1 : DDRL_OK;   // 1: accepted, but this learner's shape / variant never defers
-}
-int ddrl_sac1_internal_flush(ddrl_sac1 *h, void *stream) {
-    DDRL_REQUIRE(h != nullptr, "handle is NULL");
-    if (!h->qw_pending) return DDRL_OK;
-    ddrl::DeviceGuard g(h->device);
-    DGJobs &W = h->dg_qw;
-    W.ad.on = 1;
-    W.ad.opt = h->opt + (h->opt_cur ^ 1);
-    launch_dg(W, ddrl::as_stream(stream), 3);
-    DDRL_LAUNCH_CHECK();
-    h->qw_pending = false;
-    return DDRL_OK;
-}
-
 // Internal (loop.hip): make copy 0 of the double-buffered optimizer state the current one, so that a
 // captured graph starts and ends on the same copy whatever the number of updates it holds.
 int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
@@ -1927,7 +1925,10 @@ struct ddrl_actor {
     int n_slots;
     long long vstride;
     float *vslab;
-    int *slot_d, *perm_d;
+    int *slot_d, *perm_d;          // perm_d: the row list of every tile, [tiles][32] (+ parking space of k_version_plan)
+    bool plan_fresh;               // the tile table matches the envs' slots (set by a plan launch, cleared by whatever moves an env)
+    bool pi_p_stale;               // direct actors: the row-major copy (ddrl_actor_act / get_weights) is rebuilt from pi_d on demand
+    float *flat_tmp;               // ... through this dense staging vector
     VerTile *vtiles_d;
     VerState *vs_d;
     long long steps_since_install;   // host-side: >= the envs' max_ep_len <=> every env has adopted the newest version
@@ -1938,32 +1939,6 @@ struct ddrl_actor {
 // can ever act on it again once a newer version exists: a worker pulls whatever the server holds at ITS episode end), else
 // the lowest slot no env acts on.  n_slots >= min(n_envs, max_ep_len) + 2 always leaves one.
 constexpr int VER_MAX_SLOTS = 2048;
-__global__ void __launch_bounds__(1024) k_version_pick(const int *__restrict__ slot, long long n, int n_slots, VerState *vs) {
-    __shared__ int used[VER_MAX_SLOTS];
-    __shared__ int s_free, s_live;
-    for (int j = threadIdx.x; j < n_slots; j += 1024) used[j] = 0;
-    if (threadIdx.x == 0) { s_free = n_slots; s_live = 0; }
-    __syncthreads();
-    for (long long i = threadIdx.x; i < n; i += 1024) used[slot[i]] = 1;
-    __syncthreads();
-    const int newest = vs->newest;
-    for (int j = threadIdx.x; j < n_slots; j += 1024) {
-        if (used[j]) atomicAdd(&s_live, 1);
-        else if (j != newest) atomicMin(&s_free, j);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int target = newest;
-        if (used[newest]) {
-            if (s_free < n_slots) target = s_free;
-            else vs->err = 1;              // sticky: no free slot (the newest one is overwritten: its envs act on fresher weights)
-        }
-        vs->target = target;
-        vs->newest = target;
-        vs->live = s_live;
-    }
-}
-
 __global__ void __launch_bounds__(256) k_version_copy(const float *__restrict__ src, float *__restrict__ vslab, long long vstride,
                                                       const VerState *__restrict__ vs, long long n4) {
     float4 *dst = reinterpret_cast<float4 *>(vslab + (long long)vs->target * vstride);
@@ -1993,37 +1968,68 @@ __device__ __forceinline__ int ver_group_add(int *arr, int s, bool valid, int la
     if (valid) pos = atomicAdd(&arr[s], 1);
     return pos;
 }
-__global__ void __launch_bounds__(1024) k_version_group(const int *__restrict__ slot, long long n, int n_slots, int *__restrict__ perm,
-                                                        VerTile *__restrict__ tiles, VerState *vs) {
-    __shared__ int cnt[VER_MAX_SLOTS], cur[VER_MAX_SLOTS], start[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
-    __shared__ int wsum_c[16], wsum_t[16], s_nt;
+// ONE launch (one workgroup) plans a versioned forward — and, with `install`, first picks the slot incoming weights go to.
+//   pick   the newest slot itself while no env has adopted it (nobody can ever act on a superseded version that nobody holds: a worker
+//          pulls whatever the server holds at ITS episode end), else the lowest slot no env acts on (n_slots >= min(n_envs, max_ep_len) + 2
+//          always leaves one); sticky vs->err when none is free.  The grouping does not depend on the pick: no env sits on the target.
+//   group  envs by slot (counting sort; the order inside a group is immaterial — rows are computed independently), one VerTile per 32
+//          envs of a group, and the envs of tile ti at rows[32 ti .. 32 ti + count): the forward reads its tile record and its row list
+//          with two INDEPENDENT loads (round 4 chained n_tiles -> tile -> dense permutation -> observation rows: four round trips before
+//          the first operand).  An env's position in its group is the value its histogram atomic returned — one atomic pass, not two.
+constexpr int VER_REG_ENVS = 8;   // envs per thread kept in registers across the passes (8192 envs: config 4's rollout ranks)
+__global__ void __launch_bounds__(1024) k_version_plan(const int *__restrict__ slot, long long n, int n_slots, int *__restrict__ rows,
+                                                       VerTile *__restrict__ tiles, VerState *vs, int install) {
+    __shared__ int cnt[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
+    __shared__ int wsum_t[16], s_nt, s_free, s_live;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    // the first four envs of every thread stay in registers for both passes (n <= 4096: all of them), requested before anything else
-    int sv[4];
+    int sv[VER_REG_ENVS], pv[VER_REG_ENVS];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sv[e] = t + 1024 * e < n ? slot[t + 1024 * e] : 0;
-    for (int j = t; j < VER_MAX_SLOTS; j += 1024) { cnt[j] = 0; cur[j] = 0; }
+    for (int e = 0; e < VER_REG_ENVS; ++e) sv[e] = t + 1024 * e < n ? slot[t + 1024 * e] : 0;
+    for (int j = t; j < VER_MAX_SLOTS; j += 1024) cnt[j] = 0;
+    if (t == 0) { s_free = n_slots; s_live = 0; }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ver_group_add(cnt, sv[e], t + 1024 * e < n, lane);
-    for (long long i0 = 4096; i0 < n; i0 += 1024) ver_group_add(cnt, i0 + t < n ? slot[i0 + t] : 0, i0 + t < n, lane);
+    for (int e = 0; e < VER_REG_ENVS; ++e) pv[e] = ver_group_add(cnt, sv[e], t + 1024 * e < n, lane);
+    for (long long i0 = 1024ll * VER_REG_ENVS; i0 < n; i0 += 1024) {   // (more envs than the registers hold: positions parked in `rows`' tail)
+        const bool ok = i0 + t < n;
+        const int p = ver_group_add(cnt, ok ? slot[i0 + t] : 0, ok, lane);
+        if (ok) rows[32ll * (n / 32 + n_slots) + (i0 + t)] = p;
+    }
     __syncthreads();
-    // exclusive scans of the group sizes and of the groups' tile counts: two slots per thread, wave scan, wave totals
+    const int newest = vs->newest;
+    // exclusive scan of the groups' tile counts: two slots per thread, wave scan, wave totals
     const int c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
     const int t0 = (c0 + 31) >> 5, t1 = (c1 + 31) >> 5;
-    int sc = c0 + c1, st = t0 + t1;
+    int st = t0 + t1;
     for (int o = 1; o < 64; o <<= 1) {
-        const int uc = __shfl_up(sc, o), ut = __shfl_up(st, o);
-        if (lane >= o) { sc += uc; st += ut; }
+        const int ut = __shfl_up(st, o);
+        if (lane >= o) st += ut;
     }
-    if (lane == 63) { wsum_c[w] = sc; wsum_t[w] = st; }
+    if (lane == 63) wsum_t[w] = st;
+    if (install) {
+        int live = (c0 > 0) + (c1 > 0);
+        int fr = n_slots;
+        if (2 * t + 1 < n_slots && c1 == 0 && 2 * t + 1 != newest) fr = 2 * t + 1;
+        if (2 * t < n_slots && c0 == 0 && 2 * t != newest) fr = 2 * t;
+        for (int o = 32; o >= 1; o >>= 1) { live += __shfl_xor(live, o); fr = min(fr, __shfl_xor(fr, o)); }
+        if (lane == 0) { atomicAdd(&s_live, live); atomicMin(&s_free, fr); }
+    }
     __syncthreads();
-    int bc = 0, bt = 0;
-    for (int k = 0; k < w; ++k) { bc += wsum_c[k]; bt += wsum_t[k]; }
-    const int ec = bc + sc - (c0 + c1), et = bt + st - (t0 + t1);   // exclusive prefix of this thread's pair
-    start[2 * t] = ec; start[2 * t + 1] = ec + c0;
+    int bt = 0;
+    for (int k = 0; k < w; ++k) bt += wsum_t[k];
+    const int et = bt + st - (t0 + t1);   // exclusive prefix of this thread's pair
     tstart[2 * t] = et; tstart[2 * t + 1] = et + t0;
     if (t == 1023) { vs->n_tiles = bt + st; s_nt = bt + st; }
+    if (t == 0 && install) {
+        int target = newest;
+        if (cnt[newest] > 0) {
+            if (s_free < n_slots) target = s_free;
+            else vs->err = 1;              // sticky: no free slot (the newest one is overwritten: its envs act on fresher weights)
+        }
+        vs->target = target;
+        vs->newest = target;
+        vs->live = s_live;
+    }
     __syncthreads();
     // tile ti belongs to the LAST slot whose first tile is <= ti (the empty slots behind it start where it ends)
     for (int ti = t; ti < s_nt; ti += 1024) {
@@ -2033,19 +2039,34 @@ __global__ void __launch_bounds__(1024) k_version_group(const int *__restrict__ 
             if (tstart[mid] > ti) hi = mid; else lo = mid + 1;
         }
         const int j = lo - 1, k = ti - tstart[j], c = cnt[j];
-        tiles[ti] = VerTile{j, start[j] + 32 * k, c - 32 * k < 32 ? c - 32 * k : 32, 0};
+        tiles[ti] = VerTile{j, 32 * ti, c - 32 * k < 32 ? c - 32 * k : 32, 0};
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool ok = t + 1024 * e < n;
-        const int p = ver_group_add(cur, sv[e], ok, lane);
-        if (ok) perm[start[sv[e]] + p] = t + 1024 * e;
+    for (int e = 0; e < VER_REG_ENVS; ++e)
+        if (t + 1024 * e < n) rows[32 * (tstart[sv[e]] + (pv[e] >> 5)) + (pv[e] & 31)] = t + 1024 * e;
+    for (long long i0 = 1024ll * VER_REG_ENVS; i0 < n; i0 += 1024) {
+        if (i0 + t < n) {
+            const int p = rows[32ll * (n / 32 + n_slots) + (i0 + t)];
+            rows[32 * (tstart[slot[i0 + t]] + (p >> 5)) + (p & 31)] = (int)(i0 + t);
+        }
     }
-    for (long long i0 = 4096; i0 < n; i0 += 1024) {
-        const bool ok = i0 + t < n;
-        const int s = ok ? slot[i0 + t] : 0;
-        const int p = ver_group_add(cur, s, ok, lane);
-        if (ok) perm[start[s] + p] = (int)(i0 + t);
+}
+
+// k_pack into the actor's current direct-layout policy AND into the version slot k_version_plan picked (one launch instead of a pack and
+// a 0.5 MB copy; the slots' pads stay as allocated: zero, like the current copy's)
+__global__ void __launch_bounds__(256) k_pack_version(const Seg *__restrict__ segs, const float *__restrict__ src, float *__restrict__ dst,
+                                                      float *__restrict__ vslab, long long vstride, const VerState *__restrict__ vs) {
+    const Seg s = segs[blockIdx.y];
+    float *dst2 = vslab + (long long)vs->target * vstride;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.n; i += (long long)gridDim.x * 256) {
+        long long ii = i;
+        if (s.cols > 0) {
+            const long long k = i / s.cols, j = i - k * s.cols;
+            ii = s.mode == 2 ? w1y_index(s.d0 + (int)k, (int)j) : ((k >> 2) * s.ld + j) * 4 + (k & 3);
+        }
+        const float v = src[s.ext + i];
+        dst[s.in + ii] = v;
+        dst2[s.in + ii] = v;
     }
 }
 
@@ -2122,6 +2143,7 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
         h->direct = direct_ok(c2) && max_rows % 32 == 0 && max_rows <= 32 * 4095 && cfg->obs_dim + 1 <= 13;
         h->dslab = nullptr; h->segs_dd = nullptr;
         h->n_slots = 0; h->vslab = nullptr; h->slot_d = h->perm_d = nullptr; h->vtiles_d = nullptr; h->vs_d = nullptr;
+        h->plan_fresh = false; h->pi_p_stale = false; h->flat_tmp = nullptr;
         h->steps_since_install = 1ll << 40;
     }
     if (h->direct) {
@@ -2130,6 +2152,7 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
         const size_t nh = (size_t)DFH * max_rows * DNT;
         e = dev_alloc(&h->dslab, np + no + nh + 2048);
         if (e == hipSuccess) e = dev_alloc(&h->segs_dd, h->Ld.segs.size());
+        if (e == hipSuccess) e = dev_alloc(&h->flat_tmp, (size_t)h->L.total_ext + 64);
         if (e != hipSuccess) {
             ddrl::set_error("hipMalloc failed in ddrl_actor_create: %s", hipGetErrorString(e));
             ddrl_actor_destroy(h);
@@ -2145,7 +2168,7 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
 int ddrl_actor_destroy(ddrl_actor_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
-    (void)hipFree(h->dslab); (void)hipFree(h->segs_dd);
+    (void)hipFree(h->dslab); (void)hipFree(h->segs_dd); (void)hipFree(h->flat_tmp);
     (void)hipFree(h->vslab); (void)hipFree(h->slot_d); (void)hipFree(h->perm_d); (void)hipFree(h->vtiles_d); (void)hipFree(h->vs_d);
     (void)hipFree(h->pi_p); (void)hipFree(h->H1); (void)hipFree(h->H2); (void)hipFree(h->segs_d);
     delete h;
@@ -2155,16 +2178,32 @@ int ddrl_actor_destroy(ddrl_actor_t *h) {
 int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream) {
     DDRL_REQUIRE(h != nullptr && flat_pi_d != nullptr, "NULL pointer");
     ddrl::DeviceGuard g(h->device);
-    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_pi_d, h->pi_p, nullptr, 1);
-    if (h->direct) k_pack<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_dd, flat_pi_d, h->pi_d, nullptr, 1);
-    if (h->n_slots > 0) {   // version store: the new weights become the newest version, in a slot no env acts on
-        hipStream_t s = ddrl::as_stream(stream);
-        k_version_pick<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->vs_d);
-        k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
+    hipStream_t s = ddrl::as_stream(stream);
+    if (!h->direct) {
+        k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, s>>>(h->segs_d, flat_pi_d, h->pi_p, nullptr, 1);
+    } else if (h->n_slots > 0) {
+        // version store: the new weights become the newest version, in a slot no env acts on — ONE planning launch (slot pick + the tile
+        // table of the next forward) and ONE pack into the current copy and that slot (round 4: two packs, the pick, a 0.5 MB copy
+        // and, in the step, the grouping: five launches)
+        k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 1);
+        k_pack_version<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, s>>>(h->segs_dd, flat_pi_d, h->pi_d, h->vslab, h->vstride, h->vs_d);
+        h->plan_fresh = true;
         h->steps_since_install = 0;
+        h->pi_p_stale = true;
+    } else {
+        k_pack<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, s>>>(h->segs_dd, flat_pi_d, h->pi_d, nullptr, 1);
+        h->pi_p_stale = true;   // the row-major copy only serves ddrl_actor_act / get_weights: rebuilt there
     }
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
+}
+
+// direct actors: the row-major policy (generic kernels of ddrl_actor_act, ddrl_actor_get_weights) from the direct-layout one, on demand
+static void actor_refresh_row_major(ddrl_actor *h, hipStream_t s) {
+    if (!h->pi_p_stale) return;
+    k_pack<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, s>>>(h->segs_dd, h->pi_d, h->flat_tmp, nullptr, 0);
+    k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, s>>>(h->segs_d, h->flat_tmp, h->pi_p, nullptr, 1);
+    h->pi_p_stale = false;
 }
 
 int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
@@ -2176,7 +2215,7 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
     const long long np = ((long long)h->Ld.total_int + 2048 + 63) & ~63ll;   // as the policy part of dslab (incl. the guard)
     hipError_t e = dev_alloc(&h->vslab, (size_t)np * n_slots + 2048);
     if (e == hipSuccess) e = dev_alloc(&h->slot_d, (size_t)h->max_rows + 64);
-    if (e == hipSuccess) e = dev_alloc(&h->perm_d, (size_t)h->max_rows + 64);
+    if (e == hipSuccess) e = dev_alloc(&h->perm_d, (size_t)32 * (h->max_rows / 32 + n_slots) + (size_t)h->max_rows + 64);
     if (e == hipSuccess) e = dev_alloc(&h->vtiles_d, (size_t)(h->max_rows / 32 + n_slots) + 16);
     if (e == hipSuccess) e = dev_alloc(&h->vs_d, 2);
     if (e != hipSuccess) {
@@ -2189,6 +2228,7 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
     h->n_slots = n_slots;
     k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
     h->steps_since_install = 1ll << 40;
+    h->plan_fresh = false;
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
@@ -2237,6 +2277,7 @@ int ddrl_actor_versions_adopt(ddrl_actor_t *h, const uint8_t *ended_d, int64_t n
     DDRL_REQUIRE(n > 0 && n <= h->max_rows, "n outside [1, max_rows]");
     ddrl::DeviceGuard g(h->device);
     k_version_adopt<<<(unsigned)((n + 255) / 256), 256, 0, ddrl::as_stream(stream)>>>(h->slot_d, ended_d, n, h->vs_d);
+    h->plan_fresh = false;
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }
@@ -2244,6 +2285,11 @@ int ddrl_actor_versions_adopt(ddrl_actor_t *h, const uint8_t *ended_d, int64_t n
 int ddrl_actor_get_weights(ddrl_actor_t *h, float *flat_pi_d, void *stream) {
     DDRL_REQUIRE(h != nullptr && flat_pi_d != nullptr, "NULL pointer");
     ddrl::DeviceGuard g(h->device);
+    if (h->direct) {   // straight from the direct-layout policy
+        k_pack<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_dd, h->pi_d, flat_pi_d, nullptr, 0);
+        DDRL_LAUNCH_CHECK();
+        return DDRL_OK;
+    }
     k_pack<<<dim3(64, (unsigned)h->L.segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, h->pi_p, flat_pi_d, nullptr, 0);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
@@ -2258,6 +2304,7 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     hipStream_t s = ddrl::as_stream(stream);
     const ddrl_sac1_config_t &c = h->cfg;
     const Layout &L = h->L;
+    actor_refresh_row_major(h, s);
     L1Jobs l1{};
     l1.njobs = 1;
     l1.job[0] = L1Job{obs_d, nullptr, h->pi_p + L.pi_W1, h->pi_p + L.pi_b1, h->H1, nullptr, c.obs_dim, 0, (int)n, c.hidden1, h->ldh1, 0, 0};
@@ -2301,7 +2348,8 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream, int ve
         // envs grouped by the policy version they act on; a row tile = up to 32 envs of one version.  The launch covers the worst
         // case (every live version leaves one partial tile), surplus workgroups leave at once.
         DDRL_REQUIRE(h->n_slots > 0 && n == h->max_rows, "versioned forward: store not enabled, or n != max_rows");
-        k_version_group<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d);
+        if (!h->plan_fresh) k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 0);
+        h->plan_fresh = true;   // (ddrl_rollout_step clears it behind the env-step launch, ddrl_actor_versions_adopt behind its own)
         const long long vt = n / 32 + (h->n_slots < n ? h->n_slots : n);
         A.W1 = h->vslab + L.pi_W1; A.W2p = A.W1 + ((c.hidden1 + 31) & ~31) * 16;
         A.b2 = h->vslab + L.pi_b2; A.wmu = h->vslab + L.pi_Wmu; A.wls = h->vslab + L.pi_Wls;
@@ -2337,6 +2385,7 @@ ddrl_actor_rollout_view ddrl_actor_internal_view(ddrl_actor *h) {
     v.n_slots = h->n_slots; v.slot = h->slot_d; v.vs = h->vs_d; v.vstride = h->vstride;
     v.vbmu = h->n_slots ? h->vslab + h->Ld.pi_bmu : nullptr; v.vbls = h->n_slots ? h->vslab + h->Ld.pi_bls : nullptr;
     v.steps_since_install = &h->steps_since_install;
+    v.plan_fresh = &h->plan_fresh;
     v.obs_dim = h->cfg.obs_dim; v.act = h->cfg.act_dim; v.nt2 = (h->cfg.hidden2 + 31) / 32; v.max_rows = h->max_rows;
     v.scale = (float)h->cfg.act_scale; v.device = h->device;
     return v;

@@ -248,8 +248,8 @@ __device__ __forceinline__ void dkloop(DOps &o, const DSrc &src, int K, int lane
 // the fetch phase, not the MFMAs, is what a stage waits for): one workgroup = 64 rows x 32 columns, the wave's W2 / W1
 // registers serve both row tiles.
 template <int PH, int MT>
-__device__ __forceinline__ void dfwd_body(const int bx, const float *base, int tpj_tm, int K_Np, int B_d0, int pack, int x_off, int main_off, int targ_off, int npi, int perq,
-                                          int hp_off, const DFArgs &a) {
+__global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int pack, int x_off, int main_off, int targ_off, int npi, int perq,
+                                              int hp_off, DFArgs a) {  // 12 dwords: what the hardware preloads into SGPRs at wave launch
     static_assert(PH == 0 || MT == 1, "phase 1 computes one policy row per lane");
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ __attribute__((aligned(16))) float tr[4][32 * 36];
@@ -260,7 +260,7 @@ __device__ __forceinline__ void dfwd_body(const int bx, const float *base, int t
     unsigned long long *const st_ = a.st;
 #endif
     DRT(PH, 14); DST(PH, 0);
-    if (PH == 1 && bx == njobs * tpj) {  // only launched when a.do_sample
+    if (PH == 1 && (int)blockIdx.x == njobs * tpj) {  // only launched when a.do_sample
         ddrl_replay_dev::sample_block(a.rs, a.ring, a.sout, a.sample_batch, nullptr, 1);
         return;
     }
@@ -271,12 +271,12 @@ __device__ __forceinline__ void dfwd_body(const int bx, const float *base, int t
     // first (dispatched first: one per CU) and then a run of stored ones (the second workgroup of a CU); host: 3 tpj % 8 == 0 == 2 tpj % 8.
     bool stored = false;
     if (PH == 1 && ((pack >> 30) & 1)) {
-        const int nd = 3 * tpj, b = bx, x = b & 7, slot = b >> 3, qd = nd >> 3, qs = (2 * tpj) >> 3;
+        const int nd = 3 * tpj, b = blockIdx.x, x = b & 7, slot = b >> 3, qd = nd >> 3, qs = (2 * tpj) >> 3;
         stored = slot >= qd;
         t = stored ? nd + x * qs + (slot - qd) : x * qd + slot;
     } else {   // XCD-aware, panel-major tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s); give each XCD a
         // contiguous run of tiles so that a W2 panel is fetched by one or two L2s instead of all eight (speed only)
-        const int nwg = njobs * tpj, b = bx, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        const int nwg = njobs * tpj, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     const int ji = (t >= tpj) + (t >= 2 * tpj) + (t >= 3 * tpj) + (t >= 4 * tpj);
@@ -509,12 +509,6 @@ __device__ __forceinline__ void dfwd_body(const int bx, const float *base, int t
     DST(PH, 5); DRT(PH, 15);
 }
 
-template <int PH, int MT>
-__global__ void __launch_bounds__(256) k_dfwd(const float *base, int tpj_tm, int K_Np, int B_d0, int pack, int x_off, int main_off, int targ_off, int npi, int perq,
-                                              int hp_off, DFArgs a) {  // 12 dwords: what the hardware preloads into SGPRs at wave launch
-    dfwd_body<PH, MT>((int)blockIdx.x, base, tpj_tm, K_Np, B_d0, pack, x_off, main_off, targ_off, npi, perq, hp_off, a);
-}
-
 // Row tiles per workgroup of a phase-0 launch.  Measured at the config-2 shape (400 tiles of 32 rows): MT = 2 halves the
 // W2 bytes a CU fetches, but leaves ONE wave per SIMD whose layer-1 -> relu -> layer-2 chain of dependent MFMAs has nobody
 // to fill its issue bubbles: 15.9 us per launch against 12.0 us with two 32-row workgroups per CU.  DDRL_FWD_MT=2 selects it.
@@ -597,13 +591,19 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     int m0 = rt * 32;
     const int nt0 = grp * gbase + (grp < gextra ? grp : gextra);
     // VER: row tile rt of the grouping kernel's table — its envs (through perm) and its version's weights
-    int vcount = 32;
+    int vcount = 32, vrow = 0;
     if (VER) {
-        if (rt >= a.vs->n_tiles) return;   // the launch covers the worst case (n / 32 + live versions); block-uniform
+        // three independent loads, one round trip: the launch's tile count, this tile's record, this lane's env (the row list of tile rt
+        // sits at perm[32 rt ..): no chain through the record; entries beyond the tile's count, and tiles beyond n_tiles, hold whatever
+        // an earlier plan left — valid env numbers or zero, never read as data)
+        const int nt_live = a.vs->n_tiles;
         const VerTile vt = a.vtiles[rt];
+        vrow = a.perm[32 * rt + l31];
+        if (rt >= nt_live) return;   // the launch covers the worst case (n / 32 + live versions); block-uniform
         const long long off = (long long)vt.slot * a.vstride;
         a.W1 += off; a.W2p += off; a.b2 += off; a.wmu += off; a.wls += off;
-        m0 = vt.base; vcount = vt.count;
+        m0 = 32 * rt; vcount = vt.count;
+        vrow = __shfl(vrow, (lane & 32) + (l31 < vcount ? l31 : vcount - 1));   // rows beyond the count repeat the tile's last env
     }
     const int K = a.K, Np = a.Np, d0 = a.d0;
     const int nblk = (K + 31) >> 5, bs = nblk >> 2, rem = nblk & 3;
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     float xin[7];
     {
         long long row = m0 + l31 < a.rows ? m0 + l31 : a.rows - 1;
-        if (VER) row = a.perm[m0 + (l31 < vcount ? l31 : vcount - 1)];
+        if (VER) row = vrow;
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
             const int d = d_slot(s, h);
@@ -834,9 +834,8 @@ struct DGJobs {
 };
 
 
-// JOBS_OFF: byte offset of the DGJobs argument in the calling kernel's kernarg segment (the hot line is fetched from there by address)
-template <int GMAX, int JOBS_OFF>
-__device__ __forceinline__ void dg_body(const int bx, int total_tiles, int tsA, int tsB, int tsC, int tsD, int tsE, int tsF, int tsG, int tsH, int kid, const DGJobs &jobs) {
+template <int GMAX>
+__global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, int tsC, int tsD, int tsE, int tsF, int tsG, int tsH, int kid, DGJobs jobs) {
     __shared__ __attribute__((aligned(16))) float red[4][32][33];
     __shared__ float s_q[8][32];
     __shared__ float s_g[32];
@@ -854,7 +853,7 @@ __device__ __forceinline__ void dg_body(const int bx, int total_tiles, int tsA, 
         // XCDs with its own runs 52.3, panel-cyclic ownership (XCD x owns column panel x of every job in every launch) 52.0,
         // this 50.2: what an XCD saves in re-fetched operand panels outweighs both a job's tail and inter-launch L2 reuse
         // (which does not happen anyway: an XCD's footprint per update is the size of its L2).
-        const int nwg = total_tiles, b = bx, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        const int nwg = total_tiles, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     static_assert(MAX_DG_JOBS == 16, "k_dg takes tile_start[1..15] as eight scalar arguments, two 16-bit starts each (0xffff: no such job)");
@@ -872,8 +871,9 @@ __device__ __forceinline__ void dg_body(const int bx, int total_tiles, int tsA, 
     int kl;
     {
         // (addresses from the kernarg segment pointer: taking &jobs would make the compiler copy the by-value struct to scratch.)
-        // Kernarg layout of k_dg: ten ints, then DGJobs at the next multiple of its 64-byte alignment (JOBS_OFF = 64).
-        static_assert(alignof(DGJobs) == 64 && JOBS_OFF % 64 == 0, "kernarg offset of the DGJobs argument");
+        // Kernarg layout: ten ints, then DGJobs at the next multiple of its 64-byte alignment.
+        constexpr int JOBS_OFF = 64;
+        static_assert(alignof(DGJobs) == 64 && 10 * sizeof(int) <= JOBS_OFF, "kernarg offset of k_dg's DGJobs argument");
         const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
         const int jboff = __builtin_amdgcn_readfirstlane(JOBS_OFF + (int)offsetof(DGJobs, job) + ji * (int)sizeof(DGJob));  // (wave-uniform: an SGPR address)
         const void *hdp = ka + JOBS_OFF, *jbp = ka + jboff;
@@ -1422,29 +1422,6 @@ __device__ __forceinline__ void dg_body(const int bx, int total_tiles, int tsA, 
     DST(kid, 5); DRT(kid, 15);
 }
 
-template <int GMAX>
-__global__ void __launch_bounds__(256) k_dg(int total_tiles, int tsA, int tsB, int tsC, int tsD, int tsE, int tsF, int tsG, int tsH, int kid, DGJobs jobs) {
-    static_assert(10 * sizeof(int) <= 64, "k_dg: ten ints, then DGJobs at kernarg offset 64");
-    dg_body<GMAX, 64>((int)blockIdx.x, total_tiles, tsA, tsB, tsC, tsD, tsE, tsF, tsG, tsH, kid, jobs);
-}
-
-// Phase 0 of update u + 1 and the DEFERRED optimizer tiles of update u in one launch (the learner's graph loop only): the Q layer-2 / head
-// weight gradients with their Adam + polyak epilogues are first needed by phase 1 of the next update (phase 0 evaluates the policy
-// networks only), so they leave launch "mid" (464 -> 184 tiles) and ride beside the 240 forward tiles of the next update's phase 0
-// (0.9 workgroups per CU).  Blocks [0, nfwd) are k_dfwd<0> tiles (nfwd from the preloaded scalars: the forward prologue is unchanged),
-// blocks [nfwd, nfwd + dg_total) are k_dg tiles of a table of at most four jobs whose tile starts fit the remaining preloaded dwords.
-struct F0XLayout { const float *base; int s[14]; DFArgs a; DGJobs jobs; };
-template <int GMAX>
-__global__ void __launch_bounds__(256) k_f0x(const float *base, int tpj_tm, int K_Np, int B_d0, int pack, int x_off, int main_off, int targ_off, int npi, int perq,
-                                             int hp_off, int dg_total, int tsA, int tsB, int spare, DFArgs a, DGJobs jobs) {
-    const int nfwd = (tpj_tm & 0xffff) * (int)((unsigned)tpj_tm >> 28);
-    if ((int)blockIdx.x >= nfwd) {
-        dg_body<GMAX, (int)offsetof(F0XLayout, jobs)>((int)blockIdx.x - nfwd, dg_total, tsA, tsB, -1, -1, -1, -1, -1, -1, 5, jobs);
-        return;
-    }
-    dfwd_body<0, 1>((int)blockIdx.x, base, tpj_tm, K_Np, B_d0, pack, x_off, main_off, targ_off, npi, perq, hp_off, a);
-}
-
 static void dg_add(DGJobs &js, DGJob j) {
     j.gp = j.type == DG_DGRAD_Q ? j.gw : j.gdq;
     j.tiles_m = (j.M + 31) / 32;
@@ -1474,24 +1451,6 @@ static void launch_dg(const DGJobs &J_, hipStream_t s, int kid = 0) {
     for (int i = 0; i < 8; ++i) pk[i] = (ts[2 * i] & 0xffff) | (int)((unsigned)(ts[2 * i + 1] & 0xffff) << 16);   // pk[0]'s low half (job 0 starts at 0) is unused
     if (per_wave <= 10) k_dg<10><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], pk[6], pk[7], kid, J);
     else k_dg<DGMAX><<<J.total_tiles, 256, 0, s>>>(J.total_tiles, pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], pk[6], pk[7], kid, J);
-}
-
-static void launch_f0x(const DFHead &d, const DFArgs &F_, const DGJobs &W_, hipStream_t s) {
-#ifdef DDRL_STAMPS
-    DFArgs F = F_;
-    F.st = g_st_host;
-    DGJobs W = W_;
-    W.st = g_st_host;
-#else
-    const DFArgs &F = F_;
-    const DGJobs &W = W_;
-#endif
-    const int tiles_m = d.B / 32, tpj = tiles_m * F.tiles_n;
-    const int a1 = tpj | (tiles_m << 16) | (F.njobs << 28), a2 = d.K | (d.Np << 12), a3 = d.B | (d.d0 << 16) | (F.act << 24);
-    const int *ts = W.tile_start;
-    const int tsA = (int)((unsigned)(ts[1] & 0xffff) << 16), tsB = (ts[2] & 0xffff) | (int)((unsigned)(ts[3] & 0xffff) << 16);
-    const int grid = F.njobs * tpj + W.total_tiles;
-    k_f0x<10><<<grid, 256, 0, s>>>(d.base, a1, a2, a3, d.pack, d.x_off, d.main_off, d.targ_off, d.npi, d.perq, d.hp_off, W.total_tiles, tsA, tsB, 0, F, W);
 }
 
 // The dgrad image [N/4][ld][4] of a k4-interleaved kernel [K/4][Np][4] (after a set_weights / import / flat Adam step)

@@ -193,16 +193,13 @@ def test_actor_matches_oracle(ddrl):
     np.testing.assert_array_equal(a1, actor.get_actions(obs[:1], eps=eps[:1]).cpu().numpy()[0])
 
 
-@pytest.mark.parametrize("per_graph,defer", [(4, "0"), (3, "0"), (4, "1"), (3, "1"), (7, "1")])
-def test_graph_loop_equals_eager_sample_noise_train(ddrl, per_graph, defer, monkeypatch):
+@pytest.mark.parametrize("per_graph", [4, 3])
+def test_graph_loop_equals_eager_sample_noise_train(ddrl, per_graph):
     """ddrl_loop_run (hipGraph: the fused step with the optimizer in the wgrad epilogues, the next batch's
     sampler riding in a forward launch into the alternate input set, noise generated from the device counter,
     double-buffered optimizer state — an odd number of updates per graph ends on a copy node) == the same
-    updates issued one by one through the public surface with ddrl_normal_fill noise — bit for bit.
-    defer = "1": inside the graph the Q layer-2 / head wgrad + Adam + polyak tiles of update i run in the phase-0 launch of update
-    i + 1 (k_f0x) and the last update's in a flush launch — the same arithmetic, so still bit for bit."""
+    updates issued one by one through the public surface with ddrl_normal_fill noise — bit for bit."""
     import ctypes
-    monkeypatch.setenv("DDRL_DEFER_QW", defer)   # read when the loop captures its graph (inside td.run below)
     from distributed_drl_amd import _lib
     from distributed_drl_amd.agent import HyperParameters, Learner
     from distributed_drl_amd.workers import TrainDevice
@@ -500,3 +497,52 @@ def test_ddqn_learner_at_the_config5_observation_width(ddrl):
     g, g64 = learner.export(_lib.SAC1_GRAD).cpu().numpy(), o64.flat("grads")
     assert np.abs(g - g64).max() <= 1e-3 * np.abs(g64).max()
     assert np.abs(learner.export(_lib.SAC1_MAIN).cpu().numpy() - o64.flat("main")).max() <= 2e-2 * cfg.lr
+
+
+def test_two_thousand_updates_stay_with_the_float32_and_float64_oracles(ddrl):
+    """Long-horizon agreement (the 20-update test and the determinism soaks cannot see a slow drift — a running beta^t
+    product, a polyak image, a double-buffered operand one update stale): 2 000 sequential updates on one seeded batch stream with the
+    float32 and the float64 oracle stepped beside the HIP learner (tests/_long_horizon.py; table of a run: profiles/r05_long_horizon.txt).
+    Two float32 trajectories of relu networks separate chaotically from the float64 one (both reach 4e-2 of max |value| after 2 000
+    updates), so the band is the float32 ORACLE's own separation, not a constant:
+      * every window of 200 updates, every loss: median |relative deviation from float64| of HIP <= 2.5 x the float32 oracle's + 2e-6
+        (observed: 0.6-1.3 x);
+      * main / target / Adam m / Adam v at updates 100 .. 2000: rms deviation of HIP <= 2 x the float32 oracle's (observed 0.9-1.1 x),
+        at updates 1 and 10 below the float32 oracle's own (the literal (pi - mu) / std of the reference cancels in float32);
+      * no trend: the HIP / oracle ratio of those rms deviations at update 2000 is not above 1.5 x the ratio at update 100."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _long_horizon as lh
+    opt, learner, cfg = _mk(ddrl, 4)
+    params = so.init_params(cfg, 4)
+    rs = np.random.RandomState(14)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.05, 0.05, params[k].shape).astype(np.float32)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, threads))   # small matrices: a few threads are faster than a whole host
+    try:
+        res = lh.run(learner, cfg, params, 2000)
+    finally:
+        torch.set_num_threads(threads)
+    lines = []
+    lh.report(res, lines.append)
+    text = "\n".join(lines)
+    rh, r32 = np.abs(res["rel_hip"]), np.abs(res["rel_32"])
+    for s in range(0, 2000, 200):
+        for i, k in enumerate(lh.LOSSES):
+            mh, m32 = np.median(rh[s:s + 200, i]), np.median(r32[s:s + 200, i])
+            assert mh <= 2.5 * m32 + 2e-6, "updates %d-%d %s: HIP %.2e vs float32 oracle %.2e\n%s" % (s + 1, s + 200, k, mh, m32, text)
+    rows = {r["update"]: r for r in res["table"]}
+    for upd, row in rows.items():
+        for name in ("main", "target", "m", "v"):
+            rms_hip, rms_32 = row[name][2], row[name][3]
+            if upd >= 100:
+                assert rms_hip <= 2.0 * rms_32 + 1e-9, "update %d %s: rms deviation HIP %.2e vs float32 oracle %.2e\n%s" % (upd, name, rms_hip, rms_32, text)
+            else:
+                assert rms_hip <= rms_32 + 1e-9, "update %d %s: rms deviation HIP %.2e above the float32 oracle's %.2e\n%s" % (upd, name, rms_hip, rms_32, text)
+    for name in ("main", "target", "m"):
+        early, late = rows[100][name][2] / rows[100][name][3], rows[2000][name][2] / rows[2000][name][3]
+        assert late <= 1.5 * max(early, 1.0), "%s: HIP / oracle deviation ratio grew from %.2f (update 100) to %.2f (update 2000)\n%s" % (name, early, late, text)
+    assert learner.opt_steps() == (2000, 2000)

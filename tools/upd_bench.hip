@@ -37,11 +37,8 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 4; ++i) if (one() != DDRL_OK) { printf("step failed: %s\n", ddrl_last_error()); return 1; }
     hipStreamSynchronize(s);
     hipGraph_t g; hipGraphExec_t ge;
-    const bool defer = getenv("DDRL_DEFER_QW") && atoi(getenv("DDRL_DEFER_QW")) != 0;   // cross-update deferral of the Q wgrad / Adam tiles (k_f0x)
     hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (defer) printf("defer: %d (0 = on, 1 = shape never defers)\n", ddrl_sac1_internal_defer(h, 1));
     for (int i = 0; i < per_graph; ++i) one();
-    if (defer) { ddrl_sac1_internal_flush(h, s); ddrl_sac1_internal_defer(h, 0); }
     ddrl_sac1_internal_opt_sync(h, s);
     hipStreamEndCapture(s, &g);
     if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return 1; }
@@ -57,14 +54,12 @@ int main(int argc, char **argv) {
     printf("graph of %d updates: %.2f us/update (%s)\n", per_graph, best * 1000.f / (4 * per_graph), hipGetErrorString(hipGetLastError()));
 #ifdef DDRL_STAMPS
     unsigned long long *st;
-    const size_t NS = (size_t)6 * 1024 * 16;
+    const size_t NS = (size_t)5 * 1024 * 16;
     hipMalloc(&st, NS * 8); hipMemset(st, 0, NS * 8);
     g_st_host = st;   // the stamp pointer travels in the kernel arguments: capture the same graph again, now stamped
     hipGraph_t g2; hipGraphExec_t ge2;
     hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (defer) ddrl_sac1_internal_defer(h, 1);
     for (int i = 0; i < per_graph; ++i) one();
-    if (defer) { ddrl_sac1_internal_flush(h, s); ddrl_sac1_internal_defer(h, 0); }
     ddrl_sac1_internal_opt_sync(h, s);
     hipStreamEndCapture(s, &g2);
     if (hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return 1; }
@@ -78,10 +73,10 @@ int main(int argc, char **argv) {
     auto anatomy = [&](const char *title) {
     printf("---- %s\n", title);
     hipMemcpy(hs.data(), st, NS * 8, hipMemcpyDeviceToHost);
-    const char *kn[6] = {"k_dfwd<0>", "k_dfwd<1>", "k_dg bq", "k_dg mid", "k_dg pi", "f0x: deferred dg tiles (same launch as k_dfwd<0>)"};
+    const char *kn[5] = {"k_dfwd<0>", "k_dfwd<1>", "k_dg bq", "k_dg mid", "k_dg pi"};
     const char *pn[6] = {"", "loads-issued", "prologue", "k-loop", "combine-bar", "epilogue"};
     unsigned long long prev_end = 0;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 5; ++k) {
         double ph[6] = {0}, tot = 0; int nwg = 0;
         unsigned long long rmin = ~0ull, rmax = 0, rstart_max = 0, lmax = 0;
         for (int b = 0; b < 1024; ++b) {
@@ -98,7 +93,7 @@ int main(int argc, char **argv) {
                (rmax - rmin) / 100.0, (rstart_max - rmin) / 100.0, prev_end ? ((double)rmin - (double)prev_end) / 100.0 : 0.0);
         for (int i = 1; i < 6; ++i) printf(" %s=%.0f", pn[i], ph[i] / nwg);
         printf(" | mean total %.0f max %llu\n", tot / nwg, lmax);
-        if (k < 5) prev_end = rmax;
+        prev_end = rmax;
         // per job of a k_dg launch: when its workgroups start / end relative to the launch's first start (100 MHz real-time counter)
         const DGJobs *J = k == 2 ? &h->dg_bq[0] : (k == 3 ? &h->dg_mid : (k == 4 ? &h->dg_pi : nullptr));
         if (J) {
