@@ -312,6 +312,7 @@ struct ddrl_dqn {
     SkFrag *sk_frags_d;
     float *sk_slab;
     int *sk_flag;
+    int *sk_err_h;                   // pinned, device-visible: k_wide_sk's sticky "combine timed out" word
 };
 
 extern "C" {
@@ -321,6 +322,7 @@ int ddrl_dqn_destroy(ddrl_dqn_t *h) {
     ddrl::DeviceGuard g(h->device);
     (void)hipFree(h->slab);
     (void)hipFree(h->sk_frags_d); (void)hipFree(h->sk_slab); (void)hipFree(h->sk_flag);
+    if (h->sk_err_h) (void)hipHostFree(h->sk_err_h);
     delete h;
     return DDRL_OK;
 }
@@ -451,7 +453,7 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         }
     }
     if (h->wide) { h->wf.part = h->wpart; h->wf.consts = h->wconsts; h->wf.a_rows = B; h->wf.ldo = h->ldh1; }
-    h->sk_on = false; h->sk_frags_d = nullptr; h->sk_slab = nullptr; h->sk_flag = nullptr;
+    h->sk_on = false; h->sk_frags_d = nullptr; h->sk_slab = nullptr; h->sk_flag = nullptr; h->sk_err_h = nullptr;
     if (h->wide && !(getenv("DDRL_WIDE_SK") && atoi(getenv("DDRL_WIDE_SK")) == 0)) {
         // the wgrad as equal shares of the stage sequence over <= 512 resident workgroups (two per CU) when the shape splits that way
         int ncu = 256;
@@ -465,10 +467,13 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&h->sk_flag, (size_t)(nwg + 1) * sizeof(int));
             if (e2 == hipSuccess) e2 = hipMemset(h->sk_flag, 0, (size_t)(nwg + 1) * sizeof(int));
             if (e2 == hipSuccess) e2 = hipMemcpy(h->sk_frags_d, fr.data(), fr.size() * sizeof(SkFrag), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipHostMalloc((void **)&h->sk_err_h, sizeof(int), hipHostMallocMapped);
             if (e2 == hipSuccess) {
+                *h->sk_err_h = 0;
                 for (int n = 0; n < h->nnet; ++n) {
                     h->sk[n].w = h->ww[n]; h->sk[n].frags = h->sk_frags_d; h->sk[n].slab = h->sk_slab; h->sk[n].flag = h->sk_flag;
                     h->sk[n].nwg = nwg; h->sk[n].epoch = n + 1;   // (the networks' launches of one update share the flags: one epoch each)
+                    h->sk[n].err = h->sk_err_h;
                 }
                 h->sk_on = true;
             }
@@ -556,6 +561,15 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
                            float *loss_d, float *q_d, hipStream_t s, hipEvent_t *ev, const long long *ridx = nullptr) {
     const int B = h->cfg.batch, o = h->cfg.obs_dim;
     int e = 0;
+    if (h->sk_on && h->sk_err_h && *h->sk_err_h) {   // a stream-K combine of an EARLIER step gave up waiting for its partner (sticky, host-mapped word)
+        *h->sk_err_h = 0;
+        h->sk_on = false;
+        h->head.zero_words = nullptr; h->head.n_zero = 0;
+        ddrl::set_error("k_wide_sk: a split tile's partner did not publish within ~1 s (workgroups of the launch not co-resident: shared GPU or "
+                        "serialising profiler?) — the layer-1 gradient of an earlier update was wrong; this learner now uses the tile-per-workgroup "
+                        "kernel (DDRL_WIDE_SK=0 selects it from the start).  Restore the parameters from a checkpoint.");
+        return DDRL_ERR_HIP;
+    }
 #define STAGE_MARK() do { if (ev) DDRL_HIP_CHECK(hipEventRecord(ev[e++], s)); } while (0)
     STAGE_MARK();
     // wide layer 1 reads the caller's observation rows in place (16-byte aligned rows: obs_dim % 4 == 0 there) and the head kernel

@@ -751,6 +751,9 @@ struct ddrl_sac1 {
     int Lp1, Lp2;
     float *H1r4, *H2c4, *H2r4, *dZ1r4, *dzpi_c4, *dzpi_r4, *dhead_r4, *xa_r4, *da_part, *dq, *w3snap, *xp_r4;
     float *c4_pi[2], *c4_q[3];   // c4_q[2]: V (SAC-v)
+    float *c4_q2b;               // second copy of c4_q[1]: double-buffered like the policy's when part of the q2(x, a) dgrad runs in launch "mid",
+                                 // where the optimizer epilogue of q2's layer-2 wgrad writes the NEXT image (copy sh_cur = current, sh_cur ^ 1 = next)
+    int mid_rest_job;            // index of that dgrad's job in dg_mid (-1: none)
     float *xv_r4;                // SAC-v: the [x | 1] image of V's layer-1 wgrad
     int *part_cnt;       // arrival counters of the policy layer-1 partials (one per column tile)
     int sh_cur;          // which copy of the policy dgrad image is current (the optimizer epilogue writes the other one)
@@ -1060,6 +1063,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
     ddrl::DeviceGuard g(device);
     if (!g.ok) { ddrl::set_error("cannot select device %d", device); return DDRL_ERR_HIP; }
     ddrl_sac1 *h = new ddrl_sac1();  // value-initialised: every pointer/job table starts zeroed
+    h->mid_rest_job = -1;            // (no Q dgrad columns in launch "mid" unless the SAC1 direct build below splits them off)
     h->device = device;
     h->cfg = *cfg;
     h->fused = direct_ok(*cfg);
@@ -1102,6 +1106,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
         ALLOC(dq, (size_t)3 * B + 256); ALLOC(w3snap, (size_t)3 * 512);
         for (int i = 0; i < 2; ++i) items.push_back(Item{&h->c4_pi[i], reserve((size_t)Np2 * Kp1)});
         for (int i = 0; i < 2 + xv; ++i) items.push_back(Item{&h->c4_q[i], reserve((size_t)Np2 * Kp1)});
+        items.push_back(Item{&h->c4_q2b, reserve((size_t)Np2 * Kp1)});
     }
     ALLOC(xa, (size_t)B * h->ldxa); ALLOC(xp, (size_t)B * h->ldxp);
     ALLOC(act0, B * a); ALLOC(act2, B * a); ALLOC(logp0, B); ALLOC(logp1, B); ALLOC(save0, (size_t)B * a * 4);
@@ -1383,6 +1388,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 dg_add(M, j);
             }
             const bool split = h->bq_cols < (h1 + 31) / 32;
+            h->mid_rest_job = -1;
             if (!split) {
                 for (int q = 0; q < 2; ++q) dg_add(M, wgrad_rm(h->H2r4 + (1 + q) * H2R, h->Lp2, h2 + 1, h->dq + (long long)q * B, 1, 1, L.q_W3[q]));
             } else {
@@ -1393,6 +1399,7 @@ int ddrl_sac1_create(ddrl_sac1_t **out, int device, const ddrl_sac1_config_t *cf
                 M.rew = Q0.rew; M.done = Q0.done; M.logp0 = Q0.logp0; M.logp1 = Q0.logp1;   // (rew / done: launch_stage sets the input set's)
                 M.q1o = Q0.q1o; M.q2o = Q0.q2o; M.dq = Q0.dq; M.loss_part = Q0.loss_part;
                 M.alpha = Q0.alpha; M.gamma = Q0.gamma;
+                h->mid_rest_job = M.njobs;
                 dg_add(M, h->bq_rest);
             }
         }
@@ -1586,7 +1593,7 @@ static void refresh_shadows(ddrl_sac1 *h, hipStream_t s) {
     ShadowJobs sj{};
     int n = 0;
     sj.j4[n] = h->main_p + L.pi_W2; sj.c4[n++] = h->c4_pi[h->sh_cur];
-    for (int q = 0; q < 2; ++q) { sj.j4[n] = h->main_p + L.q_W2[q]; sj.c4[n++] = h->c4_q[q]; }
+    for (int q = 0; q < 2; ++q) { sj.j4[n] = h->main_p + L.q_W2[q]; sj.c4[n++] = (q == 1 && h->mid_rest_job >= 0 && h->sh_cur) ? h->c4_q2b : h->c4_q[q]; }
     if (h->cfg.variant == DDRL_SAC_V) { sj.j4[n] = h->main_p + L.v_W2; sj.c4[n++] = h->c4_q[2]; }
     k_shadow<<<dim3((h1 + 31) / 32, (h2 / 4 + 7) / 8, n), 256, 0, s>>>(sj, h1, h2, L.Np2, L.Kp1);   // one launch for all networks
 }
@@ -1617,13 +1624,26 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                 launch_dfwd<1>(h->fh_b[st], F, s);
                 break;
             }
-            case 7: launch_dg(h->dg_bq[st], s, 2); break;
+            case 7: {
+                DGJobs &J = h->dg_bq[st];
+                if (h->mid_rest_job >= 0) J.job[2].B = h->sh_cur ? h->c4_q2b : h->c4_q[1];   // q2(x, a) dgrad: the current image of q2's layer-2 kernel
+                launch_dg(J, s, 2);
+                break;
+            }
             case 8: {
                 DGJobs &J = h->dg_mid;
                 J.ad.on = h->fuse_apply ? 1 : 0;
                 J.ad.opt = h->opt + h->opt_cur;
                 J.job[0].B = h->c4_pi[h->sh_cur];           // the policy dgrad reads this update's image of the policy's layer-2 kernel ...
                 J.rew = h->dg_bq[st].rew; J.done = h->dg_bq[st].done;   // (read by the Q dgrad columns that run here, if any)
+                if (h->mid_rest_job >= 0) {
+                    // those columns read the CURRENT image of q2's layer-2 kernel while the optimizer epilogue of q2's layer-2 wgrad (job 3 of
+                    // this launch) writes the next one: two copies, like the policy's (found by the graph == eager test: with one copy the
+                    // dgrad saw a half-stepped kernel)
+                    float *cur = h->sh_cur ? h->c4_q2b : h->c4_q[1], *nxt = h->sh_cur ? h->c4_q[1] : h->c4_q2b;
+                    J.job[h->mid_rest_job].B = cur + (long long)h->bq_cols * 32 * 4;
+                    J.job[3].shadow = J.ad.on ? nxt : nullptr;
+                }
                 launch_dg(J, s, 3);
                 break;
             }
@@ -1848,6 +1868,9 @@ int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
     if (h->fused && h->sh_cur != 0) {  // same for the double-buffered dgrad image of the policy's layer-2 kernel
         DDRL_HIP_CHECK(hipMemcpyAsync(h->c4_pi[0], h->c4_pi[1], (size_t)h->L.Np2 * h->L.Kp1 * sizeof(float), hipMemcpyDeviceToDevice,
                                       ddrl::as_stream(stream)));
+        if (h->mid_rest_job >= 0)      // ... and of q2's, when it is double-buffered too
+            DDRL_HIP_CHECK(hipMemcpyAsync(h->c4_q[1], h->c4_q2b, (size_t)h->L.Np2 * h->L.Kp1 * sizeof(float), hipMemcpyDeviceToDevice,
+                                          ddrl::as_stream(stream)));
         h->sh_cur = 0;
     }
     return DDRL_OK;

@@ -632,7 +632,11 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
             w1[bi][4 * q + 0] = v.x; w1[bi][4 * q + 1] = v.y; w1[bi][4 * q + 2] = v.z; w1[bi][4 * q + 3] = v.w;
         }
     }
-    float4 bq[2][4][4];
+    // OCC = 1: the W2 groups double-buffered by tile parity.  OCC = 2 (two workgroups per CU, 256 registers): ONE set — the group of tile
+    // t + 1 is requested into the registers of the same group of tile t right behind the MFMAs that consumed it (the same one-tile prefetch
+    // distance with 64 registers less: the double-buffered form spilled 64 registers to scratch at this budget)
+    constexpr int NBUF = OCC == 2 ? 1 : 2;
+    float4 bq[NBUF][4][4];
     const int lane_off = (h * Np + l31) * 4;
     auto fetch_group = [&](int buf, int t, int bi, int rq) {  // one W2 group (8 hidden-1 units x 32 columns) of column tile t
         // wave-uniform base (scalar registers) + one per-lane offset shared by every group: no vector address arithmetic per load
@@ -702,7 +706,7 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         if (rq < nrq) {
-                            const float4 b = bq[t & 1][bi][rq];
+                            const float4 b = bq[t & (NBUF - 1)][bi][rq];
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 0], b.x, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 1], b.y, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[bi][4 * rq + 2], b.z, acc, 0, 0, 0);
@@ -710,13 +714,13 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
                         }
                         if (t + 1 < ANT) {  // the same group of the next column tile, requested between this group's MFMAs and the next's
                             __builtin_amdgcn_sched_barrier(0);
-                            fetch_group((t + 1) & 1, t + 1, bi, rq);
+                            fetch_group((t + 1) & (NBUF - 1), t + 1, bi, rq);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 } else if (t + 1 < ANT) {
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) fetch_group((t + 1) & 1, t + 1, bi, rq);
+                    for (int rq = 0; rq < 4; ++rq) fetch_group((t + 1) & (NBUF - 1), t + 1, bi, rq);
                 }
             }
             AST(3 + 5 * t);

@@ -107,9 +107,10 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     // What lies outside the matrices comes from a 16-byte block of zeros, the gradient's bias row from {1, 0, 0, 0}.
     constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;   // pieces per wave and stage: 4 of A, 5 of B
     static_assert(APW * WV * 256 == AOP && BPW * WV * 256 == WD_BOP, "the LDS images are dealt to the waves in whole 1 KB pieces");
+    static_assert(WV == 4 && WD_KB == 32, "a B image of 32 k x 32 NU columns is 4 NU pieces: NU per wave of four");
     const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
-    const float *pa[APW], *pb[BPW];
-    int ak[APW], bk[BPW];   // k offset inside a stage of what this lane loads (forward A: of its chunk; else of its k row)
+    const float *pa[APW];
+    int ak[APW];            // k offset inside a stage of what this lane loads (forward A: of its chunk; else of its k row)
     int amode = 1;          // wgrad: 1 data, 2 the bias row's constant, 0 beyond it
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
@@ -126,17 +127,15 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
             pa[i] = E.A + (long long)kk * E.lda + (amode == 1 ? i0 : 0);
         }
     }
-#pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-        const int f4 = 64 * (BPW * w + j) + lane, kk = f4 / (WD_BW / 4), c4 = f4 - kk * (WD_BW / 4);
-        bk[j] = kk;
-        pb[j] = (c4 < NU * 8 && n0 + 4 * c4 < a.N) ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;   // N % 4 == 0
-    }
+    // The B image of a tile is as wide as the tile: [32 k][32 NU columns] = NU pieces per wave and stage (round 4 staged 160 columns for
+    // every tile: a 4-unit tile then issued one DMA instruction of nine per wave and stage for nothing but zeros — and the issue of a
+    // stage's pieces, ~1-2 k cycles per wave, is what the matrix pipe waits for).  The pointer table and the issue are therefore part of
+    // the per-NU instance of the stage loop (run()).
     // a stage's pieces, all issued at the top of the stage before (dealing them between that stage's MFMA groups instead measured
     // the same: 359 vs 345 us at config 5 — the texture path takes ~1 k cycles per CU and stage either way)
-    auto issue = [&](int st, int buf) {
+    auto issue_a = [&](int st, int buf) {
         const int k = st * WD_KB;
-        const unsigned dA = lds_addr(sA + buf * AOP + 256 * APW * w), dB = lds_addr(sB + buf * WD_BOP + 256 * BPW * w);
+        const unsigned dA = lds_addr(sA + buf * AOP + 256 * APW * w);
 #pragma unroll
         for (int g = 0; g < APW; ++g) {
             const float *src;
@@ -144,8 +143,6 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
             else src = amode == 2 ? ones_blk : (amode == 1 && k + ak[g] < a.K) ? pa[g] + (long long)k * E.lda : zero_blk;
             glds16(src, dA + 1024 * g);
         }
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
     };
     floatx16 acc[WD_NB];
 #pragma unroll
@@ -169,7 +166,7 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
 #pragma unroll
             for (int u = 0; u < NUC; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * WD_BW + 32 * u + l31];
+                for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * (32 * NUC) + 32 * u + l31];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -178,6 +175,22 @@ __global__ void __launch_bounds__(64 * WV, 2) k_wide(WideArgs a) {
     };
     // the stage loop, one instance per NU (dispatching inside the loop made the compiler shuffle the accumulators between variants)
     auto run = [&](auto nu_c) {
+        constexpr int NUC = decltype(nu_c)::value;
+        const float *pb[NUC];
+        int bk[NUC];
+#pragma unroll
+        for (int j = 0; j < NUC; ++j) {
+            const int f4 = 64 * (NUC * w + j) + lane, kk = f4 / (8 * NUC), c4 = f4 - kk * (8 * NUC);
+            bk[j] = kk;
+            pb[j] = n0 + 4 * c4 < a.N ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;   // N % 4 == 0
+        }
+        auto issue = [&](int st, int buf) {
+            issue_a(st, buf);
+            const int k = st * WD_KB;
+            const unsigned dB = lds_addr(sB + buf * WD_BOP + 256 * NUC * w);
+#pragma unroll
+            for (int j = 0; j < NUC; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
+        };
         issue(st0, 0);
         wide_dma_wait();
         __syncthreads();
@@ -279,6 +292,7 @@ struct SkArgs {
     float *slab;           // [nwg][4 waves][WD_NB][16 regs][64 lanes]
     int *flag;             // [nwg]
     int nwg, epoch;
+    int *err;              // host-mapped sticky word: 1 = a combine ran out of patience (read by the host at the next step)
 };
 __device__ __forceinline__ void sk_store_sc1(float *p, float4 v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -305,6 +319,8 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
         const int NU = a.nu[c];
         const int unit0 = c ? a.cnt[0] * a.nu[0] + (ct - a.cnt[0]) * NU : ct * NU;
         const int m0 = mt * ROWS, n0 = unit0 * 32;
+        // (the B image stays 160 columns wide here whatever the tile's units: as wide as the tile — k_wide's form — this kernel, at the
+        // 256-register cap with 53 registers spilled, spills 107)
         const float *pa[APW], *pb[BPW];
         int ak[APW], bk[BPW], amode = 1;
 #pragma unroll
@@ -395,8 +411,11 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
             // stale L1 lines, its vmcnt drain holds the barrier for the invalidate, then every wave reads the slab with plain loads
             // (all of them in flight at once)
             // The spin is bounded: the successor publishes as its FIRST action, so with the dispatcher's in-order placement the word is
-            // there long before it is asked for — but dispatch order is no contract, so after ~1 s the kernel traps (a loud HIP error on the
-            // next call) instead of hanging the device.  (Measured alternatives that kept computing instead — this workgroup finishing the
+            // there long before it is asked for — but dispatch order is no contract (a shared GPU, a profiler serialising workgroups), so
+            // after ~1 s the workgroup gives up: it raises the sticky host-mapped error word and goes on with whatever the slab holds —
+            // this update's layer-1 gradient is then WRONG, and the next ddrl_dqn_step* call returns DDRL_ERR_HIP saying so and switches
+            // this learner to the tile-per-workgroup kernel (round 4 trapped here, which took the whole HIP context down).
+            // (Measured alternatives that kept computing instead — this workgroup finishing the
             // tile's remaining stages itself — cost the fast path 8-14 us of the 11 us gained: a second call site of the stage loop,
             // accumulators live across the fragment loop, or a second __shared__ object, which makes hipcc wait vmcnt(0) before every
             // ds_read behind the LDS-DMA loads: 130 -> 182 us.)
@@ -404,7 +423,7 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
                 int spin = 0;
                 while (__hip_atomic_load(sa.flag + wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sa.epoch) {
                     __builtin_amdgcn_s_sleep(16);
-                    if (++spin > (1 << 21)) __builtin_trap();
+                    if (++spin > (1 << 21)) { __hip_atomic_store(sa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -25,9 +25,11 @@ def rows(name):
 
 
 fetch, write, sq = rows("pmc_FETCH_SIZE.txt"), rows("pmc_WRITE_SIZE.txt"), rows("pmc_sq.txt")
-# the update's five launches, identified by kernel + grid (config 2: 240 / 400 forward tiles; 312 / 464 / 190 backward tiles)
-want = [("k_dfwd<0>", "k_dfwd<0,", 240 * 256), ("k_dfwd<1>", "k_dfwd<1,", 400 * 256), ("k_dg bq", "k_dg<10>", 312 * 256),
-        ("k_dg mid", "k_dg<10>", 464 * 256), ("k_dg pi", "k_dg<10>", 190 * 256)]
+# the update's five launches, identified by kernel + grid (config 2: 240 / 400 forward tiles; backward tiles 256 / 500 / 210 since round 5's
+# re-split, 312 / 464 / 190 before it and with DDRL_BQ_SPLIT=0)
+bwd = (256, 500, 210) if any(k[0].startswith("k_dg<10>") and k[1] == 500 * 256 for k in fetch) else (312, 464, 190)
+want = [("k_dfwd<0>", "k_dfwd<0,", 240 * 256), ("k_dfwd<1>", "k_dfwd<1,", 400 * 256), ("k_dg bq", "k_dg<10>", bwd[0] * 256),
+        ("k_dg mid", "k_dg<10>", bwd[1] * 256), ("k_dg pi", "k_dg<10>", bwd[2] * 256)]
 per, lines = {}, []
 for label, kname, grid in want:
     key = next((k for k in fetch if k[0].startswith(kname.rstrip(",")) and k[1] == grid), None)
