@@ -607,8 +607,9 @@ class RolloutDevice:
         if layout != self._layout:          # a key entered or left the server's flat table since the span was looked up
             self.span, self._layout = self.ps.span(self.actor.keys), layout
         if self.span is not None:
+            import torch
             flat = getattr(self.ps, "flat", None)
-            if flat is not None:    # same device, same stream: the pack kernel reads the server's buffer in place (its copy IS the snapshot)
+            if torch.is_tensor(flat):   # same device, same stream: the pack kernel reads the server's buffer in place (its copy IS the snapshot)
                 self.actor.set_weights_flat(flat[self.span[0]:self.span[0] + self.span[1]])
             else:
                 self.actor.set_weights_flat(self.ps.pull_flat(*self.span))

@@ -457,14 +457,15 @@ def _decode_version(acts):
     return d[0] + 40 * d[1]
 
 
-@pytest.mark.parametrize("n,limit,steps", [(64, 7, 60), (160, 23, 90), (4096, 70, 170), (1024, 300, 330)])
+@pytest.mark.parametrize("n,limit,steps", [(64, 7, 60), (160, 23, 90), (4096, 70, 170), (1024, 300, 330), (10240, 40, 100)])
 def test_vectorised_rollout_equals_n_reference_workers_in_the_weights_each_env_acts_on(n, limit, steps):
     """Bar (1) for the vectorised rollout: the reference runs one worker per env and each pulls the server's weights at ITS OWN
     episode end (example/dsac.py:127-130: o = env.reset(); weights = ps.pull(keys); agent.set_weights(keys, weights)) and acts on
     them until its next one.  RolloutDevice(adopt="episode") must act, for every env and every step, on EXACTLY the version that
     env's own worker_rollout would hold: the one the server held when the env's last episode ended (the initial pull before its
     first).  Bias-coded versions make the version behind every stored action readable; pushes land between vector steps, bursts
-    of them, long pauses (the single-version fast path), and up to min(n, limit) + 1 versions are live at once."""
+    of them, long pauses (the single-version fast path), and up to min(n, limit) + 1 versions are live at once.  (10 240 envs: more
+    than the planning kernel keeps in registers — eight per thread — so the last 2 048 take its parked-position path.)"""
     import distributed_drl_amd as ddrl
     from distributed_drl_amd.agent import HyperParameters, Learner
     from distributed_drl_amd.workers import RolloutDevice
