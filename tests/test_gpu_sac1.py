@@ -546,3 +546,39 @@ def test_two_thousand_updates_stay_with_the_float32_and_float64_oracles(ddrl):
         early, late = rows[100][name][2] / rows[100][name][3], rows[2000][name][2] / rows[2000][name][3]
         assert late <= 1.5 * max(early, 1.0), "%s: HIP / oracle deviation ratio grew from %.2f (update 100) to %.2f (update 2000)\n%s" % (name, early, late, text)
     assert learner.opt_steps() == (2000, 2000)
+
+
+def test_launch_table_resplit_is_bit_identical_to_the_unsplit_tables(tmp_path):
+    """Round 5 moved work between the update's launches (part of the q2(x, a) dgrad from launch "bq" to "mid", the Q-head wgrads from "mid"
+    to "pi", a second copy of q2's dgrad image) to keep every launch under a multiple of 256 tiles.  Same arithmetic per tile: after 40
+    graph-loop updates the parameters, targets and Adam moments must equal — bit for bit — those of the round-4 tables (DDRL_BQ_SPLIT=0,
+    read when a learner is created: one process per setting)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, zlib
+sys.path.insert(0, %r)
+import numpy as np, torch
+import distributed_drl_amd as d
+from distributed_drl_amd import _lib
+from distributed_drl_amd.agent import HyperParameters
+from distributed_drl_amd.workers import TrainDevice
+opt = HyperParameters(); opt.seed, opt.batch_size, opt.push_freq = 7, 256, 10 ** 9
+rs = np.random.RandomState(0); n = 6000
+rb = d.ReplayBufferSAC1(8, 2, 8192, seed=11)
+rb.store_batch(*(torch.from_numpy(x).cuda() for x in (rs.randn(n, 8).astype(np.float32), rs.uniform(-1, 1, (n, 2)).astype(np.float32),
+                 rs.randn(n).astype(np.float32), rs.randn(n, 8).astype(np.float32), (rs.rand(n) < 0.05).astype(np.float32))))
+td = TrainDevice(None, rb, opt, updates_per_graph=8)
+td.run(40)
+torch.cuda.synchronize()
+print("CRC", [zlib.crc32(td.agent.export(w).cpu().numpy().tobytes()) for w in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V)], td.agent.opt_steps())
+""" % root
+    out = {}
+    for split in ("1", "0"):
+        env = dict(os.environ, DDRL_BQ_SPLIT=split)
+        p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-2000:]
+        out[split] = [l for l in p.stdout.decode().splitlines() if l.startswith("CRC")][0]
+    assert out["1"] == out["0"], out

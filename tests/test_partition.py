@@ -85,6 +85,7 @@ def _rows(rb, idx):
 # (envs per rollout rank, batch, shard capacity, rows pre-filled, updates) — the toy the first tests run, and BASELINE config 4's own sizes:
 # 6 x 8192 envs, batch 256, 10^6 transitions over 6 shards (bench.py: capacity // shards), pre-filled so that the rings WRAP within the run
 TOY = (64, 32, 4096, 500, 14)
+CONFIG3 = (4096, 256, 10 ** 6 // 2, 480000, 10)
 CONFIG4 = (8192, 256, 10 ** 6 // 6, 120000, 10)
 
 
@@ -277,6 +278,13 @@ def test_config4_roles_three_ranks_on_one_gpu_two_learners_one_shard():
     """Config 4's roles at the smallest size (2 data-parallel learner ranks + 1 rollout rank with the shard): the owner
     serves both learners' blocks, the learners all-reduce their gradients and stay bit-identical."""
     _spawn(3, 2)
+
+
+@pytest.mark.gpu
+def test_config3_at_its_own_sizes_two_ranks_on_one_gpu():
+    """BASELINE config 3 as stated — the 10^6-transition replay sharded over 2 ranks (500 000 each, wrapping during the run), 4096 envs per
+    rank, batch 256, learner on rank 0 — batch by batch against NumPy's stream, like the toy run above."""
+    _spawn(2, None, extra=(CONFIG3,), timeout=600)
 
 
 @pytest.mark.gpu
