@@ -222,9 +222,58 @@ class Learner(_Net):
         t_pi, t_q, ctr = (int(x) for x in z["opt"])
         _lib.check(self._lib.ddrl_sac1_opt_state_set(self._h, t_pi, t_q, ctr, _lib.stream_ptr()))
 
+    def _host_fast(self, batch):
+        """train(replay_buffer.sample_batch()) — the reference's learner loop body with HOST arrays (example/dsac.py:142-144) — without any
+        staging launch: the five arrays go up as ONE asynchronous copy out of a page-locked block (two of them, alternating behind events)
+        straight INTO the learner's input set 0, the three noise tensors are generated in place behind it, and the update reads the input
+        set it owns (ddrl_sac1_step then skips its copy launch).  Same values, same noise stream positions as the general path.
+        -> the 12 pointers of ddrl_sac1_step, or None when the input set's items do not lie the way this needs."""
+        B, o, a = self.cfg.batch, self.cfg.obs_dim, self.cfg.act_dim
+        st = getattr(self, "_fast", None)
+        if st is None:
+            bufs = (ctypes.c_void_p * 8)()
+            _lib.check(self._lib.ddrl_sac1_input_buffers(self._h, 0, bufs))
+            p = [int(bufs[i]) for i in range(8)]
+            n = (B * o, B * o, B * a, B, B)
+            off = [(p[j] - p[0]) // 4 for j in range(5)]
+            ok = all((p[j] - p[0]) % 4 == 0 for j in range(5)) and all(off[j] + n[j] <= off[j + 1] for j in range(4)) and off[4] + B <= 4 * sum(n)
+            if not ok:
+                st = self._fast = False
+            else:
+                from .replay import _view
+                span = off[4] + B
+                hosts = [torch.zeros(span, dtype=torch.float32).pin_memory() for _ in range(2)]
+                st = self._fast = {"p": p, "off": off, "n": n, "dev": _view(p[0], (span,), self.device), "host": hosts, "np": [h.numpy() for h in hosts],
+                                   "ev": [None, None], "turn": 0, "eps_contig": p[6] - p[5] == 4 * B * a and p[7] - p[6] == 4 * B * a}
+        if st is False:
+            return None
+        t = st["turn"]
+        st["turn"] = t ^ 1
+        if st["ev"][t] is not None:
+            st["ev"][t].synchronize()                 # the copy that last read this staging block has left it
+        hv, off, n = st["np"][t], st["off"], st["n"]
+        for j, k in enumerate(("obs1", "obs2", "acts", "rews", "done")):
+            hv[off[j]:off[j] + n[j]] = np.asarray(batch[k], dtype=np.float32).reshape(n[j])
+        st["dev"].copy_(st["host"][t], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["ev"][t] = ev
+        p, m, s = st["p"], B * a, _lib.stream_ptr()
+        if st["eps_contig"]:
+            _lib.check(self._lib.ddrl_normal_fill(p[5], 3 * m, self._noise_seed, self._noise_ctr, s))
+        else:
+            for i in range(3):
+                _lib.check(self._lib.ddrl_normal_fill(p[5 + i], m, self._noise_seed, self._noise_ctr + i * m, s))
+        self._noise_ctr += 3 * m
+        return p + [_lib.dptr(self.losses), None, None, None]
+
     def _args(self, batch, eps, outs):
         B, a = self.cfg.batch, self.cfg.act_dim
         if all(isinstance(batch[k], np.ndarray) for k in ("obs1", "obs2", "acts", "rews", "done")):
+            if eps is None and not outs:
+                ptrs = self._host_fast(batch)
+                if ptrs is not None:
+                    return None, ptrs, (None, None, None)
             x, x2, ac, r, d = self._host_batch(batch)
         else:
             x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))

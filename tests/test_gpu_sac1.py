@@ -582,3 +582,41 @@ print("CRC", [zlib.crc32(td.agent.export(w).cpu().numpy().tobytes()) for w in (_
         assert p.returncode == 0, p.stderr.decode("utf-8", "replace")[-2000:]
         out[split] = [l for l in p.stdout.decode().splitlines() if l.startswith("CRC")][0]
     assert out["1"] == out["0"], out
+
+
+@pytest.mark.parametrize("variant", ["sac1", "sacv"])
+def test_host_batch_fast_path_equals_the_device_path(ddrl, variant):
+    """train(replay_buffer.sample_batch()) with NumPy arrays (the reference's learner loop body, example/dsac.py:142-144) takes a path of
+    its own since round 5 — one asynchronous copy out of alternating page-locked blocks straight into the learner's input set, noise
+    generated in place, no staging launch.  Seven updates (the staging blocks are reused from the third on, with the host mutating its
+    arrays right after every call) must leave parameters, targets and Adam moments bit-identical to the same updates fed as device tensors
+    with the same noise stream positions."""
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import HyperParameters, Learner, Model
+    lib = _lib.load()
+    if variant == "sac1":
+        opt = HyperParameters()
+        opt.seed, opt.batch_size = 5, 256
+        a_, b_ = Learner(opt), Learner(opt)
+        B, o, a = 256, 8, 2
+    else:
+        args = _DsacArgs(batch_size=100, seed=5)
+        a_, b_ = Model(args), Model(args)
+        B, o, a = 100, 8, 2
+    rs = np.random.RandomState(3)
+    ctr = 0
+    for it in range(7):
+        batch = dict(obs1=rs.randn(B, o).astype(np.float32), obs2=rs.randn(B, o).astype(np.float32), acts=rs.uniform(-1, 1, (B, a)).astype(np.float32),
+                     rews=rs.randn(B).astype(np.float32), done=(rs.rand(B) < 0.1).astype(np.float32))
+        dev = {k: torch.from_numpy(v.copy()).cuda() for k, v in batch.items()}
+        a_.train(batch)                                   # NumPy arrays: the fast path
+        for v in batch.values():
+            v += 1.0                                      # the caller's arrays may change as soon as train() has returned
+        e = torch.empty(3 * B * a, device="cuda")
+        _lib.check(lib.ddrl_normal_fill(_lib.dptr(e), e.numel(), b_._noise_seed, ctr, _lib.stream_ptr()))
+        ctr += 3 * B * a
+        e = e.view(3, B, a)
+        b_.train(dev, eps=(e[0], e[1], e[2]))
+    assert a_._fast is not False and a_._noise_ctr == ctr
+    for which in (_lib.SAC1_MAIN, _lib.SAC1_TARGET, _lib.SAC1_ADAM_M, _lib.SAC1_ADAM_V):
+        assert torch.equal(a_.export(which), b_.export(which)), which
