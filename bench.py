@@ -28,7 +28,10 @@ N > 1 — the north star's rank-role partitioning (distributed-drl_amd/partition
 Synthetic data: rings pre-filled to capacity with seeded synthetic transitions; glorot / zeros weights.
 Inputs are resident in HBM when timing starts.
 
-Prints ONE JSON line on rank 0.  `value` = whole-job env-steps/s over EXACTLY --steps steps; `updates_per_s` rides along.
+Prints ONE JSON line on rank 0.  `value` = whole-job env-steps/s over EXACTLY --steps steps; `updates_per_s` (sampled batches consumed, all
+learner ranks) and `optimizer_steps_per_s` (Adam steps of the learner GROUP: data-parallel learners make one from their batches) ride along.
+`series` = the three curves an N-GPU read-out needs, measured apart: the learner group alone, every rollout rank flat out (all ranks at
+once, no learner work), the gated `value`; `config.weak_scaling_why` says which the >= 0.7 target is read against.
 `roofline` prices the launches of one update (fp32 MFMA): algorithmic FLOPs of an update / launches per update, over the
 average launch time measured with HIP events on the launch stream around a learner-only block of graph replays (so
 launch gaps count).  `stages` adds the other rows of SURVEY §8(d): rollout-only, store, sample, the config-5 gather.
