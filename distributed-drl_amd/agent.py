@@ -392,6 +392,11 @@ class Learner(_Net):
             state["cur"] = 0
             _lib.check(lib.ddrl_sac1_graph_sync(h, sp()))
         grads.graph_sync = graph_sync
+
+        def reset():
+            """After an aborted graph capture (nothing it recorded has run): nothing drawn ahead, input set 0 next."""
+            state["cur"], state["primed"] = 0, False
+        grads.reset = reset
         return grads, apply, g
 
     def compute_gradients(self, batch, eps=None):

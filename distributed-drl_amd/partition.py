@@ -338,9 +338,24 @@ class PartitionedRun:
                 comm.allreduce_mean_(self.dp_g, group=self.lgroup)
                 self.dp_apply()
                 n -= 1
-                self._capture_dp()
-            self.dp_grads.graph_sync()
-            while n >= k:
+                # The capture (k updates with their RCCL all-reduce nodes) has only ever run on a world-size-1 group here.  Should a real
+                # multi-GPU group refuse it, the learners agree on that and fall back to the eager step instead of losing the run.
+                ok = 1.0
+                try:
+                    self._capture_dp()
+                except Exception as e:  # noqa
+                    import sys
+                    print("partition: capturing the data-parallel step failed (%r): eager updates from here on" % (e,), file=sys.stderr)
+                    ok = 0.0
+                    torch.cuda.synchronize()
+                    self.dp_grads.reset()                # (what the aborted capture recorded never ran)
+                flag = torch.tensor([ok], dtype=torch.float32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.lgroup)
+                if float(flag.item()) < 0.5:
+                    self.dp_graph, self.dp_per_graph, k = None, 0, 0
+            if k > 0:
+                self.dp_grads.graph_sync()
+            while k > 0 and n >= k:
                 self.dp_graph.replay()
                 n -= k
         for i in range(n):   # (every call ends with nothing drawn ahead: the ring / the plan / a graph may come next)
