@@ -561,9 +561,9 @@ def test_batch_cache_helper_sleeps_when_idle():
     assert calls[0] == 10 and polls[0] < 60          # a spinning helper polls millions of times in half a second
     t0 = _time.perf_counter()
     assert cache.q1.get()["id"] == 1                 # taking a batch wakes it at once
-    for _ in range(200):
+    for _ in range(1000):
         if calls[0] == 11:
             break
         _time.sleep(0.001)
-    assert calls[0] == 11 and _time.perf_counter() - t0 < 0.04
+    assert calls[0] == 11 and _time.perf_counter() - t0 < 0.5    # (an Event wake-up: milliseconds; the bound only has to beat a missed wake-up)
     cache.end()
