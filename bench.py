@@ -55,13 +55,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec (6 290 measured streaming)
 
 
+TRAFFIC_SOURCES = ("ddrl_common.h", "gemm_core.h", "policy_row.h", "replay_device.h", "sac1_direct.h", "sac1.hip")
+
+
 def kernel_source_hash():
-    """sha256 over csrc/*.h, *.hip (sorted by name): profiles/traffic.json records the one its PMC passes were taken on."""
-    import glob
+    """sha256 over the csrc/ files the five profiled launches of the SAC1 update compile from (TRAFFIC_SOURCES, sorted by name):
+    profiles/traffic.json records the one its PMC passes were taken on.  (Until round 6 the hash ran over every file of csrc/, so a
+    change to the lander or to config 5's kernels marked the SAC1 update's counters stale.)"""
     import hashlib
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "distributed-drl_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "distributed-drl_amd", "csrc", "*.hip"))):
-        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    for name in sorted(TRAFFIC_SOURCES):
+        hsh.update(name.encode() + b"\0" + open(os.path.join(ROOT, "distributed-drl_amd", "csrc", name), "rb").read())
     return hsh.hexdigest()
 
 

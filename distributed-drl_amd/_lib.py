@@ -7,7 +7,9 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddrl_hip.so")
+# DDRL_LIB_PATH: another build of the same C-ABI (same-box A/B runs of tools/*: an older library next to the in-tree one, selected
+# per process instead of copied over the package file).  Symbols an older build lacks are skipped (their call sites then fail).
+LIB_PATH = os.environ.get("DDRL_LIB_PATH") or os.path.join(_HERE, "libddrl_hip.so")
 
 DDRL_OK = 0
 DDRL_ERR_BAD_ARG = -1
@@ -106,6 +108,8 @@ SIGNATURES = {
     "ddrl_sac1_compute_grads_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_apply_grads_and_sample": (c_int, [_P, _P, c_int, _P]),
     "ddrl_sac1_graph_sync": (c_int, [_P, _P]),
+    "ddrl_sac1_capture_begin": (c_int, [_P]),
+    "ddrl_sac1_capture_abort": (c_int, [_P]),
     "ddrl_sac1_input_buffers": (c_int, [_P, c_int, POINTER(_P)]),
     "ddrl_sac1_is_fused": (c_int, [_P]),
     "ddrl_sac1_batch": (c_int, [_P]),
@@ -182,7 +186,12 @@ def load():
             "or `make -C distributed-drl_amd/csrc`; there is no CPU fallback for the product path" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        try:
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        except AttributeError:
+            if not os.environ.get("DDRL_LIB_PATH"):
+                raise
+            continue                 # an OLDER build selected for an A/B run: calls of what it lacks fail at the call site
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -399,6 +399,14 @@ class Learner(_Net):
         grads.reset = reset
         return grads, apply, g
 
+    def capture_begin(self):
+        """Snapshot the handle's host-side launch state right before a stream capture of this learner's launches ..."""
+        _lib.check(self._lib.ddrl_sac1_capture_begin(self._h))
+
+    def capture_abort(self):
+        """... and put it back when that capture was aborted (nothing it recorded has run): include/ddrl.h."""
+        _lib.check(self._lib.ddrl_sac1_capture_abort(self._h))
+
     def compute_gradients(self, batch, eps=None):
         """Forward + backward only (the stubbed compute_gradients of actor_learner.py:144-145)."""
         keep, ptrs, _ = self._args(batch, eps, False)

@@ -770,6 +770,9 @@ struct ddrl_sac1 {
     uint32_t noise_seed;
     unsigned int noise_pending;
     bool grad_imported;  // the gradient buffer was overwritten by import(GRAD): Adam must not re-sum partials
+    // ddrl_sac1_capture_begin / _abort: the host-side launch state above as it stood before a caller's stream capture (every
+    // launch function toggles some of it at LAUNCH time, so an aborted capture — whose launches never ran — must put it back)
+    struct HostSnap { bool valid; int opt_cur, sh_cur; bool fuse_apply, sample_armed, noise_armed, grad_imported; uint32_t noise_seed; unsigned int noise_pending; } snap;
 };
 
 static void refresh_shadows(ddrl_sac1 *h, hipStream_t s);
@@ -1879,6 +1882,22 @@ int ddrl_sac1_internal_opt_sync(ddrl_sac1 *h, void *stream) {
 extern "C" {
 
 int ddrl_sac1_graph_sync(ddrl_sac1_t *h, void *stream) { return ddrl_sac1_internal_opt_sync(h, stream); }
+
+int ddrl_sac1_capture_begin(ddrl_sac1_t *h) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    h->snap = ddrl_sac1::HostSnap{true, h->opt_cur, h->sh_cur, h->fuse_apply, h->sample_armed, h->noise_armed, h->grad_imported, h->noise_seed, h->noise_pending};
+    return DDRL_OK;
+}
+
+int ddrl_sac1_capture_abort(ddrl_sac1_t *h) {
+    DDRL_REQUIRE(h != nullptr, "handle is NULL");
+    DDRL_REQUIRE(h->snap.valid, "ddrl_sac1_capture_abort without ddrl_sac1_capture_begin");
+    const ddrl_sac1::HostSnap &s = h->snap;
+    h->opt_cur = s.opt_cur; h->sh_cur = s.sh_cur; h->fuse_apply = s.fuse_apply; h->sample_armed = s.sample_armed;
+    h->noise_armed = s.noise_armed; h->grad_imported = s.grad_imported; h->noise_seed = s.noise_seed; h->noise_pending = s.noise_pending;
+    h->snap.valid = false;
+    return DDRL_OK;
+}
 
 int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream) {
     DDRL_REQUIRE(h != nullptr && replay != nullptr && (set_in == 0 || set_in == 1) && (set_out == 0 || set_out == 1) && set_in != set_out,

@@ -299,9 +299,13 @@ __device__ __forceinline__ void sk_store_sc1(float *p, float4 v) {
     f4v t = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
+// (Round 6) The head fragment of a split tile STARTS from the successor's slab — its 20 loads go straight into the accumulator registers —
+// instead of adding it at the end out of a second set of 80 registers.  The poll then sits in front of the head fragment: by then this
+// workgroup has run its tail fragment and a whole tile, at least as many weighted stages as the successor needed to publish (a share is
+// at least one largest tile long).  Sum order of a split tile: slab + head stages in stage order; fixed, bit-identical run to run.
 __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
     constexpr int WV = 4, WD_KB = 32, ROWS = 32 * WV, AOP = ROWS * WD_KB, WD_BOP = WD_KB * WD_BW, NG = WD_KB / 8;
-    constexpr int APW = (AOP / 256) / WV, BPW = (WD_BOP / 256) / WV;
+    constexpr int APW = (AOP / 256) / WV;
     const WideArgs &a = sa.w;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *sA = wsm, *sB = wsm + 2 * AOP;
@@ -319,10 +323,8 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
         const int NU = a.nu[c];
         const int unit0 = c ? a.cnt[0] * a.nu[0] + (ct - a.cnt[0]) * NU : ct * NU;
         const int m0 = mt * ROWS, n0 = unit0 * 32;
-        // (the B image stays 160 columns wide here whatever the tile's units: as wide as the tile — k_wide's form — this kernel, at the
-        // 256-register cap with 53 registers spilled, spills 107)
-        const float *pa[APW], *pb[BPW];
-        int ak[APW], bk[BPW], amode = 1;
+        const float *pa[APW];
+        int ak[APW], amode = 1;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int I = APW * w + i;
@@ -331,121 +333,115 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
             amode = i0 < a.a_rows ? 1 : i0 == a.a_rows ? 2 : 0;
             pa[i] = E.A + (long long)kk * E.lda + (amode == 1 ? i0 : 0);
         }
-#pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int f4 = 64 * (BPW * w + j) + lane, kk = f4 / (WD_BW / 4), c4 = f4 - kk * (WD_BW / 4);
-            bk[j] = kk;
-            pb[j] = (c4 < NU * 8 && n0 + 4 * c4 < a.N) ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;
-        }
-        auto issue = [&](int st, int buf) {
-            const int k = st * WD_KB;
-            const unsigned dA = lds_addr(sA + buf * AOP + 256 * APW * w), dB = lds_addr(sB + buf * WD_BOP + 256 * BPW * w);
-#pragma unroll
-            for (int g = 0; g < APW; ++g) {
-                const float *src = amode == 2 ? ones_blk : (amode == 1 && k + ak[g] < a.K) ? pa[g] + (long long)k * E.lda : zero_blk;
-                glds16(src, dA + 1024 * g);
-            }
-#pragma unroll
-            for (int j = 0; j < BPW; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
-        };
-        floatx16 acc[WD_NB];
-#pragma unroll
-        for (int u = 0; u < WD_NB; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
         const bool active = m0 + 32 * w < a.M;
-        auto compute = [&](const float *cA, const float *cB, auto nu_c) {
+        // The whole fragment — accumulator start, stage loop, publish / combine / store — is ONE instance per tile width.  (With only the
+        // stage loop instantiated per width and the accumulators declared outside, the five loops' results met in a merge and the
+        // register allocator gave every width its own accumulator tuples: (5 + 4 + 3 + 2 + 1) x 16 registers, the whole file — that,
+        // not the combine's second register set, is where the 47-53 spilled registers of rounds 4-5 came from.)
+        auto body = [&](auto nu_c) {
             constexpr int NUC = decltype(nu_c)::value;
+            // the B image of a tile is as wide as the tile — [32 k][32 NUC columns] = NUC pieces per wave and stage, k_wide's form (round 5
+            // kept 160 columns here: with the accumulators of every width alive that cost 54 more spilled registers)
+            const float *pb[NUC];
+            int bk[NUC];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float av[4], bv[NUC][4];
+            for (int j = 0; j < NUC; ++j) {
+                const int f4 = 64 * (NUC * w + j) + lane, kk = f4 / (8 * NUC), c4 = f4 - kk * (8 * NUC);
+                bk[j] = kk;
+                pb[j] = n0 + 4 * c4 < a.N ? E.B + (long long)kk * a.N + n0 + 4 * c4 : nullptr;
+            }
+            auto issue = [&](int st, int buf) {
+                const int k = st * WD_KB;
+                const unsigned dA = lds_addr(sA + buf * AOP + 256 * APW * w), dB = lds_addr(sB + buf * WD_BOP + 256 * NUC * w);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) av[j] = cA[(8 * g + 4 * h + j) * ROWS + 32 * w + l31];
+                for (int g = 0; g < APW; ++g) {
+                    const float *src = amode == 2 ? ones_blk : (amode == 1 && k + ak[g] < a.K) ? pa[g] + (long long)k * E.lda : zero_blk;
+                    glds16(src, dA + 1024 * g);
+                }
+#pragma unroll
+                for (int j = 0; j < NUC; ++j) glds16((pb[j] && k + bk[j] < a.K) ? pb[j] + (long long)k * a.N : zero_blk, dB + 1024 * j);
+            };
+            floatx16 acc[NUC];
+            if (fr.role == 2) {
+                // consume (guide, Guideline 16 recipe R1): ONE lane polls the ONE word relaxed, ONE agent-scope acquire drops this CU's
+                // stale L1 lines, its vmcnt drain holds the barrier for the invalidate, then every wave reads its part of the slab with
+                // plain loads, all in flight at once, straight into the accumulators.
+                // The spin is bounded: dispatch order is no contract (a shared GPU, a profiler serialising workgroups), so after ~1 s
+                // the workgroup gives up: it raises the sticky host-mapped error word and goes on with whatever the slab holds — this
+                // update's layer-1 gradient is then WRONG, and the next ddrl_dqn_step* call returns DDRL_ERR_HIP saying so and switches
+                // this learner to the tile-per-workgroup kernel (round 4 trapped here, which took the whole HIP context down).
+                if (tid == 0) {
+                    int spin = 0;
+                    while (__hip_atomic_load(sa.flag + wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sa.epoch) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if (++spin > (1 << 21)) { __hip_atomic_store(sa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                const float *S = sa.slab + ((((long long)(wg + 1) * WV + w) * WD_NB) * 16 * 64 + lane * 4);
 #pragma unroll
                 for (int u = 0; u < NUC; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * WD_BW + 32 * u + l31];
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(S + (u * 4 + q) * 256);
+                        acc[u][4 * q] = v.x; acc[u][4 * q + 1] = v.y; acc[u][4 * q + 2] = v.z; acc[u][4 * q + 3] = v.w;
+                    }
+                // a use of the loaded registers HERE: the compiler then waits for the slab in front of the stage loop.  Without it its
+                // wait lands in front of the loop's first MFMA that reads them — a vmcnt(0) executed in EVERY stage, which also
+                // waits for the next stage's LDS-DMA loads (they are invisible to the compiler's counter) just issued: no overlap.
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int u = 0; u < NUC; ++u) asm volatile("" : "+v"(acc[u]));
+            } else {
 #pragma unroll
-                    for (int u = 0; u < NUC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[u][j], acc[u], 0, 0, 0);
+                for (int u = 0; u < NUC; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
             }
-        };
-        auto run = [&](auto nu_c, int s_begin, int s_end) {
-            issue(s_begin, 0);
-            wide_dma_wait();
-            __syncthreads();
-            for (int st = s_begin; st < s_end; ++st) {
-                const int cur = (st - s_begin) & 1;
-                if (st + 1 < s_end) issue(st + 1, cur ^ 1);
-                if (active) compute(sA + cur * AOP, sB + cur * WD_BOP, nu_c);
+            if (fr.s0 < fr.s1 && fr.s1 <= T) {
+                issue(fr.s0, 0);
                 wide_dma_wait();
                 __syncthreads();
-            }
-        };
-        auto run_nu = [&](int s_begin, int s_end) {
-            if (s_begin >= s_end || s_end > T) return;
-            if (NU == 5) run(std::integral_constant<int, 5>{}, s_begin, s_end);
-            else if (NU == 4) run(std::integral_constant<int, 4>{}, s_begin, s_end);
-            else if (NU == 3) run(std::integral_constant<int, 3>{}, s_begin, s_end);
-            else if (NU == 2) run(std::integral_constant<int, 2>{}, s_begin, s_end);
-            else run(std::integral_constant<int, 1>{}, s_begin, s_end);
-        };
-        run_nu(fr.s0, fr.s1);
-        if (fr.role == 1) {
-            // publish: [wave][unit][four-register group][lane] float4 — one fully coalesced 1 KB line per wave-instruction
-            float *S = sa.slab + (((long long)wg * WV + w) * WD_NB) * 16 * 64;
+                for (int st = fr.s0; st < fr.s1; ++st) {
+                    const int cur = (st - fr.s0) & 1;
+                    if (st + 1 < fr.s1) issue(st + 1, cur ^ 1);
+                    if (active) {
+                        const float *cA = sA + cur * AOP, *cB = sB + cur * WD_BOP;
 #pragma unroll
-            for (int u = 0; u < WD_NB; ++u)
-                if (u < NU)
+                        for (int g = 0; g < NG; ++g) {
+                            float av[4], bv[NUC][4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) av[j] = cA[(8 * g + 4 * h + j) * ROWS + 32 * w + l31];
+#pragma unroll
+                            for (int u = 0; u < NUC; ++u)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) bv[u][j] = cB[(8 * g + 4 * h + j) * (32 * NUC) + 32 * u + l31];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int u = 0; u < NUC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[u][j], acc[u], 0, 0, 0);
+                        }
+                    }
+                    wide_dma_wait();
+                    __syncthreads();
+                }
+            }
+            if (fr.role == 1) {
+                // publish: [wave][unit][four-register group][lane] float4 — one fully coalesced 1 KB line per wave-instruction
+                float *S = sa.slab + ((((long long)wg * WV + w) * WD_NB) * 16 * 64 + lane * 4);
+#pragma unroll
+                for (int u = 0; u < NUC; ++u)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        sk_store_sc1(S + ((u * 4 + q) * 64 + lane) * 4, make_float4(acc[u][4 * q], acc[u][4 * q + 1], acc[u][4 * q + 2], acc[u][4 * q + 3]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(sa.flag + wg, sa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
-        }
-        if (fr.role == 2) {
-            // consume (guide, Guideline 16 recipe R1): ONE lane polls the ONE word relaxed, ONE agent-scope acquire drops this CU's
-            // stale L1 lines, its vmcnt drain holds the barrier for the invalidate, then every wave reads the slab with plain loads
-            // (all of them in flight at once)
-            // The spin is bounded: the successor publishes as its FIRST action, so with the dispatcher's in-order placement the word is
-            // there long before it is asked for — but dispatch order is no contract (a shared GPU, a profiler serialising workgroups), so
-            // after ~1 s the workgroup gives up: it raises the sticky host-mapped error word and goes on with whatever the slab holds —
-            // this update's layer-1 gradient is then WRONG, and the next ddrl_dqn_step* call returns DDRL_ERR_HIP saying so and switches
-            // this learner to the tile-per-workgroup kernel (round 4 trapped here, which took the whole HIP context down).
-            // (Measured alternatives that kept computing instead — this workgroup finishing the
-            // tile's remaining stages itself — cost the fast path 8-14 us of the 11 us gained: a second call site of the stage loop,
-            // accumulators live across the fragment loop, or a second __shared__ object, which makes hipcc wait vmcnt(0) before every
-            // ds_read behind the LDS-DMA loads: 130 -> 182 us.)
-            if (tid == 0) {
-                int spin = 0;
-                while (__hip_atomic_load(sa.flag + wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sa.epoch) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++spin > (1 << 21)) { __hip_atomic_store(sa.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        sk_store_sc1(S + (u * 4 + q) * 256, make_float4(acc[u][4 * q], acc[u][4 * q + 1], acc[u][4 * q + 2], acc[u][4 * q + 3]));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(sa.flag + wg, sa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
             }
-            __syncthreads();
-            const float *S = sa.slab + (((long long)(wg + 1) * WV + w) * WD_NB) * 16 * 64;
-            float4 sv[WD_NB][4];
 #pragma unroll
-            for (int u = 0; u < WD_NB; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sv[u][q] = *reinterpret_cast<const float4 *>(S + (((u < NU ? u : 0) * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-            for (int u = 0; u < WD_NB; ++u)
-                if (u < NU)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[u][4 * q] += sv[u][q].x; acc[u][4 * q + 1] += sv[u][q].y; acc[u][4 * q + 2] += sv[u][q].z; acc[u][4 * q + 3] += sv[u][q].w;
-                    }
-        }
-#pragma unroll
-        for (int u = 0; u < WD_NB; ++u)
-            if (u < NU) {
+            for (int u = 0; u < NUC; ++u) {
                 const int col = n0 + 32 * u + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -453,6 +449,12 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
                     if (row < a.M && col < a.N) E.out[(long long)row * a.N + col] = acc[u][r];
                 }
             }
+        };
+        if (NU == 5) body(std::integral_constant<int, 5>{});
+        else if (NU == 4) body(std::integral_constant<int, 4>{});
+        else if (NU == 3) body(std::integral_constant<int, 3>{});
+        else if (NU == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 1>{});
     }
 }
 

@@ -314,18 +314,38 @@ class PartitionedRun:
     def _capture_dp(self):
         """k updates of the data-parallel step as one graph.  Every cursor / RNG / optimizer state the launches read lives on
         the device and the sampler follows the step's plan from device memory, so a replay continues where the stream is;
-        the graph begins with an explicit draw and ends with an update that draws nothing ahead (`last`)."""
+        the graph begins with an explicit draw and ends with an update that draws nothing ahead (`last`).
+
+        A capture that is refused part-way has run nothing on the device, but every launch call it recorded has advanced the
+        learner's HOST-side launch state (which copy of the double-buffered optimizer state / dgrad images comes next, the
+        armed noise request) and the stepper's input-set bookkeeping: both are snapshotted before the capture and put back
+        on failure (`ddrl_sac1_capture_begin / _abort`), so the eager fallback continues bit for bit as if no capture had
+        been tried.  DDRL_DP_CAPTURE_FAIL=i makes the i-th captured all-reduce raise (tests: i recorded apply() calls, one
+        more recorded gradient pass)."""
+        import os
         k = self.dp_per_graph
+        fail_at = int(os.environ.get("DDRL_DP_CAPTURE_FAIL", "-1"))
         torch.cuda.synchronize()
         self.dp_grads.graph_sync()
         torch.cuda.synchronize()
+        stream = torch.cuda.current_stream()
+        self.learner.capture_begin()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(k):
-                self.dp_grads(last=(i == k - 1))
-                comm.allreduce_mean_(self.dp_g, group=self.lgroup)
-                self.dp_apply()
-            self.dp_grads.graph_sync()
+        try:
+            with torch.cuda.graph(g):
+                for i in range(k):
+                    self.dp_grads(last=(i == k - 1))
+                    if i == fail_at:
+                        raise RuntimeError("injected capture failure before all-reduce %d (DDRL_DP_CAPTURE_FAIL)" % i)
+                    comm.allreduce_mean_(self.dp_g, group=self.lgroup)
+                    self.dp_apply()
+                self.dp_grads.graph_sync()
+        except Exception:
+            torch.cuda.set_stream(stream)            # (a capture_end that raises leaves torch on its capture stream)
+            torch.cuda.synchronize()
+            self.learner.capture_abort()
+            self.dp_grads.reset()
+            raise
         self.dp_graph = g
 
     def _train_eager(self, n, end_of_step=False):
@@ -346,9 +366,7 @@ class PartitionedRun:
                 except Exception as e:  # noqa
                     import sys
                     print("partition: capturing the data-parallel step failed (%r): eager updates from here on" % (e,), file=sys.stderr)
-                    ok = 0.0
-                    torch.cuda.synchronize()
-                    self.dp_grads.reset()                # (what the aborted capture recorded never ran)
+                    ok = 0.0                             # (_capture_dp has put the learner's and the stepper's host state back)
                 flag = torch.tensor([ok], dtype=torch.float32, device=self.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.lgroup)
                 if float(flag.item()) < 0.5:

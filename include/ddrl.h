@@ -292,6 +292,15 @@ int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t
  * it on the stream right before the capture begins and again as the LAST captured call, so that the graph starts and ends
  * on the same copy whatever the number of updates it holds (a copy node when that number is odd). */
 int ddrl_sac1_graph_sync(ddrl_sac1_t *h, void *stream);
+/* A stream capture that is ABORTED (the runtime or a collective refuses a node) leaves the device untouched, but every
+ * ddrl_sac1_* launch call made while recording has already advanced this handle's host-side launch state (which copy of the
+ * double-buffered optimizer state / dgrad images the next launch reads, the armed noise request, pending counter advances).
+ * ddrl_sac1_capture_begin snapshots that state right before the capture starts (after the leading ddrl_sac1_graph_sync);
+ * ddrl_sac1_capture_abort puts it back, so that eager calls continue exactly as if the capture had never been tried
+ * (partition.py's fallback for the data-parallel step; no counterpart in the reference).  A capture that ends normally needs
+ * neither.  One snapshot per handle; abort without begin is DDRL_ERR_BAD_ARG. */
+int ddrl_sac1_capture_begin(ddrl_sac1_t *h);
+int ddrl_sac1_capture_abort(ddrl_sac1_t *h);
 
 /* The learner's internal input buffers (device): obs1[B,obs] obs2[B,obs] acts[B,act] rews[B]
  * done[B] eps_x[B,act] eps_x2[B,act] eps_t[B,act], in this order in bufs_h[8] (host array of

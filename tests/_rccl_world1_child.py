@@ -76,7 +76,7 @@ def main():
             rs.randn(m, 8).astype(np.float32), np.zeros(m, np.float32))))
         return rb
 
-    def run_it(force_dp, per_graph, dp_graph=0):
+    def run_it(force_dp, per_graph, dp_graph=0, capture_fails=False):
         roles = partition.Roles(1, 0)
         run = partition.PartitionedRun(opt, roles, shard, lambda rb: RolloutDevice(None, rb, opt, worker_index=0),
                                        lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=per_graph, force_dp=force_dp,
@@ -84,12 +84,14 @@ def main():
         assert run.bcast is not None and (run.lgroup is not None) == force_dp
         if force_dp:
             assert run.dp_per_graph == dp_graph
-        for _ in range(5):
-            run.step(4)                                        # 20 updates: pushes (RCCL broadcasts) at 6, 12, 18 + the initial one
+        for n in (3, 4, 4, 4, 5):                              # 20 updates: pushes (RCCL broadcasts) at 6, 12, 18 + the initial one.  The
+            run.step(n)                                        # first capture attempt comes after 3 + 1 eager updates: optimizer state on copy 0, copy 1 one update OLDER
         torch.cuda.synchronize()
         run.check()
-        if dp_graph:
-            assert run.dp_graph is not None                    # steps 2 and 4 are whole segments of 4 updates: graph replays
+        if dp_graph and not capture_fails:
+            assert run.dp_graph is not None                    # steps 3 and 4 are whole graphs of 4 updates, step 5 a graph + 1 eager
+        if capture_fails:
+            assert run.dp_graph is None and run.dp_per_graph == 0   # the learners agreed on the eager step
         assert run.learner.opt_steps() == (20, 20) and run.stats["pushes"] == 4
         assert run.rb.get_counts() == (20, 500 + 5 * 64, 500 + 5 * 64)
         n_pi = run.roll.actor.n_params
@@ -101,6 +103,21 @@ def main():
     np.testing.assert_array_equal(w_loop, w_dp)
     w_dpg = run_it(True, 0, dp_graph=4)   # the same step captured with its RCCL all-reduce as graphs of 4 updates
     np.testing.assert_array_equal(w_loop, w_dpg)
+    # ---- the capture fallback (partition.py: _capture_dp / _train_eager) ------------------------------------------------------
+    # A capture refused after i recorded apply() calls (and i + 1 recorded gradient passes) has advanced the learner's host-side
+    # launch state — which optimizer-state copy / dgrad image the next launch reads, the armed noise request — without the
+    # device running anything.  The eager fallback must continue bit for bit like a run that never tried to capture: i = 0
+    # (only a gradient pass recorded), i = 1 (an ODD number of recorded optimizer steps: the stale-copy case — the capture is tried
+    # after an even number of eager updates, so the two copies of the optimizer state DIFFER at that point; with the restore
+    # switched off this case ends on different weights, scratch/capture_control.py), i = 2 (even).
+    for i in (0, 1, 2):
+        os.environ["DDRL_DP_CAPTURE_FAIL"] = str(i)
+        try:
+            w_fb = run_it(True, 0, dp_graph=4, capture_fails=True)
+        finally:
+            os.environ.pop("DDRL_DP_CAPTURE_FAIL", None)
+        np.testing.assert_array_equal(w_loop, w_fb)
+    print("rccl capture fallback ok", flush=True)
     print("rccl partition ok", flush=True)
 
 

@@ -20,6 +20,9 @@ def test_rccl_world1_comm_and_partitioned_run():
     out = p.stdout.decode("utf-8", "replace")
     assert p.returncode == 0 and "RCCL_WORLD1_OK" in out, out[-4000:]
     assert "rccl comm ok" in out and "rccl partition ok" in out
+    # an aborted capture of the data-parallel step (after 0 / an odd / an even number of recorded optimizer steps) falls back to
+    # eager updates that equal, bit for bit, a run that never captured (ddrl_sac1_capture_begin / _abort)
+    assert "rccl capture fallback ok" in out
 
 
 @pytest.mark.parametrize("mode", ["plain", "torch"])
