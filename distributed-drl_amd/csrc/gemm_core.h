@@ -678,6 +678,12 @@ struct AdamArgs {
     float *loss_out2;        // optional second destination (the caller's buffer: a copy launch per update otherwise)
     int loss_n;
     float loss_scale;
+    // optional (direct path, split API): the dgrad images [Np/4][ld][4] of up to four k4-interleaved layer-2 kernels [K/4][Np][4] are
+    // rewritten from the stepped values by the threads that step them — the flat step of a data-parallel learner then needs no
+    // k_shadow launch behind it (sh_off4[s]: first float4 of kernel s in the flat buffer; it holds (ld / 4) * Np float4)
+    int n_sh, sh_K, sh_N, sh_Np, sh_ld;
+    long long sh_off4[4];
+    float *sh_dst[4];
 };
 __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
     if (a.loss_part && !a.do_sample && (int)blockIdx.x == a.adam_blocks) {
@@ -741,6 +747,19 @@ __global__ void __launch_bounds__(256) k_adam_polyak(AdamArgs a) {
         adam1(g.z, m.z, v.z, p.z, t.z, omb1, omb2, al, a.eps, a.pk, a.pk1);
         adam1(g.w, m.w, v.w, p.w, t.w, omb1, omb2, al, a.eps, a.pk, a.pk1);
         M[i] = m; V[i] = v; P[i] = p; T[i] = t;
+        for (int sh = 0; sh < a.n_sh; ++sh) {
+            const long long e = i - a.sh_off4[sh];
+            if (e < 0 || e >= (long long)(a.sh_ld >> 2) * a.sh_Np) continue;
+            // float4 e = rows k = 4 kq .. 4 kq + 3 of column j; the image holds column group j / 4 of row k at ((j / 4) * ld + k) * 4 + j % 4
+            const int kq = (int)(e / a.sh_Np), j = (int)(e - (long long)kq * a.sh_Np);
+            if (4 * (j >> 2) >= a.sh_N) break;
+            float *c = a.sh_dst[sh] + ((long long)(j >> 2) * a.sh_ld + 4 * kq) * 4 + (j & 3);
+            const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * kq + q < a.sh_K) c[4 * q] = pv[q];
+            break;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // nobody reads the copy this writes
         OptState n = *a.opt;

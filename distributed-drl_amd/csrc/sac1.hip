@@ -1672,9 +1672,16 @@ static void launch_stage(ddrl_sac1 *h, int stage, int st, hipStream_t s) {
                     k_reduce_parts_w1y<<<(unsigned)((nk * N + 255) / 256), 256, 0, s>>>(h->part, h->grad + h->L.pi_W1, nk, N, nparts);
                 }
                 h->ad.nparts = 0;
+                {   // the dgrad images of the main layer-2 kernels (what refresh_shadows would rewrite in a launch of its own) ride in the flat step
+                    const Layout &L = h->L;
+                    int n = 0;
+                    h->ad.sh_off4[n] = L.pi_W2 >> 2; h->ad.sh_dst[n++] = h->c4_pi[h->sh_cur];
+                    for (int q = 0; q < 2; ++q) { h->ad.sh_off4[n] = L.q_W2[q] >> 2; h->ad.sh_dst[n++] = (q == 1 && h->mid_rest_job >= 0 && h->sh_cur) ? h->c4_q2b : h->c4_q[q]; }
+                    if (h->cfg.variant == DDRL_SAC_V) { h->ad.sh_off4[n] = L.v_W2 >> 2; h->ad.sh_dst[n++] = h->c4_q[2]; }
+                    h->ad.n_sh = n; h->ad.sh_K = h->cfg.hidden1; h->ad.sh_N = h->cfg.hidden2; h->ad.sh_Np = L.Np2; h->ad.sh_ld = L.Kp1;
+                }
                 k_adam_polyak<<<(unsigned)(blocks + (h->ad.do_sample ? 1 : 0)), 256, 0, s>>>(h->ad);
-                h->ad.nparts = nparts;
-                refresh_shadows(h, s);
+                h->ad.nparts = nparts; h->ad.n_sh = 0;
                 break;
             }
             default: break;  // 1, 3, 4, 6, 10: folded into the launches above

@@ -109,7 +109,7 @@ def main():
     # device running anything.  The eager fallback must continue bit for bit like a run that never tried to capture: i = 0
     # (only a gradient pass recorded), i = 1 (an ODD number of recorded optimizer steps: the stale-copy case — the capture is tried
     # after an even number of eager updates, so the two copies of the optimizer state DIFFER at that point; with the restore
-    # switched off this case ends on different weights, scratch/capture_control.py), i = 2 (even).
+    # switched off this case ends on different weights, tools/capture_fallback_control.py), i = 2 (even).
     for i in (0, 1, 2):
         os.environ["DDRL_DP_CAPTURE_FAIL"] = str(i)
         try:

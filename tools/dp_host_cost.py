@@ -44,13 +44,14 @@ it(last=True)
 timed(lambda: [it(reduce=False) for _ in range(999)] + [it(last=True, reduce=False)], 1000, "eager, no all-reduce")
 timed(lambda: [it() for _ in range(999)] + [it(last=True)], 1000, "eager + RCCL all-reduce (AVG) per update")
 K = 16
-grads.graph_sync()
-torch.cuda.synchronize()
-graph = torch.cuda.CUDAGraph()
-with torch.cuda.graph(graph):
-    for i in range(K):
-        it(last=(i == K - 1))
+for reduce, label in ((False, "graphs of %d updates, NO all-reduce (the step's own device time)" % K), (True, "graphs of %d updates, RCCL all-reduce as a graph node" % K)):
     grads.graph_sync()
-graph.replay(); torch.cuda.synchronize()
-timed(lambda: [graph.replay() for _ in range(64)], 64 * K, "graphs of %d updates, RCCL all-reduce as a graph node" % K)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(K):
+            it(last=(i == K - 1), reduce=reduce)
+        grads.graph_sync()
+    graph.replay(); torch.cuda.synchronize()
+    timed(lambda: [graph.replay() for _ in range(64)], 64 * K, label)
 dist.destroy_process_group()
