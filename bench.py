@@ -32,6 +32,9 @@ Prints ONE JSON line on rank 0.  `value` = whole-job env-steps/s over EXACTLY --
 learner ranks) and `optimizer_steps_per_s` (Adam steps of the learner GROUP: data-parallel learners make one from their batches) ride along.
 `series` = the three curves an N-GPU read-out needs, measured apart: the learner group alone, every rollout rank flat out (all ranks at
 once, no learner work), the gated `value`; `config.weak_scaling_why` says which the >= 0.7 target is read against.
+`free_running` (N = 1): the rollout on its own stream beside the learner's graph loop on another, no gate (example/dsac.py:229-236;
+workers.FreeRunningLoop): `value_ungated` / `updates_per_s_ungated` are the two rates of that ONE timed region, and
+`series.rollout_capacity_with_learner_env_steps_per_s` the rollout capacity with a learner training beside it.
 `roofline` prices the launches of one update (fp32 MFMA): algorithmic FLOPs of an update / launches per update, over the
 average launch time measured with HIP events on the launch stream around a learner-only block of graph replays (so
 launch gaps count).  `stages` adds the other rows of SURVEY §8(d): rollout-only, store, sample, the config-5 gather.
@@ -99,6 +102,8 @@ def parse_args():
                          "free: 2048 updates per learner rank per step whatever the env steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the rollout / store / sample / config-5 stage measurements")
+    ap.add_argument("--no-free", action="store_true", help="skip the free-running (ungated, two-stream) measurement at N = 1")
+    ap.add_argument("--free-segments", type=int, default=60, help="segments of the free-running measurement's timed region")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds per CPU-baseline leg")
     ap.add_argument("--gpu-seconds", type=float, default=10.0, help="keep repeating the timed block until the GPU legs lasted this long")
     ap.add_argument("--stage-samples", type=int, default=200)
@@ -560,6 +565,42 @@ def config5_stages(args, d):
     return out
 
 
+def free_running_measure(roll, trainer, opt, args, torch):
+    """example/dsac.py:229-236 at N = 1: the rollout free-running on its own stream BESIDE the learner's graph loop on another
+    (workers.FreeRunningLoop: no gate, transitions and weights cross at segment boundaries).  Both rates come from ONE timed region.
+    The segment is `n` updates; the vector steps per segment are calibrated once so that both streams are busy for about the same
+    time (neither half waits long at a boundary)."""
+    from distributed_drl_amd.workers import FreeRunningLoop
+    n = max(2, 2 * int(args.updates_per_graph))
+    k_max = max(1, min(512, trainer.rb.max_size // int(opt.num_envs)))
+    k = min(k_max, n)
+    loop = FreeRunningLoop(roll, trainer, opt, steps_per_segment=k, updates_per_segment=n, timing=True)
+    loop.run(6)
+    t = loop.segment_times(last=4)
+    loop.close()
+    k2 = int(max(4, min(k_max, round(k * t["learner_ms"] / max(t["rollout_ms"], 1e-6)))))
+    calib = {"steps_per_segment_tried": k, "rollout_ms": t["rollout_ms"], "learner_ms": t["learner_ms"]}
+    loop = FreeRunningLoop(roll, trainer, opt, steps_per_segment=k2, updates_per_segment=n, timing=True)
+    loop.run(4)
+    loop.drain()
+    segs = int(args.free_segments)
+    e0, u0 = loop.env_steps, loop.updates
+    t0 = time.perf_counter()
+    loop.run(segs)
+    loop.drain()
+    dt = time.perf_counter() - t0
+    ph = loop.segment_times(last=min(segs, 16))
+    res = {"env_steps_per_s": (loop.env_steps - e0) / dt, "updates_per_s": (loop.updates - u0) / dt, "segments": segs, "seconds": dt,
+           "steps_per_segment": k2, "updates_per_segment": n, "calibration": calib, "phase_ms_per_segment": ph,
+           "rollout_stream_busy": ph["rollout_ms"] / (dt / segs * 1e3), "learner_stream_busy": (ph["learner_ms"] + ph["commit_ms"]) / (dt / segs * 1e3),
+           "what": "workers.FreeRunningLoop: %d vector steps of %d envs on the rollout stream beside %d graph-loop updates on the learner "
+                   "stream per segment; the rollout's transitions reach the replay ring by one commit per segment (staging ring -> "
+                   "store_batch on the learner's stream), the learner's pushes reach the envs at the next boundary (per-env adoption at "
+                   "episode ends as always); no actor/learner gate (example/dsac.py:76-150)" % (k2, int(opt.num_envs), n)}
+    loop.close()
+    return res
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -856,6 +897,15 @@ def main():
         "note": "learner-group rate: the learner rank(s) alone%s; rollout capacity: rollout-only block, all rollout ranks at once; gated: the "
                 "timed region (`value`).  See config.weak_scaling_why for which series the 0.7 target is read against." %
                 (" (graph loop, HIP events)" if world == 1 else " (updates phase of one drained block: feed attached, all-reduce included)")}
+    if world == 1 and trainer is not None and not args.no_free:
+        fr = free_running_measure(roll, trainer, opt, args, torch)
+        out["free_running"] = fr
+        # at N = 1 the gated step and the "free" step of rounds 2-5 were the same step; the ungated figures are now what the two halves
+        # reach when NOTHING holds either back and they share the GPU
+        out["value_ungated"] = fr["env_steps_per_s"]
+        out["updates_per_s_ungated"] = fr["updates_per_s"]
+        out["series"]["rollout_capacity_with_learner_env_steps_per_s"] = fr["env_steps_per_s"]
+        out["series"]["learner_updates_per_s_beside_free_rollout"] = fr["updates_per_s"]
     if world == 1 and not args.no_stages:
         out["stages"] = stage_measurements(args, opt, rb, roll, d)
     if world == 1:

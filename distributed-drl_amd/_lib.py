@@ -107,6 +107,7 @@ SIGNATURES = {
     "ddrl_sac1_step_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_compute_grads_and_sample": (c_int, [_P, c_int, _P, c_int, _P]),
     "ddrl_sac1_apply_grads_and_sample": (c_int, [_P, _P, c_int, _P]),
+    "ddrl_sac1_step_host": (c_int, [_P, _P, c_int64, c_uint32, c_uint64, _P, _P]),
     "ddrl_sac1_graph_sync": (c_int, [_P, _P]),
     "ddrl_sac1_capture_begin": (c_int, [_P]),
     "ddrl_sac1_capture_abort": (c_int, [_P]),

@@ -226,8 +226,9 @@ class Learner(_Net):
         """train(replay_buffer.sample_batch()) — the reference's learner loop body with HOST arrays (example/dsac.py:142-144) — without any
         staging launch: the five arrays go up as ONE asynchronous copy out of a page-locked block (two of them, alternating behind events)
         straight INTO the learner's input set 0, the three noise tensors are generated in place behind it, and the update reads the input
-        set it owns (ddrl_sac1_step then skips its copy launch).  Same values, same noise stream positions as the general path.
-        -> the 12 pointers of ddrl_sac1_step, or None when the input set's items do not lie the way this needs."""
+        set it owns — copy, noise and update issued by ONE C call (ddrl_sac1_step_host: on this surface the interpreter, not the device,
+        sets the rate).  Same values, same noise stream positions as the general path.
+        -> True when the update has been issued, None when the input set's items do not lie the way this needs."""
         B, o, a = self.cfg.batch, self.cfg.obs_dim, self.cfg.act_dim
         st = getattr(self, "_fast", None)
         if st is None:
@@ -236,44 +237,56 @@ class Learner(_Net):
             p = [int(bufs[i]) for i in range(8)]
             n = (B * o, B * o, B * a, B, B)
             off = [(p[j] - p[0]) // 4 for j in range(5)]
-            ok = all((p[j] - p[0]) % 4 == 0 for j in range(5)) and all(off[j] + n[j] <= off[j + 1] for j in range(4)) and off[4] + B <= 4 * sum(n)
+            # one block copy covers [obs1 | obs2 | acts | rews | done]: the five items must lie in this order with nothing but alignment
+            # padding between them (a layout with another live buffer in a gap would be overwritten by the copy)
+            ok = all((p[j] - p[0]) % 4 == 0 for j in range(5)) and all(0 <= off[j + 1] - (off[j] + n[j]) < 64 for j in range(4))
             if not ok:
                 st = self._fast = False
             else:
-                from .replay import _view
                 span = off[4] + B
                 hosts = [torch.zeros(span, dtype=torch.float32).pin_memory() for _ in range(2)]
-                st = self._fast = {"p": p, "off": off, "n": n, "dev": _view(p[0], (span,), self.device), "host": hosts, "np": [h.numpy() for h in hosts],
-                                   "ev": [None, None], "turn": 0, "eps_contig": p[6] - p[5] == 4 * B * a and p[7] - p[6] == 4 * B * a}
+                st = self._fast = {"p": p, "off": off, "n": n, "span": span, "host": hosts, "np": [h.numpy() for h in hosts],
+                                   "hp": [ctypes.c_void_p(h.data_ptr()) for h in hosts],
+                                   "ev": [torch.cuda.Event(), torch.cuda.Event()], "used": [False, False], "turn": 0,
+                                   "eps_contig": p[6] - p[5] == 4 * B * a and p[7] - p[6] == 4 * B * a}
         if st is False:
             return None
         t = st["turn"]
         st["turn"] = t ^ 1
-        if st["ev"][t] is not None:
+        if st["used"][t]:
             st["ev"][t].synchronize()                 # the copy that last read this staging block has left it
         hv, off, n = st["np"][t], st["off"], st["n"]
-        for j, k in enumerate(("obs1", "obs2", "acts", "rews", "done")):
-            hv[off[j]:off[j] + n[j]] = np.asarray(batch[k], dtype=np.float32).reshape(n[j])
-        st["dev"].copy_(st["host"][t], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st["ev"][t] = ev
-        p, m, s = st["p"], B * a, _lib.stream_ptr()
-        if st["eps_contig"]:
-            _lib.check(self._lib.ddrl_normal_fill(p[5], 3 * m, self._noise_seed, self._noise_ctr, s))
+        arrs = [batch[k] for k in ("obs1", "obs2", "acts", "rews", "done")]
+        p0 = arrs[0].ctypes.data
+        if all(x.dtype == np.float32 and x.flags.c_contiguous and x.size == n[j] and x.ctypes.data - p0 == 4 * off[j] for j, x in enumerate(arrs)):
+            # the five arrays are pieces of ONE host block with the input set's own offsets (what ReplayBuffer.sample_batch hands out
+            # at the reference's shapes): one memmove instead of five conversions
+            ctypes.memmove(st["hp"][t], p0, 4 * st["span"])
         else:
-            for i in range(3):
-                _lib.check(self._lib.ddrl_normal_fill(p[5 + i], m, self._noise_seed, self._noise_ctr + i * m, s))
-        self._noise_ctr += 3 * m
-        return p + [_lib.dptr(self.losses), None, None, None]
+            for j, x in enumerate(arrs):
+                hv[off[j]:off[j] + n[j]] = np.asarray(x, dtype=np.float32).reshape(n[j])
+        _lib.check(self._lib.ddrl_sac1_step_host(self._h, st["hp"][t], st["span"], self._noise_seed, self._noise_ctr, _lib.dptr(self.losses),
+                                                 _lib.stream_ptr()))
+        st["ev"][t].record()
+        st["used"][t] = True
+        self._noise_ctr += 3 * B * a
+        return True
+
+    def _guard_stepper(self):
+        """A caller's batch is staged into input set 0 (by copy kernel or by the one-block host copy): a batch the data-parallel
+        stepper has drawn AHEAD into that set would be overwritten and its next update would silently train on this one."""
+        dp = getattr(self, "_dp_state", None)
+        if dp is not None and dp["primed"]:
+            raise RuntimeError("train / compute_gradients with a caller's batch while a dp_stepper holds a batch drawn ahead: end its "
+                               "sequence with grads(last=True) first")
 
     def _args(self, batch, eps, outs):
         B, a = self.cfg.batch, self.cfg.act_dim
+        self._guard_stepper()
         if all(isinstance(batch[k], np.ndarray) for k in ("obs1", "obs2", "acts", "rews", "done")):
-            if eps is None and not outs:
-                ptrs = self._host_fast(batch)
-                if ptrs is not None:
-                    return None, ptrs, (None, None, None)
+            if eps is None and not outs and getattr(self, "_fast_step", False):
+                if self._host_fast(batch):
+                    return None, None, (None, None, None)     # (the one call has issued the update)
             x, x2, ac, r, d = self._host_batch(batch)
         else:
             x, x2 = self._dev(batch["obs1"], (B, -1)), self._dev(batch["obs2"], (B, -1))
@@ -310,8 +323,13 @@ class Learner(_Net):
     def train(self, batch, eps=None, return_outputs=False):
         """One sess.run(step_ops) (actor_learner.py:135-142).  `batch` holds obs1/obs2/acts/rews/done
         as NumPy arrays (the reference's feed) or device tensors (no host round trip)."""
-        keep, ptrs, outs = self._args(batch, eps, return_outputs)
-        _lib.check(self._lib.ddrl_sac1_step(self._h, *ptrs, _lib.stream_ptr()))
+        self._fast_step = True                    # train(): a host batch may take the one-call path (copy + noise + update)
+        try:
+            keep, ptrs, outs = self._args(batch, eps, return_outputs)
+        finally:
+            self._fast_step = False
+        if ptrs is not None:
+            _lib.check(self._lib.ddrl_sac1_step(self._h, *ptrs, _lib.stream_ptr()))
         if return_outputs:
             return self.losses, outs
         return None  # the reference drops the fetched values (actor_learner.py:142)
@@ -323,6 +341,7 @@ class Learner(_Net):
             bufs = (ctypes.c_void_p * 8)()
             _lib.check(self._lib.ddrl_sac1_input_buffers(self._h, 0, bufs))
             self._in0 = [bufs[i] for i in range(8)]
+        self._guard_stepper()
         B, a = self.cfg.batch, self.cfg.act_dim
         keep = [self._dev(batch[k], s) for k, s in (("obs1", (B, -1)), ("obs2", (B, -1)), ("acts", (B, a)), ("rews", (B,)), ("done", (B,)))]
         _lib.check(self._lib.ddrl_sac1_fill_noise(self._h, self._noise_seed, _lib.stream_ptr()))
@@ -364,7 +383,7 @@ class Learner(_Net):
         _lib.check(lib.ddrl_sac1_grad_buffer(self._h, ctypes.byref(gp), ctypes.byref(gn)))
         g = _view(gp.value, (int(gn.value),), torch.device("cuda", torch.cuda.current_device()))
         B, h, rh, seed, nul = int(self.cfg.batch), self._h, ring._h, self._noise_seed, ctypes.c_void_p(None)
-        state = {"cur": 0, "primed": False}
+        state = self._dp_state = {"cur": 0, "primed": False}   # (train(host batch) looks at `primed` before it writes into input set 0)
 
         def grads(last=False):
             """`last`: the final update before the ring / its feed plan changes (end of a step): nothing is drawn ahead."""

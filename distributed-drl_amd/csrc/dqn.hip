@@ -313,7 +313,30 @@ struct ddrl_dqn {
     float *sk_slab;
     int *sk_flag;
     int *sk_err_h;                   // pinned, device-visible: k_wide_sk's sticky "combine timed out" word
+    long long steps_launched, poison_after;   // DDRL_SK_POISON_AFTER=n (tests): the host raises the word itself behind the n-th step's launches
+    bool poisoned;                   // that word was seen: the parameters carry at least one step from a wrong layer-1 gradient.  Every step / export
+                                     // fails until fresh parameters arrive (set_weights, import of MAIN), so they cannot be pushed or checkpointed
 };
+
+// The stream-K combine's verdict, looked at wherever the host is about to trust the parameters: at the next step (unsynchronised: the
+// steps already queued behind the failing one have run by then) and, with the stream drained, before anything is exported.
+static int dqn_poison_check(ddrl_dqn *h, hipStream_t s, bool drain) {
+    if (h->sk_err_h && !h->poisoned) {
+        if (drain && h->sk_on) (void)hipStreamSynchronize(s);
+        if (*h->sk_err_h) {
+            *h->sk_err_h = 0;
+            h->poisoned = true;
+            h->sk_on = false;                      // from here on: the tile-per-workgroup kernel
+            h->head.zero_words = nullptr; h->head.n_zero = 0;
+        }
+    }
+    if (!h->poisoned) return DDRL_OK;
+    ddrl::set_error("k_wide_sk: a split tile's partner did not publish within ~1 s (workgroups of the launch not co-resident: shared GPU or "
+                    "serialising profiler?) — the layer-1 gradient of an earlier update was wrong and every later step built on it.  This learner "
+                    "refuses to step or export until it is given fresh parameters (set_weights / import of the main parameters, e.g. from a "
+                    "checkpoint); it then runs the tile-per-workgroup kernel (DDRL_WIDE_SK=0 selects that from the start).");
+    return DDRL_ERR_HIP;
+}
 
 extern "C" {
 
@@ -453,7 +476,8 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         }
     }
     if (h->wide) { h->wf.part = h->wpart; h->wf.consts = h->wconsts; h->wf.a_rows = B; h->wf.ldo = h->ldh1; }
-    h->sk_on = false; h->sk_frags_d = nullptr; h->sk_slab = nullptr; h->sk_flag = nullptr; h->sk_err_h = nullptr;
+    h->sk_on = false; h->sk_frags_d = nullptr; h->sk_slab = nullptr; h->sk_flag = nullptr; h->sk_err_h = nullptr; h->poisoned = false;
+    h->steps_launched = 0; h->poison_after = getenv("DDRL_SK_POISON_AFTER") ? atoll(getenv("DDRL_SK_POISON_AFTER")) : -1;
     if (h->wide && !(getenv("DDRL_WIDE_SK") && atoi(getenv("DDRL_WIDE_SK")) == 0)) {
         // the wgrad as equal shares of the stage sequence over <= 512 resident workgroups (two per CU) when the shape splits that way
         int ncu = 256;
@@ -523,6 +547,7 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
 int ddrl_dqn_set_weights(ddrl_dqn_t *h, const float *flat_main_d, void *stream) {
     DDRL_REQUIRE(h != nullptr && flat_main_d != nullptr, "NULL pointer");
     ddrl::DeviceGuard g(h->device);
+    h->poisoned = false;   // fresh parameters (main and target)
     // main AND target: Learner.set_weights runs target_init (algos/dqn/actor_learner.py:99-101)
     k_pack<<<dim3(64, (unsigned)h->segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_main_d, h->main_p, h->target_p, 1);
     DDRL_LAUNCH_CHECK();
@@ -535,6 +560,7 @@ int ddrl_dqn_export(ddrl_dqn_t *h, int which, float *flat_d, void *stream) {
                  which == DDRL_SAC1_ADAM_V ? h->v : which == DDRL_SAC1_GRAD ? h->grad : nullptr;
     DDRL_REQUIRE(buf != nullptr, "unknown buffer id");
     ddrl::DeviceGuard g(h->device);
+    if (int prc = dqn_poison_check(h, ddrl::as_stream(stream), true)) return prc;   // (drains the stream while the stream-K kernel is in use)
     k_pack<<<dim3(64, (unsigned)h->segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, buf, flat_d, nullptr, 0);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
@@ -547,6 +573,7 @@ int ddrl_dqn_import(ddrl_dqn_t *h, int which, const float *flat_d, void *stream)
                  which == DDRL_SAC1_ADAM_V ? h->v : nullptr;
     DDRL_REQUIRE(buf != nullptr, "unknown or read-only buffer id");
     ddrl::DeviceGuard g(h->device);
+    if (which == DDRL_SAC1_MAIN) h->poisoned = false;   // fresh main parameters (a resumed learner imports target and moments next)
     k_pack<<<dim3(64, (unsigned)h->segs.size()), 256, 0, ddrl::as_stream(stream)>>>(h->segs_d, flat_d, buf, nullptr, 1);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
@@ -561,15 +588,7 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
                            float *loss_d, float *q_d, hipStream_t s, hipEvent_t *ev, const long long *ridx = nullptr) {
     const int B = h->cfg.batch, o = h->cfg.obs_dim;
     int e = 0;
-    if (h->sk_on && h->sk_err_h && *h->sk_err_h) {   // a stream-K combine of an EARLIER step gave up waiting for its partner (sticky, host-mapped word)
-        *h->sk_err_h = 0;
-        h->sk_on = false;
-        h->head.zero_words = nullptr; h->head.n_zero = 0;
-        ddrl::set_error("k_wide_sk: a split tile's partner did not publish within ~1 s (workgroups of the launch not co-resident: shared GPU or "
-                        "serialising profiler?) — the layer-1 gradient of an earlier update was wrong; this learner now uses the tile-per-workgroup "
-                        "kernel (DDRL_WIDE_SK=0 selects it from the start).  Restore the parameters from a checkpoint.");
-        return DDRL_ERR_HIP;
-    }
+    if (int prc = dqn_poison_check(h, s, false)) return prc;   // a stream-K combine of an EARLIER step gave up waiting for its partner
 #define STAGE_MARK() do { if (ev) DDRL_HIP_CHECK(hipEventRecord(ev[e++], s)); } while (0)
     STAGE_MARK();
     // wide layer 1 reads the caller's observation rows in place (16-byte aligned rows: obs_dim % 4 == 0 there) and the head kernel
@@ -637,6 +656,7 @@ static int dqn_step_launch(ddrl_dqn_t *h, const float *obs1_d, const float *obs2
     STAGE_MARK();   // 8 flat Adam + polyak
 #undef STAGE_MARK
     DDRL_LAUNCH_CHECK();
+    if (++h->steps_launched == h->poison_after && h->sk_on && h->sk_err_h) *h->sk_err_h = 1;   // (test hook: what a timed-out combine stores)
     if (q_d) DDRL_HIP_CHECK(hipMemcpy2DAsync(q_d, (size_t)h->cfg.n_actions * sizeof(float), h->Q, (size_t)h->ldq * sizeof(float),
                                              (size_t)h->cfg.n_actions * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, s));
     return DDRL_OK;

@@ -1860,6 +1860,33 @@ int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, con
     return ddrl_sac1_apply_grads(h, stream);
 }
 
+// train(replay_buffer.sample_batch()) with HOST arrays (example/dsac.py:142-144; algos/sac1/sac1.py:146-148) as ONE call: the caller's
+// page-locked block [obs1 | obs2 | acts | rews | done], laid out like input set 0, goes up with one asynchronous copy, the three noise
+// tensors are generated in place behind it (counter-based, ddrl_normal_fill), and the update reads the input set it owns.
+int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
+                        void *stream) {
+    DDRL_REQUIRE(h != nullptr && block_h != nullptr, "NULL pointer");
+    const ddrl_sac1_config_t &c = h->cfg;
+    const long long B = c.batch, m = B * c.act_dim;
+    float **in0 = h->in[0];
+    // the five items of set 0 in one span with nothing but alignment padding between them, the noise tensors behind one another
+    const long long need[5] = {B * c.obs_dim, B * c.obs_dim, m, B, B};
+    for (int j = 0; j < 4; ++j) {
+        const long long gap = (in0[j + 1] - in0[j]) - need[j];
+        DDRL_REQUIRE(gap >= 0 && gap < 64, "input set 0 is not one contiguous span: use ddrl_sac1_step with device pointers");
+    }
+    DDRL_REQUIRE(n_floats == (in0[4] - in0[0]) + B, "block length differs from input set 0's span");
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    DDRL_HIP_CHECK(hipMemcpyAsync(in0[0], block_h, (size_t)n_floats * sizeof(float), hipMemcpyHostToDevice, s));
+    int rc = DDRL_OK;
+    if (in0[6] - in0[5] == m && in0[7] - in0[6] == m) rc = ddrl_normal_fill(in0[5], 3 * m, noise_seed, noise_ctr, stream);
+    else
+        for (int i = 0; i < 3 && rc == DDRL_OK; ++i) rc = ddrl_normal_fill(in0[5 + i], m, noise_seed, noise_ctr + (uint64_t)(i * m), stream);
+    if (rc != DDRL_OK) return rc;
+    return ddrl_sac1_step(h, in0[0], in0[1], in0[2], in0[3], in0[4], in0[5], in0[6], in0[7], losses_d, nullptr, nullptr, nullptr, stream);
+}
+
 }  // extern "C"
 
 __global__ void k_opt_copy(const OptState *src, OptState *dst) { *dst = *src; }

@@ -119,7 +119,10 @@ class Learner:
         return list(self.keys), [flat[o:o + n].reshape(s).copy() for (o, n, s) in (self.table[k] for k in self.keys)]
 
     def set_weights(self, variable_names, weights):
-        flat = self.export()
+        # every variable given: nothing of the current parameters survives, so nothing is read back (a learner whose stream-K combine
+        # timed out refuses to export — fresh parameters are exactly what it is waiting for)
+        full = set(self.keys) <= set(variable_names)
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=self.device) if full else self.export()
         for k, w in zip(variable_names, weights):
             if k not in self.table:
                 continue

@@ -11,11 +11,41 @@ replay, learner and environments live in the same device's HBM).  Semantics kept
     algos/sac1/sac_ray.py:316-317 relies on this);
   * `.remote()` returns immediately with a future; `store.remote(...)` may be fire-and-forget;
   * tasks run concurrently (one thread each); exceptions surface at `get`.
+  * a Ray actor is a process of its own: its device work never queues behind its callers'.  Here every actor thread issues its
+    device work on a HIP stream of its own (non-blocking), so a replay actor's `sample_batch` (gather + copy down) runs beside
+    the learner's update instead of behind it on the shared default stream — what lets the reference's `Cache` prefetch
+    (algos/sac1/sac1.py:103-130) hide the sample behind the train on the host-buffer surface.  Arguments and results cross as
+    in Ray, by value: a CUDA tensor handed to an actor is waited for (event) before the method runs, and an actor drains its
+    stream before a result that holds CUDA tensors is published.
 If a real Ray is present the same classes can be wrapped by `ray.remote` unchanged.
 """
 import queue
 import threading
 from concurrent.futures import Future, wait as _fwait, FIRST_COMPLETED
+
+
+def _has_cuda(x, depth=0):
+    """Does a (shallowly nested) argument / result hold a CUDA tensor?"""
+    if hasattr(x, "is_cuda"):
+        return bool(x.is_cuda)
+    if depth < 2:
+        if isinstance(x, (list, tuple)):
+            return any(_has_cuda(v, depth + 1) for v in x)
+        if isinstance(x, dict):
+            return any(_has_cuda(v, depth + 1) for v in x.values())
+    return False
+
+
+def _record_default(x, depth=0):
+    """Device tensors an actor hands out were allocated on ITS stream; the caller most likely reads them on the default stream:
+    tell the caching allocator, so that the block is not given out again before that stream has passed the reads."""
+    import torch
+    if hasattr(x, "is_cuda"):
+        if x.is_cuda:
+            x.record_stream(torch.cuda.default_stream(x.device))
+    elif depth < 2:
+        for v in (x.values() if isinstance(x, dict) else x if isinstance(x, (list, tuple)) else ()):
+            _record_default(v, depth + 1)
 
 
 class _ActorMethod:
@@ -24,7 +54,12 @@ class _ActorMethod:
 
     def remote(self, *args, **kwargs):
         fut = Future()
-        self._actor._mailbox.put((self._name, args, kwargs, fut))
+        ev = None
+        if self._actor._stream is not None and (_has_cuda(args) or _has_cuda(kwargs)):
+            import torch
+            ev = torch.cuda.Event()
+            ev.record()                        # the caller's stream, as far as it has been issued: the actor's stream waits for it
+        self._actor._mailbox.put((self._name, args, kwargs, fut, ev))
         return fut
 
 
@@ -41,6 +76,7 @@ class ActorHandle:
         self._mailbox = queue.Queue()
         self._obj = None
         self._device = _current_device()   # torch's current device is thread-local and starts at 0 in a new thread
+        self._stream = None
         ready = Future()
         self._thread = threading.Thread(target=self._run, args=(cls, args, kwargs, ready), daemon=True)
         self._thread.start()
@@ -51,7 +87,11 @@ class ActorHandle:
             if self._device is not None:
                 import torch
                 torch.cuda.set_device(self._device)   # the actor allocates on its creator's GPU, not on cuda:0
+                self._stream = torch.cuda.Stream()    # (non-blocking: no implicit ordering against the default stream)
+                torch.cuda.set_stream(self._stream)
             self._obj = cls(*args, **kwargs)
+            if self._stream is not None:
+                self._stream.synchronize()            # what the constructor queued (ring fill, parameter upload) has landed
             ready.set_result(True)
         except BaseException as e:  # noqa
             ready.set_exception(e)
@@ -60,11 +100,17 @@ class ActorHandle:
             item = self._mailbox.get()
             if item is None:
                 return
-            name, a, k, fut = item
+            name, a, k, fut, ev = item
             if not fut.set_running_or_notify_cancel():
                 continue
             try:
-                fut.set_result(getattr(self._obj, name)(*a, **k))
+                if ev is not None:
+                    self._stream.wait_event(ev)
+                res = getattr(self._obj, name)(*a, **k)
+                if self._stream is not None and _has_cuda(res):
+                    self._stream.synchronize()
+                    _record_default(res)
+                fut.set_result(res)
             except BaseException as e:  # noqa
                 fut.set_exception(e)
 

@@ -192,28 +192,42 @@ def worker_rollout_sac1(ps, replay_buffer, opt, worker_index, make_env=None, mak
             o, r, d, ep_ret, ep_len = env.reset(), 0, False, 0, 0
 
 
-def worker_train_sac1(ps, replay_buffer, opt, learner_index, make_agent=None):
-    """algos/sac1/sac1.py:133-154.  The reference hides the sample RPC behind a `Cache` helper
-    process (depth-10 batch queue, depth-5 weight queue, sac1.py:103-130); with replay and learner
-    in the same HBM the sample is one kernel on the learner's stream and the prefetch queue has
-    nothing left to hide."""
+def worker_train_sac1(ps, replay_buffer, opt, learner_index, make_agent=None, make_cache=None):
+    """algos/sac1/sac1.py:133-154: the learner behind the `Cache` helper of sac1.py:103-130 — up to ten sampled batches wait in
+    q1 (the helper keeps calling `replay_buffer.sample_batch(opt.batch_size)`), the learner takes them in order, and every
+    push_freq-th update's weights go through q2 to `ps.push`.  On this host-buffer surface a batch crosses PCIe down and up again;
+    the helper's sample of batch i + 1 runs — on the replay actor's own stream (remote.py) — beside the learner's update i, which is
+    what the reference's Cache is for.  The batches and their order are exactly those of the loop without the helper
+    (`batch = sample_batch(); train(batch)`): one buffer, one FIFO queue (tests/test_gpu_driver.py).
+    make_cache=False: no helper (rounds 1-5)."""
     if make_agent is None:
         from .agent import Learner
         make_agent = lambda o_: Learner(o_, job="learner")
+    if make_cache is None:
+        make_cache = lambda rb: BatchCache(rb, opt, [ps], nodes=None)
     agent = make_agent(opt)
     keys = agent.get_weights()[0]
     weights = _get(_remote(ps.pull, keys))
     agent.set_weights(keys, weights)
     push_freq = int(getattr(opt, "push_freq", 300))
     max_updates = getattr(opt, "max_updates", None)
+    cache = make_cache(replay_buffer) if make_cache else None
+    if cache is not None:
+        cache.start()
     cnt = 1
     while True:
-        batch = _get(_remote(replay_buffer.sample_batch, opt.batch_size))
+        batch = cache.q1.get() if cache is not None else _get(_remote(replay_buffer.sample_batch, opt.batch_size))
         agent.train(batch)
         if cnt % push_freq == 0:
-            keys, values = agent.get_weights()
-            _remote(ps.push, keys, values)
+            if cache is not None:
+                cache.q2.put(agent.get_weights())
+            else:
+                keys, values = agent.get_weights()
+                _remote(ps.push, keys, values)
         if (max_updates is not None and cnt >= max_updates) or _stop(opt):
+            end = getattr(cache, "end", None)
+            if end is not None:
+                end()
             return cnt
         cnt += 1
 
@@ -276,8 +290,9 @@ class BatchCache:
     daemon process; device-backed handles cannot cross a process boundary, so this one is a daemon thread over the same two queues."""
 
     def __init__(self, node_buffer, opt, node_ps, rng=None, nodes=True):
-        """nodes=False: the single-server form of algos/sac1/sac_ray.py:123-153 (and algos/sac1/sac1.py:103-130) — `node_buffer` is
-        one flat list of buffers, the weights go to node_ps[0], q1 holds ten."""
+        """nodes=False: the single-server form of algos/sac1/sac_ray.py:123-153 — `node_buffer` is one flat list of buffers, the
+        weights go to node_ps[0], q1 holds ten.  nodes=None: algos/sac1/sac1.py:103-130 — `node_buffer` is THE replay buffer (one
+        handle), every batch is `sample_batch(opt.batch_size)` of it, the weights go to node_ps[0], q1 holds ten."""
         import queue
         import threading
         self.node_buffer, self.opt, self.node_ps, self.nodes = node_buffer, opt, node_ps, nodes
@@ -303,6 +318,9 @@ class BatchCache:
 
     def _one_batch(self, q1, node_buffer):
         import numpy as np
+        if self.nodes is None:
+            q1.put(_get(_remote(node_buffer.sample_batch, self.opt.batch_size)))   # (fresh arrays per call: the reference's deepcopy)
+            return
         rng = self.rng if self.rng is not None else np.random
         if not self.nodes:
             q1.put(_get(_remote(node_buffer[rng.choice(self.opt.num_buffers, 1)[0]].sample_batch)))
@@ -594,6 +612,7 @@ class RolloutDevice:
         self.adopt = getattr(opt, "adopt", "episode")
         assert self.adopt in ("episode", "step"), self.adopt
         self._versions = False
+        self.auto_pull = True     # step() looks at the server itself; FreeRunningLoop turns it off and pulls at segment boundaries
         self.pull()
         if self.adopt == "episode" and self._fused is None:
             self._fused_ready()   # the version store starts from the initial pull (dsac.py:88-90), before any step
@@ -640,7 +659,7 @@ class RolloutDevice:
         random-action phase (t <= start_steps) and shapes outside the envelope: get_action / env.step / store launches."""
         from . import _lib
         env = self.env
-        if self._versions:
+        if self._versions and self.auto_pull:
             self.pull()   # what the server holds NOW is what an env ending its episode in this step pulls (dsac.py:127-130)
         if self.t > self.opt.start_steps and self._fused_ready():
             if not self._fused_live:   # the unfused path has stepped the envs since: refresh the actor's observation rows
@@ -651,7 +670,7 @@ class RolloutDevice:
                                                 _lib.dptr(env.obs), _lib.stream_ptr()))
             a._noise_ctr += int(n_steps) * env.n * a.cfg.act_dim
             self.t += int(n_steps)
-            if not self._versions:
+            if not self._versions and self.auto_pull:
                 self.pull()
             return
         if n_steps > 1:
@@ -669,7 +688,7 @@ class RolloutDevice:
             self.actor.adopt_where_ended(ended)
         self.rb.store_batch(self.o, self.act, r, o2, d)
         self.t += 1
-        if not self._versions:
+        if not self._versions and self.auto_pull:
             self.pull()
 
 
@@ -907,3 +926,135 @@ class ActorLearnerLoop:
 
     def counts(self):
         return self.trainer.rb.get_counts()
+
+
+_FREE_STREAMS = {}
+
+
+def _free_streams(torch):
+    dev = torch.cuda.current_device()
+    if dev not in _FREE_STREAMS:
+        _FREE_STREAMS[dev] = (torch.cuda.Stream(), torch.cuda.Stream())
+    return _FREE_STREAMS[dev]
+
+
+class FreeRunningLoop:
+    """example/dsac.py:229-236 starts its rollout and learner tasks and leaves them running — `worker_rollout` (dsac.py:76-130) and
+    `worker_train` (dsac.py:133-150) have NO gate between them: nothing couples them but the replay buffer's store / sample_batch
+    calls and the parameter server's push / pull.  Device form of that asynchrony on ONE GPU: the vectorised rollout free-runs on
+    its own HIP stream while the learner's graph loop trains on another, in segments of `steps_per_segment` vector steps beside
+    `updates_per_segment` updates.
+
+    What crosses between the two streams crosses at segment boundaries, behind events — kernels of two streams that overlap in
+    time have no coherent view of each other's stores on this part (per-XCD L2s), so nothing is shared while it is being written:
+      * store: the rollout appends to one of two STAGING rings of exactly steps_per_segment x num_envs rows (a vector step is still
+        `num_envs` reference store() calls, in env order); when the learner's segment is over and the rollout's staging ring is
+        complete, the learner's stream commits it to the replay ring with one store_batch — the same rows in the same order the
+        direct stores would have written, `steps` advancing by the same count.  The reference's store is a fire-and-forget RPC
+        (dsac.py:112): a transition reaches the buffer some queueing delay after the env step that produced it; here that delay
+        is at most one segment.
+      * pull: the rollout adopts what the server held at the END of the learner's previous segment (per env at that env's own
+        episode end, through the actor's version store, exactly as in RolloutDevice); the learner's pushes of the running segment
+        are not looked at until the boundary.
+    Neither side ever waits for the other INSIDE a segment; at a boundary the rollout waits for the learner's previous segment
+    (its pushes) and the commit waits for the rollout's segment.  With both segment lengths about equal in time both streams stay
+    busy.  The index streams stay exactly the replay ring's own (one MT19937 draw per update, in update order); which transitions
+    the ring holds at a given update is timing-free too (commits sit at fixed points of the update sequence), so a run is
+    reproducible — unlike the reference's."""
+
+    def __init__(self, rollout, trainer, opt, steps_per_segment=64, updates_per_segment=None, timing=False, streams=None):
+        import torch
+        from .replay import ReplayBufferSAC1
+        self.rollout, self.trainer, self.opt = rollout, trainer, opt
+        self.timing, self.marks = bool(timing), []
+        self.K = int(steps_per_segment)
+        self.n = int(self.K if updates_per_segment is None else updates_per_segment)
+        self.rb = trainer.rb
+        n_env = int(opt.num_envs)
+        self.rows = self.K * n_env
+        assert self.rows <= self.rb.max_size, "a segment's transitions must fit the replay ring"
+        self.stage = [ReplayBufferSAC1(opt.obs_dim, opt.act_dim, self.rows) for _ in range(2)]
+        self.views = [st.rings() for st in self.stage]
+        # streams=(s, s): both halves on ONE stream — the same launches in the order [pull, K vector steps, n updates, commit] per
+        # segment: what the two-stream run must equal bit for bit (tests)
+        # (the pair is created once per device and reused: the runtime multiplexes streams onto a handful of hardware queues —
+        # four by default — and a later pair can land on ONE queue, where the two halves then run strictly one after the other;
+        # measured: the second FreeRunningLoop of a process took 9.7 ms per segment against the first one's 6.1)
+        self.sR, self.sL = streams if streams is not None else _free_streams(torch)
+        self.seg = 0
+        self.ev_roll, self.ev_commit, self.ev_learn, self.ev_pull = {}, {}, {}, {}
+        self.env_steps = self.updates = 0
+        rollout.auto_pull = False
+        # both streams start behind whatever the caller's stream has queued (construction, ring fill, set_weights)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.sR.wait_event(ev)
+        self.sL.wait_event(ev)
+
+    def run(self, segments):
+        import torch
+        ro, tr = self.rollout, self.trainer
+        mk = (lambda: torch.cuda.Event(enable_timing=True)) if self.timing else None
+        for _ in range(int(segments)):
+            s = self.seg
+            m = {}
+            with torch.cuda.stream(self.sR):
+                if s - 1 in self.ev_learn:
+                    self.sR.wait_event(self.ev_learn[s - 1])      # the pushes of the learner's previous segment have landed
+                if mk:
+                    m["r0"] = mk(); m["r0"].record()
+                ro.pull()
+                self.ev_pull[s] = torch.cuda.Event()
+                self.ev_pull[s].record()
+                if s - 2 in self.ev_commit:
+                    self.sR.wait_event(self.ev_commit.pop(s - 2))  # this staging ring's last commit has read it
+                ro.rb = self.stage[s % 2]
+                ro.step(self.K)
+                self.ev_roll[s] = mk() if mk else torch.cuda.Event()
+                self.ev_roll[s].record()
+                m["r1"] = self.ev_roll[s]
+            with torch.cuda.stream(self.sL):
+                self.sL.wait_event(self.ev_pull.pop(s))            # (the pack kernel of that pull reads the server's buffer)
+                if mk:
+                    m["l0"] = mk(); m["l0"].record()
+                tr.run(self.n)
+                self.ev_learn[s] = mk() if mk else torch.cuda.Event()
+                self.ev_learn[s].record()
+                m["l1"] = self.ev_learn[s]
+                self.sL.wait_event(self.ev_roll.pop(s))
+                if mk:
+                    m["c0"] = mk(); m["c0"].record()
+                v = self.views[s % 2]
+                self.rb.store_batch(v["obs1_buf"], v["acts_buf"], v["rews_buf"], v["obs2_buf"], v["done_buf"])
+                self.ev_commit[s] = mk() if mk else torch.cuda.Event()
+                self.ev_commit[s].record()
+                m["c1"] = self.ev_commit[s]
+            if mk:
+                self.marks.append(m)
+            self.ev_learn.pop(s - 1, None)
+            self.seg += 1
+            self.env_steps += self.rows
+            self.updates += self.n
+
+    def drain(self):
+        """Both streams empty (and the caller's stream ordered behind them)."""
+        import torch
+        self.sR.synchronize()
+        self.sL.synchronize()
+        torch.cuda.current_stream().synchronize()
+
+    def segment_times(self, last=8):
+        """timing=True: mean device time (ms) of the last segments' phases — the rollout's K vector steps, the learner's n updates, the
+        commit — and the segment's span on the learner stream (start of its updates to the end of its commit)."""
+        self.drain()
+        ms = self.marks[-int(last):]
+        if not ms:
+            return None
+        avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in ms) / len(ms)
+        return {"rollout_ms": avg("r0", "r1"), "learner_ms": avg("l0", "l1"), "commit_ms": avg("c0", "c1"), "segment_ms": avg("l0", "c1"),
+                "segments": len(ms)}
+
+    def close(self):
+        """Back to one stream: the rollout stores into the replay ring again and looks at the server itself."""
+        self.drain()
+        self.rollout.rb, self.rollout.auto_pull = self.rb, True

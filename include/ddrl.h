@@ -286,6 +286,15 @@ int ddrl_sac1_step_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay,
  * input set set_in while the sampler of the NEXT batch rides in a forward launch and gathers into set_out. */
 int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t *replay, int set_out, void *stream);
 
+/* The reference's learner loop body with HOST arrays — `agent.train(replay_buffer.sample_batch())`, example/dsac.py:142-144,
+ * algos/sac1/sac1.py:146-148 — as one call: block_h (page-locked host memory; n_floats floats) holds obs1, obs2, acts, rews, done at
+ * the offsets the five buffers of ddrl_sac1_input_buffers(h, 0, .) have from the first one (DDRL_ERR_BAD_ARG if those do not form one
+ * span); it goes up with one asynchronous copy, eps_x / eps_x2 / eps_t are generated in place exactly as three ddrl_normal_fill calls
+ * at noise_ctr, noise_ctr + B*act, noise_ctr + 2*B*act would, then one ddrl_sac1_step on that set.  The block may be rewritten once
+ * work queued on `stream` behind this call has started (record an event after the call and wait for it). */
+int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
+                        void *stream);
+
 /* For a caller that captures update sequences into a graph of its own (partition.py captures `gradients -> RCCL all-reduce ->
  * apply` of the data-parallel learners with torch.cuda.graph; the reference has no counterpart: its learners never
  * synchronise, example/dsac.py:59-62,233): puts the learner's double-buffered optimizer state / dgrad image on copy 0.  Call
@@ -371,7 +380,12 @@ int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream
 int ddrl_actor_get_weights(ddrl_actor_t *h, float *flat_pi_d, void *stream);
 /* get_action for n observations: act = tanh(mu + eps*exp(log_std))*act_scale, or
  * tanh(mu)*act_scale when deterministic (core.py:49-87,104-106).  obs_d[n,obs], eps_d[n,act]
- * (ignored when deterministic; may be NULL then), act_d[n,act].  n <= max_rows. */
+ * (ignored when deterministic; may be NULL then), act_d[n,act].  n <= max_rows.
+ * Threading / capture: an actor handle belongs to ONE host thread and ONE stream at a time.  For policies inside the direct-operand
+ * envelope ddrl_actor_set_weights only packs the direct-layout copy; the row-major copy this call (and get_weights) reads is rebuilt
+ * lazily, by a launch this call issues the first time after a set_weights (a host-side flag).  A caller that captures
+ * ddrl_actor_act into a graph of its own must therefore call it once eagerly after every set_weights before capturing or
+ * replaying — a captured call replays "no rebuild" and would act on the weights of the capture. */
 int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int64_t n,
                    int deterministic, float *act_d, void *stream);
 

@@ -161,6 +161,79 @@ def test_actor_learner_ratio_gate():
     assert ps.version > v0                        # the learner pushed (every 50th update)
 
 
+def test_free_running_loop_two_streams_equal_the_one_stream_order():
+    """example/dsac.py:229-236 leaves rollouts and learner running with no gate between them.  FreeRunningLoop runs the vectorised
+    rollout and the learner's graph loop on TWO streams, exchanging transitions (staging ring -> commit) and weights (pull of the
+    learner's previous segment) at segment boundaries only.  Nothing inside a segment depends on the other stream, so the run must
+    equal — bit for bit: parameters, ring contents, counters, sampler state, the envs — the same launches issued on ONE stream in
+    the order [pull, K vector steps, n updates, commit]; and it is reproducible run to run."""
+    import distributed_drl_amd as d
+    from distributed_drl_amd.agent import HyperParameters, Learner
+
+    def run_it(one_stream):
+        opt = HyperParameters()
+        opt.num_envs, opt.start_steps, opt.batch_size, opt.hidden_sizes, opt.push_freq, opt.max_ep_len, opt.seed = 64, -1, 32, (64, 32), 6, 40, 3
+        rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 2000, seed=5)
+        rs = np.random.RandomState(1)
+        m = 300
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in (
+            rs.randn(m, 8).astype(np.float32), rs.uniform(-1, 1, (m, 2)).astype(np.float32), rs.randn(m).astype(np.float32),
+            rs.randn(m, 8).astype(np.float32), np.zeros(m, np.float32))))
+        net = Learner(opt)
+        ps = d.ParameterServer(*net.get_weights())
+        roll, tr = d.RolloutDevice(ps, rb, opt), d.TrainDevice(ps, rb, opt, updates_per_graph=4)
+        st = torch.cuda.current_stream()
+        loop = d.FreeRunningLoop(roll, tr, opt, steps_per_segment=5, updates_per_segment=9, streams=(st, st) if one_stream else None)
+        loop.run(7)                                  # 35 vector steps (2240 transitions: the 2000-row ring wraps), 63 updates, pushes at 6, 12, ...
+        loop.close()
+        assert (loop.env_steps, loop.updates) == (7 * 5 * 64, 63)
+        assert rb.get_counts() == (63, m + 7 * 5 * 64, 2000)
+        assert ps.version >= 10 and roll.rb is rb
+        rings = {k: v.clone() for k, v in rb.rings().items()}
+        key, pos = rb.mt_state()
+        return tr.agent.get_weights_flat().cpu().numpy(), rings, (key.copy(), pos), roll.env.obs.clone(), roll.actor.get_weights_flat().cpu().numpy()
+
+    a, b, c = run_it(False), run_it(True), run_it(False)
+    for x, y in ((a, b), (a, c)):
+        np.testing.assert_array_equal(x[0], y[0])
+        for k in x[1]:
+            assert torch.equal(x[1][k], y[1][k]), k
+        np.testing.assert_array_equal(x[2][0], y[2][0])
+        assert x[2][1] == y[2][1] and torch.equal(x[3], y[3])
+        np.testing.assert_array_equal(x[4], y[4])
+
+
+def test_worker_train_sac1_behind_the_cache_equals_the_plain_loop():
+    """algos/sac1/sac1.py:103-154: the learner takes its batches from the Cache helper's queue (q1, depth 10) and leaves its weights in
+    q2.  One buffer, one FIFO queue: the learner trains on exactly the batches, in exactly the order, of `batch = sample_batch();
+    train(batch)` without the helper — the server ends on bit-identical weights (pushes after updates 16 and 32)."""
+    import distributed_drl_amd as d
+    from distributed_drl_amd import remote as ray
+    from distributed_drl_amd.agent import HyperParameters, Learner
+
+    def run_it(cached):
+        opt = HyperParameters()
+        opt.batch_size, opt.hidden_sizes, opt.push_freq, opt.max_updates, opt.seed = 64, (64, 32), 16, 40, 2
+        ray.init()
+        net = Learner(opt)
+        ps = ray.remote(d.ParameterServer).remote(*net.get_weights())
+        rb = ray.remote(d.ReplayBufferSAC1).remote(opt.obs_dim, opt.act_dim, 5000, None, 11)
+        rs = np.random.RandomState(4)
+        for _ in range(200):
+            rb.store.remote(rs.randn(8), rs.uniform(-1, 1, 2), float(rs.randn()), rs.randn(8), bool(rs.rand() < 0.1))
+        n = d.worker_train_sac1(ps, rb, opt, 0) if cached else d.worker_train_sac1(ps, rb, opt, 0, make_cache=False)
+        assert n == 40
+        w = ray.get(ps.get_weights.remote())
+        samples, steps, size = ray.get(rb.get_counts.remote())
+        assert steps == 200 and (samples == 40 if not cached else 40 <= samples <= 40 + 12)   # the helper had drawn ahead
+        return w
+
+    a, b = run_it(True), run_it(False)
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_checkpoint_resume_formats(tmp_path):
     """N3: (a) weights pickle {name: ndarray} + per-node recover (algos/dqn/train.py:111-174);
     (b) full learner state: a learner restored from save_state() continues bit-identically."""

@@ -471,6 +471,34 @@ def test_wide_layer1_shapes(ddrl, variant, obs, acts, hid, batch, misalign):
         np.testing.assert_allclose(learner.q_values(x).cpu().numpy(), qn.numpy(), rtol=1e-3, atol=1e-4)
 
 
+def test_stream_k_timeout_poisons_the_learner_until_it_gets_fresh_parameters(ddrl, monkeypatch):
+    """k_wide_sk's combine gives up after ~1 s without its partner's slab and raises a sticky host-mapped word: that update's layer-1
+    gradient was wrong, and every later step built on it.  The learner must then refuse to step AND to hand its parameters out
+    (get_weights / export: a push or a checkpoint of corrupted weights) until it is given fresh ones; afterwards it runs the
+    tile-per-workgroup kernel.  DDRL_SK_POISON_AFTER=n makes the host raise the word behind the n-th step."""
+    from distributed_drl_amd import _lib, dqn
+
+    class Opt:
+        obs_dim, act_dim, hidden_size, gamma, lr, polyak, batch_size, seed, alpha = 28224, 4, [400, 300], 0.99, 1e-3, 0.995, 512, 2, 0.1
+    monkeypatch.setenv("DDRL_SK_POISON_AFTER", "2")
+    learner = dqn.Learner(Opt, "learner")
+    monkeypatch.delenv("DDRL_SK_POISON_AFTER")
+    keys, vals = learner.get_weights()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    b = {"obs1": torch.randint(0, 256, (512, Opt.obs_dim), device="cuda", generator=g).float(), "obs2": torch.randint(0, 256, (512, Opt.obs_dim), device="cuda", generator=g).float(),
+         "acts": torch.randint(0, 4, (512,), device="cuda", generator=g).float(), "rews": torch.randn(512, device="cuda", generator=g), "done": torch.zeros(512, device="cuda")}
+    learner.train(b, 0)
+    learner.train(b, 1)                       # the word is raised behind this step's launches
+    with pytest.raises(_lib.DdrlError, match="k_wide_sk"):
+        learner.get_weights()                 # seen with the stream drained: nothing corrupted leaves the learner
+    with pytest.raises(_lib.DdrlError, match="k_wide_sk"):
+        learner.train(b, 2)                   # sticky: not a one-off report
+    learner.set_weights(keys, vals)           # fresh parameters: usable again (tile-per-workgroup layer-1 gradient from here on)
+    learner.train(b, 3)
+    k2, v2 = learner.get_weights()
+    assert k2 == keys and all(np.isfinite(v).all() for v in v2)
+
+
 def test_ddqn_learner_at_the_config5_observation_width(ddrl):
     """BASELINE config 5's learner input: flat 84x84x4 = 28 224-wide observations (algos/dqn/train.py:43-52) through the
     Double-DQN learner — layer 1 is a K = 28 224 GEMM (csrc/wide_l1.h).  One update vs the float64 oracle; the

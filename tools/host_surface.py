@@ -23,6 +23,18 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(300): lh.train(rbh.sample_batch(B))
 torch.cuda.synchronize(); t_iter = (time.perf_counter() - t0) / 300
 print("store %.1f us  sample_batch %.1f us  sample+train %.1f us" % (t_store * 1e6, t_samp * 1e6, t_iter * 1e6))
+# the reference's own remedy for that loop: worker_train behind the Cache helper (algos/sac1/sac1.py:103-154) — replay buffer and
+# parameter server as actors (remote.py: a thread + a HIP stream each), the helper drawing batch i + 1 while update i trains
+from distributed_drl_amd import remote as ray
+opt.max_updates, opt.push_freq = 3000, 300
+for cached in (False, True, False, True):
+    ps_a = ray.remote(d.ParameterServer).remote(*lh.get_weights())
+    rb_a = ray.remote(d.ReplayBufferSAC1).remote(8, 2, 100000, None, 5)
+    ray.get(rb_a.store_batch.remote(torch.randn(m, 8).cuda(), torch.rand(m, 2).cuda(), torch.randn(m).cuda(), torch.randn(m, 8).cuda(), torch.zeros(m).cuda()))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n_upd = d.worker_train_sac1(ps_a, rb_a, opt, 0, make_agent=lambda o_: lh) if cached else d.worker_train_sac1(ps_a, rb_a, opt, 0, make_agent=lambda o_: lh, make_cache=False)
+    torch.cuda.synchronize(); t_w = (time.perf_counter() - t0) / n_upd
+    print("worker_train_sac1 over actor handles, %s: %.1f us per update = %.0f updates/s" % ("Cache helper" if cached else "no helper  ", t_w * 1e6, 1.0 / t_w))
 # per-step policy calls of the reference-style rollout workers (one observation up, one action down)
 from distributed_drl_amd.agent import Actor
 from distributed_drl_amd import dqn
