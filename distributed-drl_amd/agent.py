@@ -237,9 +237,12 @@ class Learner(_Net):
             p = [int(bufs[i]) for i in range(8)]
             n = (B * o, B * o, B * a, B, B)
             off = [(p[j] - p[0]) // 4 for j in range(5)]
-            # one block copy covers [obs1 | obs2 | acts | rews | done]: the five items must lie in this order with nothing but alignment
-            # padding between them (a layout with another live buffer in a gap would be overwritten by the copy)
-            ok = all((p[j] - p[0]) % 4 == 0 for j in range(5)) and all(0 <= off[j + 1] - (off[j] + n[j]) < 64 for j in range(4))
+            # one block copy covers [obs1 | obs2 | acts | rews | done]: the five items must follow one another exactly as the learner
+            # allocates them — rup32(batch) rows each on the direct path (the rows past the batch are zero padding and stay zero: the
+            # page-locked block holds zeros there), rounded up to 64 floats — so that no other live buffer lies inside the span
+            Bp = (B + 31) // 32 * 32 if self._lib.ddrl_sac1_is_fused(self._h) == 1 else B
+            alloc = [(Bp * w + 63) // 64 * 64 for w in (o, o, a, 1, 1)]
+            ok = all((p[j] - p[0]) % 4 == 0 for j in range(5)) and all(off[j + 1] - off[j] == alloc[j] for j in range(4))
             if not ok:
                 st = self._fast = False
             else:
@@ -247,8 +250,8 @@ class Learner(_Net):
                 hosts = [torch.zeros(span, dtype=torch.float32).pin_memory() for _ in range(2)]
                 st = self._fast = {"p": p, "off": off, "n": n, "span": span, "host": hosts, "np": [h.numpy() for h in hosts],
                                    "hp": [ctypes.c_void_p(h.data_ptr()) for h in hosts],
-                                   "ev": [torch.cuda.Event(), torch.cuda.Event()], "used": [False, False], "turn": 0,
-                                   "eps_contig": p[6] - p[5] == 4 * B * a and p[7] - p[6] == 4 * B * a}
+                                   "ev": [torch.cuda.Event(), torch.cuda.Event()], "used": [False, False], "turn": 0, "one_block": Bp == B,
+                                   }
         if st is False:
             return None
         t = st["turn"]
@@ -258,7 +261,7 @@ class Learner(_Net):
         hv, off, n = st["np"][t], st["off"], st["n"]
         arrs = [batch[k] for k in ("obs1", "obs2", "acts", "rews", "done")]
         p0 = arrs[0].ctypes.data
-        if all(x.dtype == np.float32 and x.flags.c_contiguous and x.size == n[j] and x.ctypes.data - p0 == 4 * off[j] for j, x in enumerate(arrs)):
+        if st["one_block"] and all(x.dtype == np.float32 and x.flags.c_contiguous and x.size == n[j] and x.ctypes.data - p0 == 4 * off[j] for j, x in enumerate(arrs)):
             # the five arrays are pieces of ONE host block with the input set's own offsets (what ReplayBuffer.sample_batch hands out
             # at the reference's shapes): one memmove instead of five conversions
             ctypes.memmove(st["hp"][t], p0, 4 * st["span"])

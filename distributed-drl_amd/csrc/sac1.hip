@@ -1869,12 +1869,12 @@ int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, 
     const ddrl_sac1_config_t &c = h->cfg;
     const long long B = c.batch, m = B * c.act_dim;
     float **in0 = h->in[0];
-    // the five items of set 0 in one span with nothing but alignment padding between them, the noise tensors behind one another
-    const long long need[5] = {B * c.obs_dim, B * c.obs_dim, m, B, B};
-    for (int j = 0; j < 4; ++j) {
-        const long long gap = (in0[j + 1] - in0[j]) - need[j];
-        DDRL_REQUIRE(gap >= 0 && gap < 64, "input set 0 is not one contiguous span: use ddrl_sac1_step with device pointers");
-    }
+    // the five items of set 0 follow one another exactly as ddrl_sac1_create lays them out: rup32(batch) rows each on the direct path
+    // (the caller's block holds zeros in the padding rows), every item rounded up to 64 floats — no other buffer inside the span
+    const long long Bp = h->fused ? rup32(B) : B;
+    const long long w[5] = {c.obs_dim, c.obs_dim, c.act_dim, 1, 1};
+    for (int j = 0; j < 4; ++j)
+        DDRL_REQUIRE(in0[j + 1] - in0[j] == ((Bp * w[j] + 63) & ~63ll), "input set 0 is not one contiguous span: use ddrl_sac1_step with device pointers");
     DDRL_REQUIRE(n_floats == (in0[4] - in0[0]) + B, "block length differs from input set 0's span");
     ddrl::DeviceGuard g(h->device);
     hipStream_t s = ddrl::as_stream(stream);

@@ -82,9 +82,57 @@ class ReplayBuffer:
         _lib.check(self._lib.ddrl_replay_store(self._h, _lib.dptr(obs), _lib.dptr(act), _lib.dptr(rew),
                                                _lib.dptr(next_obs), _lib.dptr(done), n, _lib.stream_ptr()))
 
+    def prefetch(self, batch_size=None, depth=12, hold=2):
+        """The reference's `Cache` (algos/sac1/sac1.py:103-130: a helper that keeps ten sampled batches waiting so that the learner never
+        waits for a sample) INSIDE the buffer: from now on `depth - hold` sample_batch(batch_size) draws are always in flight — index
+        draw, gather and the copy down into page-locked host blocks, queued on the buffer's stream — and sample_batch(batch_size)
+        hands out the oldest one, waiting only if it has not landed yet.  Batches, and their order, are exactly those of the calls
+        without prefetch (one sampler, one queue); what changes is WHEN a batch was drawn: up to `depth - hold` calls earlier, so
+        transitions stored in between are not in it — the reference's Cache has the same staleness.
+        The arrays of a returned batch are views of a ring of host blocks: valid until `hold` further sample_batch calls (copy them to
+        keep them longer).  prefetch(0) turns it off."""
+        pf = getattr(self, "_pf", None)
+        if pf is not None:
+            torch.cuda.current_stream().synchronize()
+            self._pf = None
+        B = int(self._default_batch if batch_size is None else batch_size)
+        if B <= 0 or depth <= 0:
+            return
+        assert 1 <= hold < depth
+        o, a = self.obs_dim, self.act_dim
+        offs = [0]
+        for n in (B * o, B * o, B * a, B, B):
+            offs.append((offs[-1] + n + 3) & ~3)
+        dev = [torch.empty(offs[5], dtype=torch.float32, device=self.device) for _ in range(depth)]
+        host = [torch.empty(offs[5], dtype=torch.float32).pin_memory() for _ in range(depth)]
+        views = []
+        for h in host:
+            v = h.numpy()
+            views.append(dict(obs1=v[offs[0]:offs[0] + B * o].reshape(B, o), obs2=v[offs[1]:offs[1] + B * o].reshape(B, o),
+                              acts=v[offs[2]:offs[2] + B * a] if self._acts_1d else v[offs[2]:offs[2] + B * a].reshape(B, a),
+                              rews=v[offs[3]:offs[3] + B], done=v[offs[4]:offs[4] + B]))
+        ptrs = [[d.data_ptr() + 4 * offs[j] for j in range(5)] for d in dev]
+        self._pf = dict(B=B, depth=depth, hold=hold, dev=dev, host=host, views=views, ptrs=ptrs, ev=[torch.cuda.Event() for _ in range(depth)], head=0)
+        for i in range(depth - hold):
+            self._pf_enqueue(i)
+
+    def _pf_enqueue(self, i):
+        pf = self._pf
+        p = pf["ptrs"][i]
+        _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
+        pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
+        pf["ev"][i].record()
+
     def sample_batch(self, batch_size=None):
         """dict(obs1, obs2, acts, rews, done) of fresh float32 NumPy arrays (example/dsac.py:39-45).
         Raises ValueError("high <= 0") on an empty buffer like the reference."""
+        pf = getattr(self, "_pf", None)
+        if pf is not None and pf["B"] == int(self._default_batch if batch_size is None else batch_size):
+            i, D = pf["head"], pf["depth"]
+            pf["head"] = (i + 1) % D
+            pf["ev"][i].synchronize()
+            self._pf_enqueue((i + D - pf["hold"]) % D)       # the block handed out `hold` calls ago goes back into flight
+            return pf["views"][i]
         # gathered into ONE packed device block and brought down with one copy (five device-to-host copies were most of the call);
         # the five arrays are disjoint pieces of that fresh host block
         B = int(self._default_batch if batch_size is None else batch_size)

@@ -199,10 +199,15 @@ def worker_train_sac1(ps, replay_buffer, opt, learner_index, make_agent=None, ma
     the helper's sample of batch i + 1 runs — on the replay actor's own stream (remote.py) — beside the learner's update i, which is
     what the reference's Cache is for.  The batches and their order are exactly those of the loop without the helper
     (`batch = sample_batch(); train(batch)`): one buffer, one FIFO queue (tests/test_gpu_driver.py).
-    make_cache=False: no helper (rounds 1-5)."""
+    make_cache=False: no helper (rounds 1-5).  make_cache="prefetch": the Cache inside the buffer (ReplayBuffer.prefetch: ten draws
+    always in flight on the buffer's stream, no helper thread — three Python threads share one interpreter lock here, where the
+    reference's helper is a process), then the plain loop."""
     if make_agent is None:
         from .agent import Learner
         make_agent = lambda o_: Learner(o_, job="learner")
+    if make_cache == "prefetch":
+        _get(_remote(replay_buffer.prefetch, opt.batch_size))
+        make_cache = False
     if make_cache is None:
         make_cache = lambda rb: BatchCache(rb, opt, [ps], nodes=None)
     agent = make_agent(opt)

@@ -289,7 +289,8 @@ int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t
 /* The reference's learner loop body with HOST arrays — `agent.train(replay_buffer.sample_batch())`, example/dsac.py:142-144,
  * algos/sac1/sac1.py:146-148 — as one call: block_h (page-locked host memory; n_floats floats) holds obs1, obs2, acts, rews, done at
  * the offsets the five buffers of ddrl_sac1_input_buffers(h, 0, .) have from the first one (DDRL_ERR_BAD_ARG if those do not form one
- * span); it goes up with one asynchronous copy, eps_x / eps_x2 / eps_t are generated in place exactly as three ddrl_normal_fill calls
+ * span; where an item is allocated with more rows than the batch — the direct path pads to whole 32-row tiles — the block must hold
+ * zeros there); it goes up with one asynchronous copy, eps_x / eps_x2 / eps_t are generated in place exactly as three ddrl_normal_fill calls
  * at noise_ctr, noise_ctr + B*act, noise_ctr + 2*B*act would, then one ddrl_sac1_step on that set.  The block may be rewritten once
  * work queued on `stream` behind this call has started (record an event after the call and wait for it). */
 int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,

@@ -733,3 +733,35 @@ def test_nstep_ring_random_walk(ddrl, seed):
             rings = buf.rings()
             for k in ("buffer_o", "buffer_a", "buffer_r", "buffer_d"):
                 np.testing.assert_array_equal(rings[k].cpu().numpy().reshape(getattr(ora, k).shape), getattr(ora, k), err_msg="op %d %s" % (op, k))
+
+
+def test_prefetch_hands_out_the_same_batches_in_the_same_order():
+    """ReplayBuffer.prefetch = the reference's Cache (algos/sac1/sac1.py:103-130) inside the buffer: draws run ahead on the buffer's
+    stream into a ring of page-locked blocks.  One sampler, one queue: the batches, and their order, are exactly those of plain
+    sample_batch calls on an identically seeded buffer; a returned batch stays intact for `hold` further calls; prefetch(0) goes back
+    to fresh arrays with the sampler where the prefetcher left it."""
+    import distributed_drl_amd as d
+    rs = np.random.RandomState(0)
+    m = 3000
+    data = (rs.randn(m, 8).astype(np.float32), rs.uniform(-1, 1, (m, 2)).astype(np.float32), rs.randn(m).astype(np.float32),
+            rs.randn(m, 8).astype(np.float32), (rs.rand(m) < 0.1).astype(np.float32))
+    a, b = d.ReplayBufferSAC1(8, 2, 5000, seed=9), d.ReplayBufferSAC1(8, 2, 5000, seed=9)
+    for rb in (a, b):
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in data))
+    a.prefetch(64, depth=6, hold=2)
+    prev = None
+    for it in range(25):
+        got, want = a.sample_batch(64), b.sample_batch(64)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg="%s @ %d" % (k, it))
+        if prev is not None:                      # the batch of the previous call is still intact (hold = 2)
+            for k in prev[1]:
+                np.testing.assert_array_equal(prev[0][k], prev[1][k])
+        prev = (got, {k: v.copy() for k, v in want.items()})
+    assert a.get_counts()[0] == 25 + 4 and b.get_counts()[0] == 25      # depth - hold draws are in flight
+    a.prefetch(0)
+    for _ in range(4):
+        b.sample_batch(64)                        # the draws the prefetcher had made ahead
+    got, want = a.sample_batch(64), b.sample_batch(64)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k])

@@ -23,18 +23,30 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(300): lh.train(rbh.sample_batch(B))
 torch.cuda.synchronize(); t_iter = (time.perf_counter() - t0) / 300
 print("store %.1f us  sample_batch %.1f us  sample+train %.1f us" % (t_store * 1e6, t_samp * 1e6, t_iter * 1e6))
+# the reference's Cache inside the buffer (ReplayBuffer.prefetch): ten draws always in flight, sample_batch hands out the oldest
+rbh.prefetch(B)
+for _ in range(20): lh.train(rbh.sample_batch(B))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(300): bh = rbh.sample_batch(B)
+t_samp_p = (time.perf_counter() - t0) / 300
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(1000): lh.train(rbh.sample_batch(B))
+torch.cuda.synchronize(); t_iter_p = (time.perf_counter() - t0) / 1000
+rbh.prefetch(0)
+print("with ReplayBuffer.prefetch: sample_batch %.1f us  sample+train %.1f us = %.0f updates/s" % (t_samp_p * 1e6, t_iter_p * 1e6, 1.0 / t_iter_p))
 # the reference's own remedy for that loop: worker_train behind the Cache helper (algos/sac1/sac1.py:103-154) — replay buffer and
 # parameter server as actors (remote.py: a thread + a HIP stream each), the helper drawing batch i + 1 while update i trains
 from distributed_drl_amd import remote as ray
 opt.max_updates, opt.push_freq = 3000, 300
-for cached in (False, True, False, True):
+for cached in (False, True, "prefetch", False, True, "prefetch"):
     ps_a = ray.remote(d.ParameterServer).remote(*lh.get_weights())
     rb_a = ray.remote(d.ReplayBufferSAC1).remote(8, 2, 100000, None, 5)
     ray.get(rb_a.store_batch.remote(torch.randn(m, 8).cuda(), torch.rand(m, 2).cuda(), torch.randn(m).cuda(), torch.randn(m, 8).cuda(), torch.zeros(m).cuda()))
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n_upd = d.worker_train_sac1(ps_a, rb_a, opt, 0, make_agent=lambda o_: lh) if cached else d.worker_train_sac1(ps_a, rb_a, opt, 0, make_agent=lambda o_: lh, make_cache=False)
+    n_upd = d.worker_train_sac1(ps_a, rb_a, opt, 0, make_agent=lambda o_: lh, make_cache={True: None, False: False, "prefetch": "prefetch"}[cached])
     torch.cuda.synchronize(); t_w = (time.perf_counter() - t0) / n_upd
-    print("worker_train_sac1 over actor handles, %s: %.1f us per update = %.0f updates/s" % ("Cache helper" if cached else "no helper  ", t_w * 1e6, 1.0 / t_w))
+    print("worker_train_sac1 over actor handles, %-22s: %.1f us per update = %.0f updates/s" %
+          ({True: "Cache helper thread", False: "no helper", "prefetch": "prefetch in the buffer"}[cached], t_w * 1e6, 1.0 / t_w))
 # per-step policy calls of the reference-style rollout workers (one observation up, one action down)
 from distributed_drl_amd.agent import Actor
 from distributed_drl_amd import dqn
