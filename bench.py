@@ -104,6 +104,7 @@ def parse_args():
     ap.add_argument("--no-stages", action="store_true", help="skip the rollout / store / sample / config-5 stage measurements")
     ap.add_argument("--no-free", action="store_true", help="skip the free-running (ungated, two-stream) measurement at N = 1")
     ap.add_argument("--free-segments", type=int, default=60, help="segments of the free-running measurement's timed region")
+    ap.add_argument("--free-steps", type=int, default=256, help="N > 1, free-running mode: vector steps per rollout rank and step")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds per CPU-baseline leg")
     ap.add_argument("--gpu-seconds", type=float, default=10.0, help="keep repeating the timed block until the GPU legs lasted this long")
     ap.add_argument("--stage-samples", type=int, default=200)
@@ -666,15 +667,20 @@ def main():
             r = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, shard_cap, seed=1000 + rank)
             fill_replay(r, shard_cap, 1234 + rank)
             return r
-        run = partition.PartitionedRun(opt, roles, make_replay, lambda r_: RolloutDevice(None, r_, opt, worker_index=rank),
-                                       lambda: Learner(opt, job="learner", index=rank), seed=opt.seed, updates_per_graph=args.updates_per_graph)
+        def make_run(free_steps):
+            return partition.PartitionedRun(opt, roles, make_replay, lambda r_: RolloutDevice(None, r_, opt, worker_index=rank),
+                                            lambda: Learner(opt, job="learner", index=rank), seed=opt.seed, updates_per_graph=args.updates_per_graph,
+                                            free_steps=free_steps)
+        # --gate free at N > 1 is the free-running mode (partition.py): K vector steps per rollout rank beside the learners' updates,
+        # the next step's blocks in flight under this step's updates, pushes adopted a step later off a communication stream
+        run = make_run(args.free_steps if args.gate == "free" else 0)
 
         def one_step(n_upd=updates_per_step):
             run.step(n_upd)
 
     busy = [0.0]
 
-    def block(n_upd=updates_per_step):
+    def block(n_upd=updates_per_step, one_step=one_step):
         torch.cuda.synchronize()
         comm.barrier()
         t0 = time.perf_counter()
@@ -696,10 +702,26 @@ def main():
             break
         blocks.append(block())
 
-    env_steps = args.steps * num_envs * len(roles.rollouts)
+    vsteps_by_gate = {"hold": 1, "free": args.free_steps if world > 1 else 1}   # vector steps per rollout rank and step
+    env_steps = args.steps * num_envs * len(roles.rollouts) * vsteps_by_gate[args.gate]
     updates = args.steps * updates_per_step * len(roles.learners)
-    # the same timed block under the other gate setting (identical by construction when both owe the same updates per step: N = 1)
-    if upd_by_gate[other_gate] != updates_per_step:
+    # the same timed block under the other gate setting (identical by construction when both owe the same updates per step: N = 1,
+    # where the ungated figures come from workers.FreeRunningLoop instead).  N > 1: a second PartitionedRun in the other mode —
+    # lock-step under the gate, free-running (partition.py: free_steps) without it
+    run_other = None
+    if world > 1:
+        if run.learner is not None:
+            run.check()
+        run_other = make_run(args.free_steps if other_gate == "free" else 0)
+
+        def other_step(n_upd):
+            run_other.step(n_upd)
+        for _ in range(max(1, args.warmup)):
+            other_step(upd_by_gate[other_gate])
+        dt_other = block(upd_by_gate[other_gate], other_step)
+        if run_other.learner is not None:
+            run_other.check()
+    elif upd_by_gate[other_gate] != updates_per_step:
         one_step(upd_by_gate[other_gate])
         dt_other = block(upd_by_gate[other_gate])
     else:
@@ -848,9 +870,10 @@ def main():
                           "note": "`value` is block 0 (exactly --steps steps); the same block repeated to keep the GPU leg visible"},
         "roofline": roofline,
     }
-    g_env, g_upd = env_steps, args.steps * upd_by_gate[other_gate] * len(roles.learners)
+    g_env = args.steps * num_envs * len(roles.rollouts) * vsteps_by_gate[other_gate]
+    g_upd = args.steps * upd_by_gate[other_gate] * len(roles.learners)
     other = {"value": g_env / dt_other, "updates_per_s": g_upd / dt_other, "ms_per_step": dt_other / args.steps * 1e3,
-             "updates_per_step": upd_by_gate[other_gate], "gate": other_gate,
+             "updates_per_step": upd_by_gate[other_gate], "gate": other_gate, "vector_steps_per_rollout_rank_and_step": vsteps_by_gate[other_gate],
              "what": "the same timed block of --steps steps under --gate %s%s" % (other_gate, " (identical step at N = 1: not re-run)" if dt_other is dt else "")}
     out["value_ungated" if other_gate == "free" else "value_gated"] = other["value"]
     out["other_gate"] = other

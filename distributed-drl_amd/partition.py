@@ -181,8 +181,24 @@ class PartitionedRun:
     broadcasts the flat parameter vector and the rollout ranks adopt it."""
 
     def __init__(self, opt, roles, make_replay, make_rollout, make_learner, seed=0, push_freq=None, device=None, updates_per_graph=16,
-                 force_dp=False, dp_updates_per_graph=None):
+                 force_dp=False, dp_updates_per_graph=None, free_steps=0):
+        """free_steps = K > 0: the FREE-RUNNING mode (example/dsac.py:229-236: rollouts and learners are launched and left running, no
+        gate between them, dsac.py:76-150).  A step is then K vector steps on every rollout rank beside the learners' n updates, and
+        nothing on a rollout rank's env stream ever waits for the learners of the SAME step:
+          * blocks: an owner draws and sends, behind its K vector steps of step s, the batches of step s + 1; a learner posts the
+            receives for step s + 1 BEFORE it runs the updates of step s (lock-step mode waits for a step's blocks in front of
+            its updates) — the transfer runs under the updates;
+          * pushes: a rollout rank joins the step's broadcasts on a communication stream of its own and adopts the last of them
+            at the start of its NEXT step (per env at episode ends, as always) — its env stream waits for learner step s - 1,
+            never for learner step s.
+        The batches of step s + 1 are therefore drawn from the rings as they stand after the env steps of step s, one step
+        earlier than in lock-step mode: which transitions an update sees differs (the reference's own timing is not defined at
+        all), every index stream and the shard schedule stay exactly the same.  0 (default): lock-step, what the provenance
+        tests pin."""
         self.opt, self.roles = opt, roles
+        self.free_steps = int(free_steps)
+        self.pending, self.regions_free = None, {}
+        self.comm_stream, self.push_event, self.adopt_event, self.push_pending = None, None, None, False
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.B = int(opt.batch_size)
         self.nf = batch_floats(opt.obs_dim, opt.act_dim, self.B)
@@ -238,6 +254,20 @@ class PartitionedRun:
 
     # -- parameters -----------------------------------------------------------------------------
     def _push(self):
+        if self.free_steps > 0 and self.learner is None and self.roll is not None and self.stats["pushes"] >= 1:
+            # free-running rollout rank: the collective runs on a stream of its own, the env stream goes on; the weights are adopted
+            # at the start of the next step (step(): _adopt_pushed)
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            with torch.cuda.stream(self.comm_stream):
+                if self.adopt_event is not None:
+                    self.comm_stream.wait_event(self.adopt_event)   # the pack kernel of the last adoption has read the buffer
+                self.bcast.sync(None)
+                self.push_event = torch.cuda.Event()
+                self.push_event.record()
+            self.push_pending = True
+            self.stats["pushes"] += 1
+            return
         flat = self.learner.get_weights_flat() if self.roles.rank == self.roles.learners[0] else None
         self.bcast.sync(flat)
         self.stats["pushes"] += 1
@@ -248,6 +278,17 @@ class PartitionedRun:
         if self.roll is not None:
             n_pi = self.roll.actor.n_params
             self.roll.actor.set_weights_flat(self.bcast.buf[:n_pi])
+
+    def _adopt_pushed(self):
+        """Free mode, rollout rank: the last broadcast of the previous step becomes the newest policy version."""
+        if not self.push_pending:
+            return
+        torch.cuda.current_stream().wait_event(self.push_event)
+        n_pi = self.roll.actor.n_params
+        self.roll.actor.set_weights_flat(self.bcast.buf[:n_pi])
+        self.adopt_event = torch.cuda.Event()
+        self.adopt_event.record()
+        self.push_pending = False
 
     # -- one step's traffic ---------------------------------------------------------------------
     def _buf(self, table, key, batches):
@@ -272,15 +313,25 @@ class PartitionedRun:
 
     def _receive(self, plans):
         """Learner side: post one receive per remote owner, lay the step's plan down for the sampler."""
+        self._arm(self._post(plans, self.regions))
+
+    def _post(self, plans, table, parity=None):
+        """Post the receives of one step's blocks (into `table`'s buffers; free mode: one table per step parity)."""
         me, li = self.roles.rank, self.roles.learners.index(self.roles.rank)
         owners = [p[li][1] for p in plans]
         remote = sorted(set(o for o in owners if o != me))
         count = {o: owners.count(o) for o in remote}
         recvs, regions = [], []
         for o in remote:
-            buf = self._buf(self.regions, o, count[o])[: count[o] * self.nf]
+            buf = self._buf(table, o if parity is None else (o, parity), count[o])[: count[o] * self.nf]
             recvs.append(_Recv(buf, o))
             regions.append((buf, count[o]))
+        return {"owners": owners, "remote": remote, "count": count, "recvs": recvs, "regions": regions}
+
+    def _arm(self, rec):
+        """The posted blocks of a step become the sampler's feed: plan to the device, set_feed, wait for the blocks."""
+        me = self.roles.rank
+        owners, remote, count, recvs, regions = rec["owners"], rec["remote"], rec["count"], rec["recvs"], rec["regions"]
         nxt = {o: 0 for o in remote}
         plan = np.empty(len(owners), dtype=np.int32)
         for u, o in enumerate(owners):
@@ -381,6 +432,36 @@ class PartitionedRun:
             comm.allreduce_mean_(self.dp_g, group=self.lgroup)
             self.dp_apply()
 
+    def _free_front(self, n, t):
+        """Free mode, everything in front of a step's updates: adopt the previous step's last push, K vector steps, the blocks of
+        the NEXT step drawn and sent, this step's (already posted) blocks armed, the next step's receives posted."""
+        first = self.pending is None and not getattr(self, "_free_started", False)
+        if first:
+            # prologue: this step's blocks travel now (drawn in front of the env steps: the rings as constructed), like a lock-step step
+            self._free_started, self._free_n = True, n
+            plans0 = [self.schedule.next() for _ in range(n)]
+            if self.rb is not None:
+                self._serve(plans0)
+            if self.learner is not None:
+                self.pending = self._post(plans0, self.regions_free, 0)
+            self._free_parity = 0
+        assert n == self._free_n, "free mode draws the next step's batches ahead: the updates per step must not change"
+        if self.roll is not None:
+            self._adopt_pushed()
+            self.roll.step(self.free_steps)
+        t = self._tick("s_env", t)
+        plans_next = [self.schedule.next() for _ in range(n)]
+        if self.rb is not None:
+            self._serve(plans_next)                     # behind this step's env steps: what step s + 1 trains on
+        t = self._tick("s_serve", t)
+        if self.learner is not None:
+            cur = self.pending
+            self._free_parity ^= 1
+            self.pending = self._post(plans_next, self.regions_free, self._free_parity)   # posted BEFORE this step's updates run
+            self._arm(cur)
+        t = self._tick("s_receive", t)
+        return t
+
     def _tick(self, key, t0):
         """DDRL_PART_TIMING=1: wall time per phase (device drained at every phase boundary — diagnosis only)."""
         if not self.timing:
@@ -405,6 +486,10 @@ class PartitionedRun:
 
     def check(self):
         """Drain the device and raise what its samplers reported."""
+        if self.pending is not None:                 # free mode: the blocks posted for a step that will not run (their sends have been issued)
+            for r in self.pending["recvs"]:
+                r.wait()
+            self.pending = None
         if self.learner is not None:
             self._poll_error(drain=True)
 
@@ -414,17 +499,20 @@ class PartitionedRun:
         if self.learner is not None:
             self._poll_error()
         t = self._tick(None, 0.0)
-        if self.roll is not None:
-            self.roll.step()
-        t = self._tick("s_env", t)
         n = int(n_updates)
-        plans = [self.schedule.next() for _ in range(n)]
-        if self.rb is not None:
-            self._serve(plans)
-        t = self._tick("s_serve", t)
-        if self.learner is not None:
-            self._receive(plans)
-        t = self._tick("s_receive", t)
+        if self.free_steps > 0:
+            t = self._free_front(n, t)
+        else:
+            if self.roll is not None:
+                self.roll.step()
+            t = self._tick("s_env", t)
+            plans = [self.schedule.next() for _ in range(n)]
+            if self.rb is not None:
+                self._serve(plans)
+            t = self._tick("s_serve", t)
+            if self.learner is not None:
+                self._receive(plans)
+            t = self._tick("s_receive", t)
         left = n
         while left > 0:
             seg = min(left, self.push_freq - self.cnt % self.push_freq)   # updates until the next push

@@ -253,6 +253,90 @@ def _gpu_worker_async(rank, world, port, q, num_learners):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
+def _gpu_worker_free(rank, world, port, q, num_learners, sizes=TOY, K=3):
+    """FREE-RUNNING mode (PartitionedRun(free_steps=K); example/dsac.py:229-236: no gate): K vector steps per rollout rank and step,
+    the blocks of step s + 1 drawn and sent behind the env steps of step s and received under the updates of step s, pushes adopted
+    by the rollout ranks one step later off a communication stream.  Checked batch by batch against NumPy's own stream with the
+    provenance the mode defines: update s trained on the batch the scheduled owner's ring handed out when it held the env steps
+    of steps 0 .. s - 1 (step 0: the rings as constructed)."""
+    try:
+        n_envs, batch, cap, prefill, n_upd = sizes
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          DDRL_DIST_BACKEND="gloo")
+        import distributed_drl_amd as d
+        import torch.distributed as dist
+        from distributed_drl_amd import _lib, comm, partition
+        from distributed_drl_amd.agent import HyperParameters, Learner
+        from distributed_drl_amd.workers import RolloutDevice
+        r, w, _ = comm.init_from_env()
+        torch.cuda.set_device(0)
+        _lib.require_gpu()
+        opt = HyperParameters()
+        opt.num_envs, opt.batch_size, opt.seed, opt.start_steps, opt.max_ep_len, opt.push_freq = n_envs, batch, 5, -1, 50, 3
+        B = opt.batch_size
+        roles = partition.Roles(w, r, num_learners=num_learners)
+        run = partition.PartitionedRun(opt, roles, lambda: _prefilled_shard(d, opt, r, cap, prefill), lambda rb: RolloutDevice(None, rb, opt, worker_index=r),
+                                       lambda: Learner(opt, job="learner", index=0), seed=9, updates_per_graph=0, free_steps=K)
+        n_pi = 8 * 400 + 400 + 400 * 300 + 300 + 2 * (300 * 2 + 2)
+        sched = partition.Schedule(roles, seed=9)
+        per_step = 2                                   # updates per learner and step: a push (every 3 updates) inside every other step
+        n_steps = n_upd // per_step
+        plans = [[sched.next() for _ in range(per_step)] for _ in range(n_steps + 1)]   # (+1: the blocks drawn ahead for a step that never runs)
+        rs = np.random.RandomState(100 + r)
+        handed, trained, adopted, pushed = [], [], [], []
+        for s_ in range(n_steps):
+            run.step(per_step)
+            torch.cuda.synchronize()
+            if run.rb is not None:
+                # this ring's sampler has now drawn, in this order: (first call only) the blocks of step 0 for REMOTE learners from the ring
+                # as constructed; behind the K env steps of this step, the blocks of step s + 1 for remote learners; then — a rank that
+                # learns from its own shard (config 3's rank 0) — the local batches of step s, one per update, at update time
+                after = min(cap, prefill + opt.num_envs * K * (s_ + 1))
+                for kind, st, size in ((("remote", 0, prefill),) if s_ == 0 else ()) + (("remote", s_ + 1, after), ("local", s_, after)):
+                    for li, l in enumerate(roles.learners):          # a shard serves learner 0's batches of a step first
+                        if (l == r) != (kind == "local"):
+                            continue
+                        for u, p in enumerate(plans[st]):
+                            if p[li][1] == r:
+                                handed.append((st, u, l, _rows(run.rb, rs.randint(0, size, B))))
+            if run.learner is not None:
+                v = run.learner.input_batch(run.learner._dp_last_set if run.loop is None else (per_step * s_ + per_step - 1) & 1)
+                trained.append(torch.cat([v[k].reshape(-1) for k in ("obs1", "obs2", "acts", "rews", "done")]).cpu().numpy().copy())
+            if run.roll is not None:
+                adopted.append(run.roll.actor.get_weights_flat().cpu().numpy().copy())
+            pushed.append((run.stats["pushes"], run.bcast.buf[:n_pi].cpu().numpy().copy()))
+        everything = [None] * w
+        dist.all_gather_object(everything, handed)
+        if roles.is_learner:
+            want = {(st, u, l): rows for per_rank in everything for (st, u, l, rows) in per_rank}
+            for s_ in range(n_steps):     # (the last update of every step is the one still lying in an input set)
+                np.testing.assert_array_equal(trained[s_], want[(s_, per_step - 1, r)], err_msg="last update of step %d, learner %d" % (s_, r))
+            assert run.learner.opt_steps() == (n_steps * per_step,) * 2
+            assert run.stats["remote_batches"] + run.stats["local_batches"] == n_steps * per_step
+        if run.rb is not None:
+            served = sum(1 for st in range(n_steps + 1) for p in plans[st] for l, owner in p if owner == r and l != r) + \
+                sum(1 for st in range(n_steps) for p in plans[st] for l, owner in p if owner == r and l == r)
+            samples, steps, size = run.rb.get_counts()
+            assert samples == served and steps == prefill + n_steps * K * opt.num_envs and size == min(cap, steps), (samples, served, steps)
+        assert run.stats["pushes"] == 1 + (n_steps * per_step) // 3
+        if run.roll is not None and not roles.is_learner:
+            # a free-running rollout rank acts, during step s, on what the server held at the END of step s - 1 (the last push it saw
+            # land before its env steps of step s were issued), never on a push of step s itself
+            for s_ in range(1, n_steps):
+                np.testing.assert_array_equal(adopted[s_], pushed[s_ - 1][1], err_msg="policy during step %d" % s_)
+        if num_learners == 2:
+            ws = [None] * w
+            dist.all_gather_object(ws, run.learner.get_weights_flat().cpu().numpy() if roles.is_learner else None)
+            np.testing.assert_array_equal(ws[0], ws[1])
+        run.check()
+        comm.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
 def _spawn(world, num_learners, target=None, extra=(), timeout=300):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -278,6 +362,22 @@ def test_config4_roles_three_ranks_on_one_gpu_two_learners_one_shard():
     """Config 4's roles at the smallest size (2 data-parallel learner ranks + 1 rollout rank with the shard): the owner
     serves both learners' blocks, the learners all-reduce their gradients and stay bit-identical."""
     _spawn(3, 2)
+
+
+@pytest.mark.gpu
+def test_free_running_mode_config3_roles_two_ranks_on_one_gpu():
+    """PartitionedRun(free_steps=K) with config 3's roles (rank 0 learns AND rolls out, both ranks own a shard): local draws and
+    prefetched remote blocks in one plan."""
+    _spawn(2, None, target=_gpu_worker_free)
+
+
+@pytest.mark.gpu
+def test_free_running_mode_config4_roles_eight_ranks_on_one_gpu():
+    """The free-running mode with config 4's roles — 8 ranks on the one GPU over gloo: 2 data-parallel learner ranks, 6 rollout ranks
+    running K vector steps per step: every checked update trained on the batch NumPy's stream says the scheduled owner's ring handed
+    out one step EARLIER (the blocks travel under the previous step's updates), each owner's sampler advanced once per batch it drew
+    (one step ahead included), the rollout ranks act on the previous step's last push, the learners end identical."""
+    _spawn(8, 2, target=_gpu_worker_free, timeout=600)
 
 
 @pytest.mark.gpu
