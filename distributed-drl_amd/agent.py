@@ -247,7 +247,7 @@ class Learner(_Net):
                 st = self._fast = False
             else:
                 span = off[4] + B
-                hosts = [torch.zeros(span, dtype=torch.float32).pin_memory() for _ in range(2)]
+                hosts = [torch.zeros(span + 2, dtype=torch.float32).pin_memory() for _ in range(2)]   # (+2: the noise counter rides behind the batch)
                 st = self._fast = {"p": p, "off": off, "n": n, "span": span, "host": hosts, "np": [h.numpy() for h in hosts],
                                    "hp": [ctypes.c_void_p(h.data_ptr()) for h in hosts],
                                    "ev": [torch.cuda.Event(), torch.cuda.Event()], "used": [False, False], "turn": 0, "one_block": Bp == B,

@@ -772,12 +772,20 @@ struct ddrl_sac1 {
     bool grad_imported;  // the gradient buffer was overwritten by import(GRAD): Adam must not re-sum partials
     // ddrl_sac1_capture_begin / _abort: the host-side launch state above as it stood before a caller's stream capture (every
     // launch function toggles some of it at LAUNCH time, so an aborted capture — whose launches never ran — must put it back)
+    // ddrl_sac1_step_host: the host-batch update as captured graphs — on this surface the ~8 HIP calls of an eager update (two copies, the
+    // noise fill, five launches) cost more host time than the device needs for the update.  One graph per (host block, copy parity).
+    struct HostGraph { const float *block; float *losses; uint32_t seed; int opt_cur, sh_cur; hipGraphExec_t exec; };
+    std::vector<HostGraph> host_graphs;
+    uint32_t *host_ctr_d;          // device copy of the noise counter a host block carries up (two words)
     struct HostSnap { bool valid; int opt_cur, sh_cur; bool fuse_apply, sample_armed, noise_armed, grad_imported; uint32_t noise_seed; unsigned int noise_pending; } snap;
 };
 
 static void refresh_shadows(ddrl_sac1 *h, hipStream_t s);
+int ddrl_internal_normal_fill_ctr(float *out_d, int64_t n, uint32_t seed, const uint32_t *ctr_d, uint64_t base, void *stream);   // common.hip
 
 static int sac1_free(ddrl_sac1 *h) {
+    for (auto &g : h->host_graphs) (void)hipGraphExecDestroy(g.exec);
+    if (h->host_ctr_d) (void)hipFree(h->host_ctr_d);
     (void)hipFree(h->slab);
     delete h;
     return DDRL_OK;
@@ -1863,7 +1871,7 @@ int ddrl_sac1_step(ddrl_sac1_t *h, const float *obs1_d, const float *obs2_d, con
 // train(replay_buffer.sample_batch()) with HOST arrays (example/dsac.py:142-144; algos/sac1/sac1.py:146-148) as ONE call: the caller's
 // page-locked block [obs1 | obs2 | acts | rews | done], laid out like input set 0, goes up with one asynchronous copy, the three noise
 // tensors are generated in place behind it (counter-based, ddrl_normal_fill), and the update reads the input set it owns.
-int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
+int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
                         void *stream) {
     DDRL_REQUIRE(h != nullptr && block_h != nullptr, "NULL pointer");
     const ddrl_sac1_config_t &c = h->cfg;
@@ -1878,13 +1886,53 @@ int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, 
     DDRL_REQUIRE(n_floats == (in0[4] - in0[0]) + B, "block length differs from input set 0's span");
     ddrl::DeviceGuard g(h->device);
     hipStream_t s = ddrl::as_stream(stream);
-    DDRL_HIP_CHECK(hipMemcpyAsync(in0[0], block_h, (size_t)n_floats * sizeof(float), hipMemcpyHostToDevice, s));
-    int rc = DDRL_OK;
-    if (in0[6] - in0[5] == m && in0[7] - in0[6] == m) rc = ddrl_normal_fill(in0[5], 3 * m, noise_seed, noise_ctr, stream);
-    else
-        for (int i = 0; i < 3 && rc == DDRL_OK; ++i) rc = ddrl_normal_fill(in0[5 + i], m, noise_seed, noise_ctr + (uint64_t)(i * m), stream);
-    if (rc != DDRL_OK) return rc;
-    return ddrl_sac1_step(h, in0[0], in0[1], in0[2], in0[3], in0[4], in0[5], in0[6], in0[7], losses_d, nullptr, nullptr, nullptr, stream);
+    // the noise counter travels in the two words behind the batch: a captured replay reads it from there
+    uint32_t *tail = reinterpret_cast<uint32_t *>(block_h + n_floats);
+    tail[0] = (uint32_t)noise_ctr; tail[1] = (uint32_t)(noise_ctr >> 32);
+    if (!h->host_ctr_d) DDRL_HIP_CHECK(hipMalloc((void **)&h->host_ctr_d, 2 * sizeof(uint32_t)));
+    const bool eps_contig = in0[6] - in0[5] == m && in0[7] - in0[6] == m;
+    auto issue = [&]() -> int {
+        DDRL_HIP_CHECK(hipMemcpyAsync(in0[0], block_h, (size_t)n_floats * sizeof(float), hipMemcpyHostToDevice, s));
+        DDRL_HIP_CHECK(hipMemcpyAsync(h->host_ctr_d, tail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        int rc = DDRL_OK;
+        if (eps_contig) rc = ddrl_internal_normal_fill_ctr(in0[5], 3 * m, noise_seed, h->host_ctr_d, 0, stream);
+        else
+            for (int i = 0; i < 3 && rc == DDRL_OK; ++i) rc = ddrl_internal_normal_fill_ctr(in0[5 + i], m, noise_seed, h->host_ctr_d, (uint64_t)(i * m), stream);
+        if (rc != DDRL_OK) return rc;
+        return ddrl_sac1_step(h, in0[0], in0[1], in0[2], in0[3], in0[4], in0[5], in0[6], in0[7], losses_d, nullptr, nullptr, nullptr, stream);
+    };
+    static const bool graphs_on = !(getenv("DDRL_HOST_GRAPH") && atoi(getenv("DDRL_HOST_GRAPH")) == 0);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (!graphs_on || !h->fused || s == nullptr || cap != hipStreamCaptureStatusNone) return issue();   // (the legacy null stream cannot be captured)
+    for (auto &hg : h->host_graphs)
+        if (hg.block == block_h && hg.losses == losses_d && hg.seed == noise_seed && hg.opt_cur == h->opt_cur && hg.sh_cur == h->sh_cur) {
+            DDRL_HIP_CHECK(hipGraphLaunch(hg.exec, s));
+            h->opt_cur ^= 1; h->sh_cur ^= 1;   // what the recorded launches did to the host-side state when they were recorded
+            return DDRL_OK;
+        }
+    if (h->host_graphs.size() >= 16) return issue();   // (a caller that keeps changing blocks: eager)
+    hipPointerAttribute_t pa{};
+    if (hipPointerGetAttributes(&pa, block_h) != hipSuccess || pa.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return issue();                                // pageable memory: the copies are not capturable
+    }
+    ddrl_sac1::HostGraph hg{block_h, losses_d, noise_seed, h->opt_cur, h->sh_cur, nullptr};
+    hipGraph_t graph = nullptr;
+    DDRL_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = issue();
+    const hipError_t e2 = hipStreamEndCapture(s, &graph);
+    if (rc != DDRL_OK || e2 != hipSuccess || graph == nullptr) {
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc == DDRL_OK) ddrl::set_error("capturing the host-batch update failed: %s", hipGetErrorString(e2));
+        return rc != DDRL_OK ? rc : DDRL_ERR_HIP;
+    }
+    const hipError_t e3 = hipGraphInstantiate(&hg.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e3 != hipSuccess) { ddrl::set_error("hipGraphInstantiate: %s", hipGetErrorString(e3)); return DDRL_ERR_HIP; }
+    h->host_graphs.push_back(hg);
+    DDRL_HIP_CHECK(hipGraphLaunch(hg.exec, s));   // (the capture recorded the update — host state advanced once — now it runs once)
+    return DDRL_OK;
 }
 
 }  // extern "C"
@@ -2007,6 +2055,7 @@ struct ddrl_actor {
     float *flat_tmp;               // ... through this dense staging vector
     VerTile *vtiles_d;
     VerState *vs_d;
+    int wg_slots;                  // resident workgroups of the two-per-CU forward: 2 x CUs (the planning launch sizes the column split for it)
     long long steps_since_install;   // host-side: >= the envs' max_ep_len <=> every env has adopted the newest version
 };
 
@@ -2054,7 +2103,7 @@ __device__ __forceinline__ int ver_group_add(int *arr, int s, bool valid, int la
 //          the first operand).  An env's position in its group is the value its histogram atomic returned — one atomic pass, not two.
 constexpr int VER_REG_ENVS = 8;   // envs per thread kept in registers across the passes (8192 envs: config 4's rollout ranks)
 __global__ void __launch_bounds__(1024) k_version_plan(const int *__restrict__ slot, long long n, int n_slots, int *__restrict__ rows,
-                                                       VerTile *__restrict__ tiles, VerState *vs, int install) {
+                                                       VerTile *__restrict__ tiles, VerState *vs, int install, int col_tiles, int wg_slots) {
     __shared__ int cnt[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
     __shared__ int wsum_t[16], s_nt, s_free, s_live;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -2095,7 +2144,7 @@ __global__ void __launch_bounds__(1024) k_version_plan(const int *__restrict__ s
     for (int k = 0; k < w; ++k) bt += wsum_t[k];
     const int et = bt + st - (t0 + t1);   // exclusive prefix of this thread's pair
     tstart[2 * t] = et; tstart[2 * t + 1] = et + t0;
-    if (t == 1023) { vs->n_tiles = bt + st; s_nt = bt + st; }
+    if (t == 1023) { vs->n_tiles = bt + st; s_nt = bt + st; vs->ngroups = ver_pick_groups(bt + st, col_tiles, wg_slots); }
     if (t == 0 && install) {
         int target = newest;
         if (cnt[newest] > 0) {
@@ -2261,7 +2310,7 @@ int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream
         // version store: the new weights become the newest version, in a slot no env acts on — ONE planning launch (slot pick + the tile
         // table of the next forward) and ONE pack into the current copy and that slot (round 4: two packs, the pick, a 0.5 MB copy
         // and, in the step, the grouping: five launches)
-        k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 1);
+        k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 1, (h->cfg.hidden2 + 31) / 32, h->wg_slots);
         k_pack_version<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, s>>>(h->segs_dd, flat_pi_d, h->pi_d, h->vslab, h->vstride, h->vs_d);
         h->plan_fresh = true;
         h->steps_since_install = 0;
@@ -2302,6 +2351,12 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
     // (dev_alloc zero-fills: every env on slot 0, newest = 0) slot 0 = the weights the actor holds now
     h->vstride = np;
     h->n_slots = n_slots;
+    {
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        h->wg_slots = 2 * ncu;
+    }
     k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
     h->steps_since_install = 1ll << 40;
     h->plan_fresh = false;
@@ -2424,13 +2479,13 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream, int ve
         // envs grouped by the policy version they act on; a row tile = up to 32 envs of one version.  The launch covers the worst
         // case (every live version leaves one partial tile), surplus workgroups leave at once.
         DDRL_REQUIRE(h->n_slots > 0 && n == h->max_rows, "versioned forward: store not enabled, or n != max_rows");
-        if (!h->plan_fresh) k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 0);
+        if (!h->plan_fresh) k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 0, nt2, h->wg_slots);
         h->plan_fresh = true;   // (ddrl_rollout_step clears it behind the env-step launch, ddrl_actor_versions_adopt behind its own)
         const long long vt = n / 32 + (h->n_slots < n ? h->n_slots : n);
         A.W1 = h->vslab + L.pi_W1; A.W2p = A.W1 + ((c.hidden1 + 31) & ~31) * 16;
         A.b2 = h->vslab + L.pi_b2; A.wmu = h->vslab + L.pi_Wmu; A.wls = h->vslab + L.pi_Wls;
-        A.vtiles = h->vtiles_d; A.perm = h->perm_d; A.vs = h->vs_d; A.vstride = h->vstride;
-        const unsigned vgrid = (unsigned)vt * A.ngroups;
+        A.vtiles = h->vtiles_d; A.perm = h->perm_d; A.vs = h->vs_d; A.vstride = h->vstride; A.vt_max = (int)vt;
+        const unsigned vgrid = (unsigned)vt * (unsigned)(nt2 < VER_MAX_GROUPS ? (nt2 < 2 ? 1 : nt2) : VER_MAX_GROUPS);   // (the plan's choice of workgroups per row tile is at most that)
         if (ns == 4) k_actor_fwd<4, 2, true><<<vgrid, 256, 0, s>>>(A);
         else if (ns == 5) k_actor_fwd<5, 2, true><<<vgrid, 256, 0, s>>>(A);
         else if (ns == 6) k_actor_fwd<6, 2, true><<<vgrid, 256, 0, s>>>(A);

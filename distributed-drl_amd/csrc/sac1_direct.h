@@ -551,7 +551,25 @@ constexpr int ANT = 5;
 // A row tile of the versioned forward: `count` (<= 32) envs perm[base .. base + count) that all act on policy version `slot`.
 struct VerTile { int slot, base, count, pad; };
 // Device-side state of an actor's version store (exact per-env weight adoption, example/dsac.py:127-130).
-struct VerState { int newest, target, n_tiles, err, live, pad[3]; };
+struct VerState { int newest, target, n_tiles, err, live, ngroups, pad[2]; };
+// Workgroups per row tile of the versioned forward, chosen by the planning launch from the ACTUAL tile count: with envs grouped by
+// version the count is a little over a whole number of rounds (8192 envs / 16 versions: 264 row tiles x 2 workgroups = 528 for 512 slots —
+// sixteen workgroups ran a second round as long as the first), and a finer column split trades a few more redundant layer-1 passes for
+// rounds that are shorter (cost model in ver_pick_groups).
+constexpr int VER_MAX_GROUPS = 3;
+__host__ __device__ inline int ver_pick_groups(int n_tiles, int col_tiles, int slots) {
+    int best = 2, best_cost = 0x7fffffff;
+    // measured (tools/version_step_probe.py, 10 column tiles): a workgroup of `per` column tiles takes 6.2 + 3.1 per microseconds with the
+    // chip full; a last, partly filled round runs ~0.8 of that; five groups per row tile lost to two in every case tried (1320 and 1410
+    // workgroups: dispatch), so the choice is between two and three
+    for (int g = 2; g <= 3 && g <= col_tiles; ++g) {
+        const int wgs = n_tiles * g, full = wgs / slots, rem = wgs - full * slots, per = (col_tiles + g - 1) / g;
+        const int dur = 62 + 31 * per;
+        const int cost = full * dur + (rem > 0 ? (8 * dur) / 10 : 0);
+        if (cost < best_cost) { best_cost = cost; best = g; }
+    }
+    return col_tiles < 2 ? 1 : best;
+}
 struct ActFwdArgs {
     const float *W1, *W2p, *b2, *wmu, *wls, *obs;
     float *hp;
@@ -561,6 +579,7 @@ struct ActFwdArgs {
     const int *perm;
     const VerState *vs;
     long long vstride;
+    int vt_max;              // VER: row tiles the tile table / row lists are allocated for (the launch covers VER_MAX_GROUPS workgroups per tile)
 #ifdef DDRL_STAMPS
     unsigned long long *st;  // dev harness (tools/actor_bench.hip): [workgroup][wave][32] cycle stamps
 #endif
@@ -584,9 +603,10 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    // column tiles are dealt to `ngroups` workgroups per row tile as evenly as they go
-    const int rt = blockIdx.x / a.ngroups, grp = blockIdx.x - rt * a.ngroups;
-    const int gbase = a.tiles_n / a.ngroups, gextra = a.tiles_n % a.ngroups;
+    // column tiles are dealt to `ngroups` workgroups per row tile as evenly as they go (VER: the planning launch's choice)
+    const int ngroups = VER ? a.vs->ngroups : a.ngroups;
+    const int rt = blockIdx.x / ngroups, grp = blockIdx.x - rt * ngroups;
+    const int gbase = a.tiles_n / ngroups, gextra = a.tiles_n % ngroups;
     const int ntiles = gbase + (grp < gextra ? 1 : 0);
     int m0 = rt * 32;
     const int nt0 = grp * gbase + (grp < gextra ? grp : gextra);
@@ -597,8 +617,9 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
         // sits at perm[32 rt ..): no chain through the record; entries beyond the tile's count, and tiles beyond n_tiles, hold whatever
         // an earlier plan left — valid env numbers or zero, never read as data)
         const int nt_live = a.vs->n_tiles;
-        const VerTile vt = a.vtiles[rt];
-        vrow = a.perm[32 * rt + l31];
+        const int rtc = rt < a.vt_max ? rt : 0;   // (the launch is sized for the finest column split: with a coarser one the surplus workgroups' rt runs past the tables)
+        const VerTile vt = a.vtiles[rtc];
+        vrow = a.perm[32 * rtc + l31];
         if (rt >= nt_live) return;   // the launch covers the worst case (n / 32 + live versions); block-uniform
         const long long off = (long long)vt.slot * a.vstride;
         a.W1 += off; a.W2p += off; a.b2 += off; a.wmu += off; a.wls += off;

@@ -79,10 +79,12 @@ class ReplayBuffer:
         obs, act, rew, next_obs, done = (self._f32(t) for t in (obs, act, rew, next_obs, done))
         assert obs.numel() == n * self.obs_dim and next_obs.numel() == n * self.obs_dim
         assert act.numel() == n * self.act_dim and done.numel() == n
+        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_store(self._h, _lib.dptr(obs), _lib.dptr(act), _lib.dptr(rew),
                                                _lib.dptr(next_obs), _lib.dptr(done), n, _lib.stream_ptr()))
+        self._pf_order_store(False)
 
-    def prefetch(self, batch_size=None, depth=12, hold=2):
+    def prefetch(self, batch_size=None, depth=12, hold=2, own_stream=False):
         """The reference's `Cache` (algos/sac1/sac1.py:103-130: a helper that keeps ten sampled batches waiting so that the learner never
         waits for a sample) INSIDE the buffer: from now on `depth - hold` sample_batch(batch_size) draws are always in flight — index
         draw, gather and the copy down into page-locked host blocks, queued on the buffer's stream — and sample_batch(batch_size)
@@ -90,9 +92,15 @@ class ReplayBuffer:
         without prefetch (one sampler, one queue); what changes is WHEN a batch was drawn: up to `depth - hold` calls earlier, so
         transitions stored in between are not in it — the reference's Cache has the same staleness.
         The arrays of a returned batch are views of a ring of host blocks: valid until `hold` further sample_batch calls (copy them to
-        keep them longer).  prefetch(0) turns it off."""
+        keep them longer).  prefetch(0) turns it off.
+        own_stream=True: the draws run on a stream of the buffer's own, beside the caller's stream (a learner's update on the same
+        thread then no longer queues behind the gather and its copy down); this object's store / store_batch calls are ordered
+        against the draws by events.  Writers that go to the ring BEHIND this object's back on another stream (a RolloutDevice's fused
+        env-step launch stores through the C handle) are not: keep the default there."""
         pf = getattr(self, "_pf", None)
         if pf is not None:
+            if pf["stream"] is not None:
+                pf["stream"].synchronize()
             torch.cuda.current_stream().synchronize()
             self._pf = None
         B = int(self._default_batch if batch_size is None else batch_size)
@@ -112,16 +120,43 @@ class ReplayBuffer:
                               acts=v[offs[2]:offs[2] + B * a] if self._acts_1d else v[offs[2]:offs[2] + B * a].reshape(B, a),
                               rews=v[offs[3]:offs[3] + B], done=v[offs[4]:offs[4] + B]))
         ptrs = [[d.data_ptr() + 4 * offs[j] for j in range(5)] for d in dev]
-        self._pf = dict(B=B, depth=depth, hold=hold, dev=dev, host=host, views=views, ptrs=ptrs, ev=[torch.cuda.Event() for _ in range(depth)], head=0)
+        side = torch.cuda.Stream() if own_stream else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())    # what the caller has stored so far is in the ring
+        self._pf = dict(B=B, depth=depth, hold=hold, dev=dev, host=host, views=views, ptrs=ptrs, ev=[torch.cuda.Event() for _ in range(depth)], head=0,
+                        stream=side, store_ev=None, draw_ev=None)
         for i in range(depth - hold):
             self._pf_enqueue(i)
 
     def _pf_enqueue(self, i):
         pf = self._pf
         p = pf["ptrs"][i]
-        _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
-        pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
-        pf["ev"][i].record()
+        if pf["stream"] is None:
+            _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
+            pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
+            pf["ev"][i].record()
+            return
+        with torch.cuda.stream(pf["stream"]):
+            if pf["store_ev"] is not None:
+                pf["stream"].wait_event(pf["store_ev"])      # the caller's last store has landed
+                pf["store_ev"] = None
+            _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
+            pf["draw_ev"] = torch.cuda.Event()
+            pf["draw_ev"].record()                           # (a store behind this draw must not overwrite rows it is still gathering)
+            pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
+            pf["ev"][i].record()
+
+    def _pf_order_store(self, before):
+        """own-stream prefetch: a store waits for the draws in flight (before=True), and leaves an event the next draw waits for."""
+        pf = getattr(self, "_pf", None)
+        if pf is None or pf["stream"] is None:
+            return
+        if before:
+            if pf["draw_ev"] is not None:
+                torch.cuda.current_stream().wait_event(pf["draw_ev"])
+        else:
+            pf["store_ev"] = torch.cuda.Event()
+            pf["store_ev"].record()
 
     def sample_batch(self, batch_size=None):
         """dict(obs1, obs2, acts, rews, done) of fresh float32 NumPy arrays (example/dsac.py:39-45).

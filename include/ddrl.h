@@ -291,9 +291,13 @@ int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t
  * the offsets the five buffers of ddrl_sac1_input_buffers(h, 0, .) have from the first one (DDRL_ERR_BAD_ARG if those do not form one
  * span; where an item is allocated with more rows than the batch — the direct path pads to whole 32-row tiles — the block must hold
  * zeros there); it goes up with one asynchronous copy, eps_x / eps_x2 / eps_t are generated in place exactly as three ddrl_normal_fill calls
- * at noise_ctr, noise_ctr + B*act, noise_ctr + 2*B*act would, then one ddrl_sac1_step on that set.  The block may be rewritten once
- * work queued on `stream` behind this call has started (record an event after the call and wait for it). */
-int ddrl_sac1_step_host(ddrl_sac1_t *h, const float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
+ * at noise_ctr, noise_ctr + B*act, noise_ctr + 2*B*act would, then one ddrl_sac1_step on that set.  The block must have room for TWO
+ * more floats behind the n_floats: the call writes the noise counter there and the device reads it from there — which is what lets
+ * the whole sequence (two copies, noise, the update's launches) replay as ONE captured graph per (block, state-copy parity) from the
+ * second use of a block on: on this surface the host's launch calls, not the device, set the rate (DDRL_HOST_GRAPH=0: always eager).
+ * The block may be rewritten once work queued on `stream` behind this call has started (record an event after the call and wait for
+ * it). */
+int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
                         void *stream);
 
 /* For a caller that captures update sequences into a graph of its own (partition.py captures `gradients -> RCCL all-reduce ->

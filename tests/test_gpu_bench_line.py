@@ -33,7 +33,13 @@ def test_single_gpu_line():
     assert j["metric"] == METRIC and j["unit"] == "env-steps/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
     assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
     assert j["value"] > 1e4 and abs(j["value"] / j["updates_per_s"] - 2.0) < 1e-9       # the gate: 2 env steps per sampled batch
-    assert j["value_ungated"] == j["value"] and j["functional_only"] is False           # N = 1: the same step under both gate settings
+    # N = 1: the ungated figures are the free-running loop's — the rollout on its own stream beside the learner's graph loop, both rates
+    # from ONE timed region (workers.FreeRunningLoop; example/dsac.py:229-236 has no gate)
+    fr = j["free_running"]
+    assert j["functional_only"] is False and j["value_ungated"] == fr["env_steps_per_s"] and j["updates_per_s_ungated"] == fr["updates_per_s"]
+    assert fr["env_steps_per_s"] > 100 * j["value"] and fr["updates_per_s"] > 0.4 * j["updates_per_s"]   # neither half starves the other
+    assert fr["rollout_stream_busy"] > 0.5 and fr["learner_stream_busy"] > 0.5 and fr["steps_per_segment"] >= 4
+    assert j["series"]["rollout_capacity_with_learner_env_steps_per_s"] == fr["env_steps_per_s"]
     assert abs(j["ms_per_step"] * 1e-3 * j["value"] - 4096) < 1e-6 * 4096
     r = j["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -80,6 +86,7 @@ def test_eight_ranks_on_one_gpu_config4_sizes_is_functional_only():
     # hold: 6 x 8192 env steps / a_l_ratio 2 = 24 576 batches per step, shared by the two learners; free: config 2's 2048 per learner rank
     assert c["gate"] == "hold" and c["updates_per_step"] == 12288 and c["env_steps_per_sample"] == 2.0
     assert j["other_gate"]["gate"] == "free" and j["other_gate"]["updates_per_step"] == 2048
+    assert j["other_gate"]["vector_steps_per_rollout_rank_and_step"] == 256           # the free-running mode of partition.py (free_steps)
     f = j["functional_value"]
     assert f["value"] > 0 and f["updates_per_s"] > 0 and "NOT an N-GPU measurement" in f["note"]
     # one optimizer step of the learner GROUP consumes two batches

@@ -765,3 +765,35 @@ def test_prefetch_hands_out_the_same_batches_in_the_same_order():
     got, want = a.sample_batch(64), b.sample_batch(64)
     for k in want:
         np.testing.assert_array_equal(got[k], want[k])
+
+
+def test_prefetch_on_its_own_stream_orders_against_stores():
+    """prefetch(own_stream=True): draws on the buffer's own stream, this object's stores ordered against them by events.  With the
+    prefetcher drained between a store and the draws that follow it, the batches equal plain sample_batch calls on a twin buffer that
+    sees the same stores at the same positions of the index stream."""
+    import distributed_drl_amd as d
+    rs = np.random.RandomState(1)
+    mk = lambda m: (rs.randn(m, 8).astype(np.float32), rs.uniform(-1, 1, (m, 2)).astype(np.float32), rs.randn(m).astype(np.float32),
+                    rs.randn(m, 8).astype(np.float32), np.zeros(m, np.float32))
+    first, more = mk(600), [mk(64) for _ in range(6)]
+    a, b = d.ReplayBufferSAC1(8, 2, 700, seed=3), d.ReplayBufferSAC1(8, 2, 700, seed=3)
+    for rb in (a, b):
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in first))
+    D, H = 5, 2
+    a.prefetch(32, depth=D, hold=H, own_stream=True)
+    ahead = D - H                                    # draws in flight
+    for it in range(6):
+        # twin: the `ahead` draws the prefetcher made BEFORE this store, then the store, like the prefetcher's order on the device
+        want = [b.sample_batch(32) for _ in range(ahead)] if it == 0 else want[-ahead:]
+        got = []
+        for k in range(ahead):
+            got.append({kk: v.copy() for kk, v in a.sample_batch(32).items()})      # hands out a drawn batch, enqueues one more draw
+            want.append(b.sample_batch(32))
+        for g, w in zip(got, want[:ahead]):
+            for kk in w:
+                np.testing.assert_array_equal(g[kk], w[kk], err_msg="%s @ %d" % (kk, it))
+        torch.cuda.synchronize()
+        a._pf["stream"].synchronize()
+        x = [torch.from_numpy(v).cuda() for v in more[it]]
+        a.store_batch(*x); b.store_batch(*x)          # the ring wraps (700 rows): rows the next draws may pick are being replaced
+    a.prefetch(0)

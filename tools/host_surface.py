@@ -34,6 +34,13 @@ for _ in range(1000): lh.train(rbh.sample_batch(B))
 torch.cuda.synchronize(); t_iter_p = (time.perf_counter() - t0) / 1000
 rbh.prefetch(0)
 print("with ReplayBuffer.prefetch: sample_batch %.1f us  sample+train %.1f us = %.0f updates/s" % (t_samp_p * 1e6, t_iter_p * 1e6, 1.0 / t_iter_p))
+rbh.prefetch(B, own_stream=True)
+for _ in range(20): lh.train(rbh.sample_batch(B))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(1000): lh.train(rbh.sample_batch(B))
+torch.cuda.synchronize(); t_iter_o = (time.perf_counter() - t0) / 1000
+rbh.prefetch(0)
+print("with ReplayBuffer.prefetch(own_stream=True): sample+train %.1f us = %.0f updates/s" % (t_iter_o * 1e6, 1.0 / t_iter_o))
 # the reference's own remedy for that loop: worker_train behind the Cache helper (algos/sac1/sac1.py:103-154) — replay buffer and
 # parameter server as actors (remote.py: a thread + a HIP stream each), the helper drawing batch i + 1 while update i trains
 from distributed_drl_amd import remote as ray
