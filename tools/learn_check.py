@@ -31,6 +31,9 @@ ap.add_argument("--start-env-steps", type=int, default=None, help="random action
 ap.add_argument("--max-ep-len", type=int, default=1000)
 ap.add_argument("--windows", type=int, default=24)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--free", type=int, default=0, metavar="K", help="free-running mode (workers.FreeRunningLoop: no gate, example/dsac.py:229-236): K vector steps "
+                "per segment on the rollout stream beside --free-updates updates on the learner stream")
+ap.add_argument("--free-updates", type=int, default=100)
 args = ap.parse_args()
 
 preset = {"sac1": dict(lr=5e-5, alpha=0.1, gamma=0.997, polyak=0.995, start=50000),
@@ -52,13 +55,22 @@ rb = d.ReplayBufferSAC1(opt.obs_dim, opt.act_dim, 10 ** 6, seed=opt.seed)
 ps = d.ParameterServer(*Learner(opt).get_weights())
 ro = d.RolloutDevice(ps, rb, opt)
 tr = d.TrainDevice(ps, rb, opt, updates_per_graph=50)
-loop = d.ActorLearnerLoop(ro, tr, opt)
-loop.start_steps = (opt.start_steps + 1) * opt.num_envs          # the learner starts when the policy does (sac1.py:196)
 t0 = time.time()
+if args.free > 0:
+    ro.step(opt.start_steps + 1)                                 # the random-action phase fills the ring first (nothing to train on before)
+
+    class _Free(d.FreeRunningLoop):
+        steps = property(lambda self: self.env_steps + (opt.start_steps + 1) * opt.num_envs)
+        sample_times = property(lambda self: self.updates)
+    loop = _Free(ro, tr, opt, steps_per_segment=args.free, updates_per_segment=args.free_updates)
+    run_some = lambda: (loop.run(8), loop.drain())
+else:
+    loop = d.ActorLearnerLoop(ro, tr, opt)
+    loop.start_steps = (opt.start_steps + 1) * opt.num_envs          # the learner starts when the policy does (sac1.py:196)
+    run_some = lambda: (loop.run(4 if args.envs >= 1024 else 32), torch.cuda.synchronize())
 win, best, t200 = 0, -1e9, None
 while time.time() - t0 < args.seconds:
-    loop.run(4 if args.envs >= 1024 else 32)
-    torch.cuda.synchronize()
+    run_some()
     if time.time() - t0 > (win + 1) * args.seconds / args.windows:
         win += 1
         ep, ret, ln = ro.env.stats()
