@@ -476,12 +476,6 @@ int ddrl_dqn_create(ddrl_dqn_t **out, int device, const ddrl_dqn_config_t *cfg) 
         }
     }
     if (h->wide) { h->wf.part = h->wpart; h->wf.consts = h->wconsts; h->wf.a_rows = B; h->wf.ldo = h->ldh1; }
-    if (h->wide) {   // DDRL_WIDE_STAGGER=f,g: start delay (64-cycle units) of every CU's second workgroup in the layer-1 forward / stream-K wgrad
-        int sf = 0, sg = 0;
-        if (const char *e = getenv("DDRL_WIDE_STAGGER")) sscanf(e, "%d,%d", &sf, &sg);
-        h->wf.stagger = sf;
-        for (int n = 0; n < h->nnet; ++n) h->ww[n].stagger = sg;
-    }
     h->sk_on = false; h->sk_frags_d = nullptr; h->sk_slab = nullptr; h->sk_flag = nullptr; h->sk_err_h = nullptr; h->poisoned = false;
     h->steps_launched = 0; h->poison_after = getenv("DDRL_SK_POISON_AFTER") ? atoll(getenv("DDRL_SK_POISON_AFTER")) : -1;
     if (h->wide && !(getenv("DDRL_WIDE_SK") && atoi(getenv("DDRL_WIDE_SK")) == 0)) {
