@@ -293,6 +293,9 @@ struct SkArgs {
     int *flag;             // [nwg]
     int nwg, epoch;
     int *err;              // host-mapped sticky word: 1 = a combine ran out of patience (read by the host at the next step)
+#ifdef WD_STAMPS
+    long long *stamps;     // diagnostic builds (tools/wide_bench.hip): [workgroup][wave][16] — start, end, stages, then accumulated phase cycles
+#endif
 };
 __device__ __forceinline__ void sk_store_sc1(float *p, float4 v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -315,6 +318,13 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
     const WideEval E = a.ev[0];
     const int T = (a.K + WD_KB - 1) / WD_KB, ntc = a.cnt[0] + a.cnt[1];
     const float *const ones_blk = a.consts, *const zero_blk = a.consts + 4;
+#ifdef WD_STAMPS
+    long long sk_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sk_prev = (long long)__builtin_amdgcn_s_memtime();
+    const long long sk_t0 = sk_prev;
+#define SK_PH(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); sk_ph[i] += t_now - sk_prev; sk_prev = t_now; } while (0)
+#else
+#define SK_PH(i) do { } while (0)
+#endif
     for (int f = 0; f < 3; ++f) {
         const SkFrag fr = sa.frags[3 * wg + f];
         if (fr.role < 0) continue;   // block-uniform
@@ -399,13 +409,16 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
             }
+            SK_PH(0);   // fragment set-up (pointers; role 2: poll + slab into the accumulators)
             if (fr.s0 < fr.s1 && fr.s1 <= T) {
                 issue(fr.s0, 0);
                 wide_dma_wait();
                 __syncthreads();
+                SK_PH(1);   // pipeline fill: the fragment's first stage, nothing to compute meanwhile
                 for (int st = fr.s0; st < fr.s1; ++st) {
                     const int cur = (st - fr.s0) & 1;
                     if (st + 1 < fr.s1) issue(st + 1, cur ^ 1);
+                    SK_PH(2);   // issue of the next stage
                     if (active) {
                         const float *cA = sA + cur * AOP, *cB = sB + cur * WD_BOP;
 #pragma unroll
@@ -423,8 +436,14 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
                                 for (int u = 0; u < NUC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[u][j], acc[u], 0, 0, 0);
                         }
                     }
+                    SK_PH(3);   // compute
                     wide_dma_wait();
+                    SK_PH(4);   // next stage landed
                     __syncthreads();
+                    SK_PH(5);   // barrier
+#ifdef WD_STAMPS
+                    sk_ph[10] += 1;
+#endif
                 }
             }
             if (fr.role == 1) {
@@ -438,6 +457,7 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) __hip_atomic_store(sa.flag + wg, sa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                SK_PH(6);   // publish
                 return;
             }
 #pragma unroll
@@ -449,6 +469,7 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
                     if (row < a.M && col < a.N) E.out[(long long)row * a.N + col] = acc[u][r];
                 }
             }
+            SK_PH(7);   // tile stores
         };
         if (NU == 5) body(std::integral_constant<int, 5>{});
         else if (NU == 4) body(std::integral_constant<int, 4>{});
@@ -456,6 +477,13 @@ __global__ void __launch_bounds__(256, 2) k_wide_sk(SkArgs sa) {
         else if (NU == 2) body(std::integral_constant<int, 2>{});
         else body(std::integral_constant<int, 1>{});
     }
+#ifdef WD_STAMPS
+    if (sa.stamps && lane == 0) {
+        long long *o = sa.stamps + ((long long)wg * WV + w) * 16;
+        o[0] = sk_t0; o[1] = (long long)__builtin_amdgcn_s_memtime(); o[2] = sk_ph[10];
+        for (int i = 0; i < 8; ++i) o[3 + i] = sk_ph[i];
+    }
+#endif
 }
 
 // Host side of k_wide_sk: the fragments of every workgroup.  `a` is a one-evaluation, one-K-range plan (wide_plan(..., split = false)).

@@ -152,6 +152,44 @@ int main(int argc, char **argv) {
         }
     }
 #endif
+    {   // the stream-K wgrad (k_wide_sk): timing, and with -DWD_STAMPS the per-wave anatomy
+        std::vector<SkFrag> fr;
+        const int nwg = wide_plan_sk(g, 512, fr);
+        printf("stream-K plan: %d workgroups\n", nwg);
+        if (nwg > 1) {
+            SkFrag *fr_d; float *slab; int *flag, *err_h;
+            hipMalloc(&fr_d, fr.size() * sizeof(SkFrag)); hipMemcpy(fr_d, fr.data(), fr.size() * sizeof(SkFrag), hipMemcpyHostToDevice);
+            hipMalloc(&slab, (size_t)nwg * 4 * WD_NB * 16 * 64 * 4); hipMalloc(&flag, (nwg + 1) * 4); hipHostMalloc(&err_h, 4, hipHostMallocMapped); *err_h = 0;
+            SkArgs sa{}; sa.w = g; sa.frags = fr_d; sa.slab = slab; sa.flag = flag; sa.nwg = nwg; sa.err = err_h;
+            int epoch = 0;
+            auto run = [&]() { hipMemsetAsync(flag, 0, (nwg + 1) * 4, 0); sa.epoch = ++epoch; launch_wide_sk(sa, 0); };
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0, 0);
+                for (int i = 0; i < 10; ++i) run();
+                hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+                printf("stream-K wgrad (%d workgroups, incl. a 2 KB flag memset per launch): %.1f us  = %.1f TFLOP/s\n", nwg, ms * 100.f, 2.0 * M * N * (double)(K + 1) / (ms * 1e-4) / 1e12);
+            }
+#ifdef WD_STAMPS
+            long long *st; hipMalloc(&st, (size_t)nwg * 4 * 16 * 8); hipMemset(st, 0, (size_t)nwg * 4 * 16 * 8);
+            sa.stamps = st;
+            run(); hipDeviceSynchronize();
+            std::vector<long long> hs((size_t)nwg * 4 * 16);
+            hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+            double ph[8] = {0}, life = 0, stages = 0; long long tmin = 1ll << 62, tmax = 0, emin = 1ll << 62; int n = 0;
+            for (int wgi = 0; wgi < nwg; ++wgi)
+                for (int w = 0; w < 4; ++w) {
+                    const long long *o = &hs[((size_t)wgi * 4 + w) * 16];
+                    ++n; life += (double)(o[1] - o[0]); stages += (double)o[2];
+                    tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[1]); emin = std::min(emin, o[1]);
+                    for (int i = 0; i < 8; ++i) ph[i] += (double)o[3 + i];
+                }
+            // s_memtime counts at 100 MHz on this part: 1 tick = 10 ns
+            printf("stream-K anatomy (mean per wave, in s_memtime ticks of 10 ns): lifetime %.0f, stages %.1f | set-up %.0f  fill %.0f  issue %.0f  compute %.0f  landed %.0f  barrier %.0f  publish %.0f  stores %.0f\n",
+                   life / n, stages / n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[6] / n, ph[7] / n);
+            printf("launch span: first start -> last end %lld ticks; earliest end %lld ticks after the first start\n", tmax - tmin, emin - tmin);
+#endif
+        }
+    }
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
