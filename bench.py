@@ -387,6 +387,16 @@ def stage_measurements(args, opt, rb, roll, d):
             lh.train(rbh.sample_batch(B))                       # worker_train's loop body through the host surface
         torch.cuda.synchronize()
         t_iter = (time.perf_counter() - t0) / 300
+        rbh.prefetch(B, own_stream=True)                        # the reference's Cache (algos/sac1/sac1.py:103-130) inside the buffer
+        for _ in range(20):
+            lh.train(rbh.sample_batch(B))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(1000):
+            lh.train(rbh.sample_batch(B))
+        torch.cuda.synchronize()
+        t_iter_pf = (time.perf_counter() - t0) / 1000
+        rbh.prefetch(0)
         from distributed_drl_amd.agent import Actor
         ah = Actor(opt, job="worker", index=78)
         for _ in range(20):
@@ -399,9 +409,12 @@ def stage_measurements(args, opt, rb, roll, d):
         out["host_surface_pcie_inclusive"] = {
             "store_per_s": 1.0 / t_store, "store_us": t_store * 1e6, "sample_batch_per_s": 1.0 / t_samp, "sample_batch_us": t_samp * 1e6,
             "sample_plus_train_per_s": 1.0 / t_iter, "sample_plus_train_us": t_iter * 1e6, "get_action_us": t_act * 1e6,
+            "sample_plus_train_prefetch_per_s": 1.0 / t_iter_pf, "sample_plus_train_prefetch_us": t_iter_pf * 1e6,
             "what": "the reference's call shapes with HOST buffers crossing PCIe on every call: ReplayBuffer.store(obs, act, rew, next_obs, done) "
                     "of one transition (five NumPy values up), sample_batch(256) (a dict of NumPy arrays down), and worker_train's loop body "
-                    "train(sample_batch()) (batch down and up again, eager launches).  Reported beside the device-resident figures, never as `value`."}
+                    "train(sample_batch()) (batch down and up again) — plain, and with the reference's Cache prefetch inside the buffer "
+                    "(ReplayBuffer.prefetch(B, own_stream=True): ten draws in flight on the buffer's own stream; same batches, same order).  "
+                    "Reported beside the device-resident figures, never as `value`."}
         del rbh, lh
     except Exception as e:  # noqa
         out["host_surface_pcie_inclusive"] = {"error": repr(e)[:200]}

@@ -1,0 +1,9 @@
+set -u
+cd "${GRAFT_REPO_ROOT:?}"; O=gpurun_out/r6_final2; mkdir -p $O
+python -m pytest tests/ -x -q -m gpu > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+( for seed in 21 22 23; do echo "== DDRL_FUZZ_N=150 DDRL_FUZZ_SEED=$seed python -m pytest tests/test_gpu_fuzz_shapes.py -q -m gpu"; DDRL_FUZZ_N=150 DDRL_FUZZ_SEED=$seed python -m pytest tests/test_gpu_fuzz_shapes.py -q -m gpu 2>&1 | tail -1; done ) | tee $O/fuzz.txt
+( echo "== soak 200000 x 256 (50 per graph)"; python tools/soak.py 200000 256 50 2>&1 | grep -v amdgpu | tail -1
+  echo "== dqn_soak 3000 ddqn"; python tools/dqn_soak.py 3000 ddqn 2>&1 | grep -v amdgpu | tail -1
+  echo "== dqn_soak 2000 sqn"; python tools/dqn_soak.py 2000 sqn 2>&1 | grep -v amdgpu | tail -1 ) | tee $O/soak.txt
+python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; head -c 600 $O/bench.json
