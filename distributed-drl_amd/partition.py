@@ -486,10 +486,10 @@ class PartitionedRun:
 
     def check(self):
         """Drain the device and raise what its samplers reported."""
-        if self.pending is not None:                 # free mode: the blocks posted for a step that will not run (their sends have been issued)
-            for r in self.pending["recvs"]:
+        if self.pending is not None:                 # free mode: the blocks posted for the next step (their sends have been issued) land
+            for r in self.pending["recvs"]:          # now; a later step() arms them as usual, a run that ends here leaves nothing in flight
                 r.wait()
-            self.pending = None
+            self.pending["recvs"] = []
         if self.learner is not None:
             self._poll_error(drain=True)
 

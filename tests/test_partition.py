@@ -286,7 +286,9 @@ def _gpu_worker_free(rank, world, port, q, num_learners, sizes=TOY, K=3):
         rs = np.random.RandomState(100 + r)
         handed, trained, adopted, pushed = [], [], [], []
         for s_ in range(n_steps):
-            run.step(per_step)
+            if s_ == 2:
+                run.check()                            # a drain between steps (bench.py does one behind its timed region) changes nothing:
+            run.step(per_step)                         # the blocks already posted for this step stay posted
             torch.cuda.synchronize()
             if run.rb is not None:
                 # this ring's sampler has now drawn, in this order: (first call only) the blocks of step 0 for REMOTE learners from the ring
