@@ -1905,6 +1905,7 @@ int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     if (!graphs_on || !h->fused || s == nullptr || cap != hipStreamCaptureStatusNone) return issue();   // (the legacy null stream cannot be captured)
+    if (h->noise_armed || h->sample_armed) return issue();   // a request armed through another call belongs to THIS update only: not into a graph
     for (auto &hg : h->host_graphs)
         if (hg.block == block_h && hg.losses == losses_d && hg.seed == noise_seed && hg.opt_cur == h->opt_cur && hg.sh_cur == h->sh_cur) {
             DDRL_HIP_CHECK(hipGraphLaunch(hg.exec, s));
@@ -1919,17 +1920,25 @@ int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32
     }
     ddrl_sac1::HostGraph hg{block_h, losses_d, noise_seed, h->opt_cur, h->sh_cur, nullptr};
     hipGraph_t graph = nullptr;
+    // the recorded launches advance the host-side launch state without running: kept if the graph then runs once, put back if not
+    const ddrl_sac1::HostSnap before{true, h->opt_cur, h->sh_cur, h->fuse_apply, h->sample_armed, h->noise_armed, h->grad_imported, h->noise_seed, h->noise_pending};
+    auto put_back = [&]() {
+        h->opt_cur = before.opt_cur; h->sh_cur = before.sh_cur; h->fuse_apply = before.fuse_apply; h->sample_armed = before.sample_armed;
+        h->noise_armed = before.noise_armed; h->grad_imported = before.grad_imported; h->noise_seed = before.noise_seed; h->noise_pending = before.noise_pending;
+    };
     DDRL_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = issue();
     const hipError_t e2 = hipStreamEndCapture(s, &graph);
     if (rc != DDRL_OK || e2 != hipSuccess || graph == nullptr) {
         if (graph) (void)hipGraphDestroy(graph);
-        if (rc == DDRL_OK) ddrl::set_error("capturing the host-batch update failed: %s", hipGetErrorString(e2));
-        return rc != DDRL_OK ? rc : DDRL_ERR_HIP;
+        (void)hipGetLastError();
+        put_back();
+        if (rc != DDRL_OK) return rc;                  // the update itself was refused (arguments): the same eagerly
+        return issue();                                // the capture was refused: nothing ran — this update goes eagerly
     }
     const hipError_t e3 = hipGraphInstantiate(&hg.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e3 != hipSuccess) { ddrl::set_error("hipGraphInstantiate: %s", hipGetErrorString(e3)); return DDRL_ERR_HIP; }
+    if (e3 != hipSuccess) { (void)hipGetLastError(); put_back(); return issue(); }
     h->host_graphs.push_back(hg);
     DDRL_HIP_CHECK(hipGraphLaunch(hg.exec, s));   // (the capture recorded the update — host state advanced once — now it runs once)
     return DDRL_OK;
@@ -2055,6 +2064,7 @@ struct ddrl_actor {
     float *flat_tmp;               // ... through this dense staging vector
     VerTile *vtiles_d;
     VerState *vs_d;
+    int vt_cap;                    // records of the forward's workgroup table (= the versioned forward's grid)
     int wg_slots;                  // resident workgroups of the two-per-CU forward: 2 x CUs (the planning launch sizes the column split for it)
     long long steps_since_install;   // host-side: >= the envs' max_ep_len <=> every env has adopted the newest version
 };
@@ -2103,9 +2113,11 @@ __device__ __forceinline__ int ver_group_add(int *arr, int s, bool valid, int la
 //          the first operand).  An env's position in its group is the value its histogram atomic returned — one atomic pass, not two.
 constexpr int VER_REG_ENVS = 8;   // envs per thread kept in registers across the passes (8192 envs: config 4's rollout ranks)
 __global__ void __launch_bounds__(1024) k_version_plan(const int *__restrict__ slot, long long n, int n_slots, int *__restrict__ rows,
-                                                       VerTile *__restrict__ tiles, VerState *vs, int install, int col_tiles, int wg_slots) {
+                                                       VerTile *__restrict__ tiles, VerState *vs, int install, int col_tiles, int wg_slots,
+                                                       int tiles_cap) {
     __shared__ int cnt[VER_MAX_SLOTS], tstart[VER_MAX_SLOTS];
-    __shared__ int wsum_t[16], s_nt, s_free, s_live;
+    __shared__ int wsum_t[16], s_free, s_live;
+    __shared__ VerSplit s_split;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     int sv[VER_REG_ENVS], pv[VER_REG_ENVS];
 #pragma unroll
@@ -2144,7 +2156,10 @@ __global__ void __launch_bounds__(1024) k_version_plan(const int *__restrict__ s
     for (int k = 0; k < w; ++k) bt += wsum_t[k];
     const int et = bt + st - (t0 + t1);   // exclusive prefix of this thread's pair
     tstart[2 * t] = et; tstart[2 * t + 1] = et + t0;
-    if (t == 1023) { vs->n_tiles = bt + st; s_nt = bt + st; vs->ngroups = ver_pick_groups(bt + st, col_tiles, wg_slots); }
+    if (t == 1023) {
+        const VerSplit sp = ver_split(bt + st, col_tiles, wg_slots, tiles_cap);
+        vs->n_tiles = bt + st; vs->n_wgs = sp.n_wgs; s_split = sp;
+    }
     if (t == 0 && install) {
         int target = newest;
         if (cnt[newest] > 0) {
@@ -2156,15 +2171,23 @@ __global__ void __launch_bounds__(1024) k_version_plan(const int *__restrict__ s
         vs->live = s_live;
     }
     __syncthreads();
-    // tile ti belongs to the LAST slot whose first tile is <= ti (the empty slots behind it start where it ends)
-    for (int ti = t; ti < s_nt; ti += 1024) {
+    // one record per WORKGROUP of the forward (ver_split: the long workgroups of the full rounds first, the surplus tiles' short ones
+    // behind them).  Tile ti belongs to the LAST slot whose first tile is <= ti (the empty slots behind it start where it ends)
+    const VerSplit sp = s_split;
+    const int n_long_wgs = sp.n_long * sp.g_long;
+    for (int b = t; b < sp.n_wgs; b += 1024) {
+        const bool lg = b < n_long_wgs;
+        const int g = lg ? sp.g_long : sp.g_short, bb = lg ? b : b - n_long_wgs;
+        const int ti = (lg ? 0 : sp.n_long) + bb / g, grp = bb % g;
         int lo = 0, hi = VER_MAX_SLOTS;            // first index with tstart > ti
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (tstart[mid] > ti) hi = mid; else lo = mid + 1;
         }
         const int j = lo - 1, k = ti - tstart[j], c = cnt[j];
-        tiles[ti] = VerTile{j, 32 * ti, c - 32 * k < 32 ? c - 32 * k : 32, 0};
+        const int gbase = col_tiles / g, gextra = col_tiles % g;   // column tiles dealt to the g workgroups as evenly as they go
+        const int ntl = gbase + (grp < gextra ? 1 : 0), nt0 = grp * gbase + (grp < gextra ? grp : gextra);
+        tiles[b] = VerTile{j, 32 * ti, c - 32 * k < 32 ? c - 32 * k : 32, nt0 | (ntl << 8)};
     }
 #pragma unroll
     for (int e = 0; e < VER_REG_ENVS; ++e)
@@ -2310,7 +2333,7 @@ int ddrl_actor_set_weights(ddrl_actor_t *h, const float *flat_pi_d, void *stream
         // version store: the new weights become the newest version, in a slot no env acts on — ONE planning launch (slot pick + the tile
         // table of the next forward) and ONE pack into the current copy and that slot (round 4: two packs, the pick, a 0.5 MB copy
         // and, in the step, the grouping: five launches)
-        k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 1, (h->cfg.hidden2 + 31) / 32, h->wg_slots);
+        k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, h->max_rows, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 1, (h->cfg.hidden2 + 31) / 32, h->wg_slots, h->vt_cap);
         k_pack_version<<<dim3(64, (unsigned)h->Ld.segs.size()), 256, 0, s>>>(h->segs_dd, flat_pi_d, h->pi_d, h->vslab, h->vstride, h->vs_d);
         h->plan_fresh = true;
         h->steps_since_install = 0;
@@ -2341,7 +2364,17 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
     hipError_t e = dev_alloc(&h->vslab, (size_t)np * n_slots + 2048);
     if (e == hipSuccess) e = dev_alloc(&h->slot_d, (size_t)h->max_rows + 64);
     if (e == hipSuccess) e = dev_alloc(&h->perm_d, (size_t)32 * (h->max_rows / 32 + n_slots) + (size_t)h->max_rows + 64);
-    if (e == hipSuccess) e = dev_alloc(&h->vtiles_d, (size_t)(h->max_rows / 32 + n_slots) + 16);
+    int ncu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    // the forward's workgroup table: the coarsest split of the worst-case tile count (every live version leaves one partial tile) plus
+    // one round of short workgroups (ver_split)
+    const int col_tiles = (h->cfg.hidden2 + 31) / 32, g2 = col_tiles < 2 ? 1 : ((col_tiles + ANT - 1) / ANT < 2 ? 2 : (col_tiles + ANT - 1) / ANT);
+    const long long vt_worst = h->max_rows / 32 + (n_slots < h->max_rows ? n_slots : h->max_rows);
+    const long long vt_cap = vt_worst * g2 + 2 * ncu;
+    if (e == hipSuccess) e = dev_alloc(&h->vtiles_d, (size_t)vt_cap + 16);
     if (e == hipSuccess) e = dev_alloc(&h->vs_d, 2);
     if (e != hipSuccess) {
         ddrl::set_error("hipMalloc failed in ddrl_actor_versions_enable (%d slots of %lld floats): %s", n_slots, np, hipGetErrorString(e));
@@ -2351,12 +2384,12 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
     // (dev_alloc zero-fills: every env on slot 0, newest = 0) slot 0 = the weights the actor holds now
     h->vstride = np;
     h->n_slots = n_slots;
-    {
-        int ncu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        h->wg_slots = 2 * ncu;
+    h->wg_slots = 2 * ncu;
+    if (const char *ev = getenv("DDRL_VER_WG_SLOTS")) {   // tests: a small "chip", so that small env counts walk the multi-round splits
+        const int v = atoi(ev);
+        if (v >= 1 && v <= 2 * ncu) h->wg_slots = v;
     }
+    h->vt_cap = (int)vt_cap;
     k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
     h->steps_since_install = 1ll << 40;
     h->plan_fresh = false;
@@ -2479,13 +2512,12 @@ int ddrl_actor_internal_forward(ddrl_actor *h, long long n, void *stream, int ve
         // envs grouped by the policy version they act on; a row tile = up to 32 envs of one version.  The launch covers the worst
         // case (every live version leaves one partial tile), surplus workgroups leave at once.
         DDRL_REQUIRE(h->n_slots > 0 && n == h->max_rows, "versioned forward: store not enabled, or n != max_rows");
-        if (!h->plan_fresh) k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 0, nt2, h->wg_slots);
+        if (!h->plan_fresh) k_version_plan<<<1, 1024, 0, s>>>(h->slot_d, n, h->n_slots, h->perm_d, h->vtiles_d, h->vs_d, 0, nt2, h->wg_slots, h->vt_cap);
         h->plan_fresh = true;   // (ddrl_rollout_step clears it behind the env-step launch, ddrl_actor_versions_adopt behind its own)
-        const long long vt = n / 32 + (h->n_slots < n ? h->n_slots : n);
         A.W1 = h->vslab + L.pi_W1; A.W2p = A.W1 + ((c.hidden1 + 31) & ~31) * 16;
         A.b2 = h->vslab + L.pi_b2; A.wmu = h->vslab + L.pi_Wmu; A.wls = h->vslab + L.pi_Wls;
-        A.vtiles = h->vtiles_d; A.perm = h->perm_d; A.vs = h->vs_d; A.vstride = h->vstride; A.vt_max = (int)vt;
-        const unsigned vgrid = (unsigned)vt * (unsigned)(nt2 < VER_MAX_GROUPS ? (nt2 < 2 ? 1 : nt2) : VER_MAX_GROUPS);   // (the plan's choice of workgroups per row tile is at most that)
+        A.vtiles = h->vtiles_d; A.perm = h->perm_d; A.vs = h->vs_d; A.vstride = h->vstride; A.vt_max = h->vt_cap;
+        const unsigned vgrid = (unsigned)h->vt_cap;   // (the plan's workgroup count is at most that; the rest leave at once)
         if (ns == 4) k_actor_fwd<4, 2, true><<<vgrid, 256, 0, s>>>(A);
         else if (ns == 5) k_actor_fwd<5, 2, true><<<vgrid, 256, 0, s>>>(A);
         else if (ns == 6) k_actor_fwd<6, 2, true><<<vgrid, 256, 0, s>>>(A);

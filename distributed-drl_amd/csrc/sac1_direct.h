@@ -548,27 +548,49 @@ static void launch_dfwd(const DFHead &d, const DFArgs &F_, hipStream_t s) {
 // Same summation orders as k_dfwd (block order inside a wave, waves 0..3 in the combine, columns 0..31 in the head dot).
 // ==========================================================================================
 constexpr int ANT = 5;
-// A row tile of the versioned forward: `count` (<= 32) envs perm[base .. base + count) that all act on policy version `slot`.
-struct VerTile { int slot, base, count, pad; };
+// One WORKGROUP of the versioned forward: `count` (<= 32) envs perm[base .. base + count) that all act on policy version `slot`, and the
+// column tiles [cols & 255, + cols >> 8) of their row tile.
+struct VerTile { int slot, base, count, cols; };
 // Device-side state of an actor's version store (exact per-env weight adoption, example/dsac.py:127-130).
-struct VerState { int newest, target, n_tiles, err, live, ngroups, pad[2]; };
-// Workgroups per row tile of the versioned forward, chosen by the planning launch from the ACTUAL tile count: with envs grouped by
-// version the count is a little over a whole number of rounds (8192 envs / 16 versions: 264 row tiles x 2 workgroups = 528 for 512 slots —
-// sixteen workgroups ran a second round as long as the first), and a finer column split trades a few more redundant layer-1 passes for
-// rounds that are shorter (cost model in ver_pick_groups).
-constexpr int VER_MAX_GROUPS = 3;
-__host__ __device__ inline int ver_pick_groups(int n_tiles, int col_tiles, int slots) {
-    int best = 2, best_cost = 0x7fffffff;
-    // measured (tools/version_step_probe.py, 10 column tiles): a workgroup of `per` column tiles takes 6.2 + 3.1 per microseconds with the
-    // chip full; a last, partly filled round runs ~0.8 of that; five groups per row tile lost to two in every case tried (1320 and 1410
-    // workgroups: dispatch), so the choice is between two and three
-    for (int g = 2; g <= 3 && g <= col_tiles; ++g) {
-        const int wgs = n_tiles * g, full = wgs / slots, rem = wgs - full * slots, per = (col_tiles + g - 1) / g;
-        const int dur = 62 + 31 * per;
-        const int cost = full * dur + (rem > 0 ? (8 * dur) / 10 : 0);
+struct VerState { int newest, target, n_tiles, err, live, n_wgs, pad[2]; };
+// How the planning launch deals the row tiles' column tiles to workgroups, from the ACTUAL tile count.  With envs grouped by version
+// the count sits a little over a whole number of rounds (8192 envs / 16 versions: 264 row tiles x 2 workgroups = 528 for 512 resident
+// slots: sixteen workgroups ran a second round as long as the first).  A workgroup of `per` column tiles takes about 6.2 + 3.1 per
+// microseconds with the chip full (tools/version_step_probe.py), so:
+//   * everything fits one round: as many workgroups per row tile as still fit it (two, or three when 3 T <= slots);
+//   * otherwise the first floor(g T / slots) FULL rounds' worth of row tiles take g = ceil(col_tiles / ANT) workgroups each (the
+//     coarsest split, the least redundant layer-1 work), and the SURPLUS row tiles behind them are cut fine enough that their workgroups
+//     are short and fit one more round of their own: 16 surplus tiles x 10 single-tile workgroups add 9 us behind the long round
+//     instead of 17-22.  (A finer split of EVERY tile lost in every case tried: 1320 and 1410 workgroups, dispatch.)
+// The long workgroups come first in launch order, the short ones fill the slots the long ones leave.
+struct VerSplit { int g_long, n_long, g_short, n_wgs; };   // n_long row tiles x g_long workgroups, the rest x g_short
+__host__ __device__ inline int ver_wg_dur(int col_tiles, int g) { return 62 + 31 * ((col_tiles + g - 1) / g); }
+__host__ __device__ inline VerSplit ver_split(int n_tiles, int col_tiles, int slots, int cap) {
+    const int ant = 5;   // = ANT (declared below the launch tables)
+    int g2 = (col_tiles + ant - 1) / ant;
+    if (g2 < 2 && col_tiles >= 2) g2 = 2;
+    if (g2 < 1) g2 = 1;
+    VerSplit v{g2, n_tiles, g2, n_tiles * g2};
+    if (n_tiles <= 0 || slots <= 0) return v;
+    const int rounds = (n_tiles * g2) / slots;
+    if (rounds == 0) {       // one round: a finer uniform split while it still fits
+        if (g2 + 1 <= col_tiles && n_tiles * (g2 + 1) <= slots && n_tiles * (g2 + 1) <= cap &&
+            (col_tiles + g2) / (g2 + 1) < (col_tiles + g2 - 1) / g2) { v.g_long = v.g_short = g2 + 1; v.n_wgs = n_tiles * (g2 + 1); }
+        return v;
+    }
+    const int n_long = (rounds * slots) / g2 < n_tiles ? (rounds * slots) / g2 : n_tiles;
+    const int u = n_tiles - n_long;
+    if (u == 0) return v;
+    int best = g2, best_cost = ((u * g2 + slots - 1) / slots) * ver_wg_dur(col_tiles, g2);
+    const int cand[5] = {g2 + 1, 4, 5, (col_tiles + 1) / 2, col_tiles};
+    for (int i = 0; i < 5; ++i) {
+        const int g = cand[i];
+        if (g <= g2 || g > col_tiles || u * g > slots || n_long * g2 + u * g > cap) continue;   // short workgroups: one round of their own
+        const int cost = ver_wg_dur(col_tiles, g);
         if (cost < best_cost) { best_cost = cost; best = g; }
     }
-    return col_tiles < 2 ? 1 : best;
+    v.n_long = n_long; v.g_short = best; v.n_wgs = n_long * g2 + u * best;
+    return v;
 }
 struct ActFwdArgs {
     const float *W1, *W2p, *b2, *wmu, *wls, *obs;
@@ -579,7 +601,7 @@ struct ActFwdArgs {
     const int *perm;
     const VerState *vs;
     long long vstride;
-    int vt_max;              // VER: row tiles the tile table / row lists are allocated for (the launch covers VER_MAX_GROUPS workgroups per tile)
+    int vt_max;              // VER: records the workgroup table is allocated for (= the launch's grid: the worst case; the plan says how many run)
 #ifdef DDRL_STAMPS
     unsigned long long *st;  // dev harness (tools/actor_bench.hip): [workgroup][wave][32] cycle stamps
 #endif
@@ -603,27 +625,26 @@ __global__ void __launch_bounds__(256, OCC) k_actor_fwd(ActFwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    // column tiles are dealt to `ngroups` workgroups per row tile as evenly as they go (VER: the planning launch's choice)
-    const int ngroups = VER ? a.vs->ngroups : a.ngroups;
-    const int rt = blockIdx.x / ngroups, grp = blockIdx.x - rt * ngroups;
-    const int gbase = a.tiles_n / ngroups, gextra = a.tiles_n % ngroups;
-    const int ntiles = gbase + (grp < gextra ? 1 : 0);
-    int m0 = rt * 32;
-    const int nt0 = grp * gbase + (grp < gextra ? grp : gextra);
-    // VER: row tile rt of the grouping kernel's table — its envs (through perm) and its version's weights
+    // column tiles are dealt to `ngroups` workgroups per row tile as evenly as they go (VER: the planning launch's table, one record per workgroup)
+    int m0, ntiles, nt0;
     int vcount = 32, vrow = 0;
-    if (VER) {
-        // three independent loads, one round trip: the launch's tile count, this tile's record, this lane's env (the row list of tile rt
-        // sits at perm[32 rt ..): no chain through the record; entries beyond the tile's count, and tiles beyond n_tiles, hold whatever
-        // an earlier plan left — valid env numbers or zero, never read as data)
-        const int nt_live = a.vs->n_tiles;
-        const int rtc = rt < a.vt_max ? rt : 0;   // (the launch is sized for the finest column split: with a coarser one the surplus workgroups' rt runs past the tables)
-        const VerTile vt = a.vtiles[rtc];
-        vrow = a.perm[32 * rtc + l31];
-        if (rt >= nt_live) return;   // the launch covers the worst case (n / 32 + live versions); block-uniform
+    if (!VER) {
+        const int ngroups = a.ngroups;
+        const int rt = blockIdx.x / ngroups, grp = blockIdx.x - rt * ngroups;
+        const int gbase = a.tiles_n / ngroups, gextra = a.tiles_n % ngroups;
+        ntiles = gbase + (grp < gextra ? 1 : 0);
+        nt0 = grp * gbase + (grp < gextra ? grp : gextra);
+        m0 = rt * 32;
+    } else {
+        // two independent loads (the launch's workgroup count, this workgroup's record), then this lane's env out of the record's row list;
+        // entries beyond the tile's count hold whatever an earlier plan left — valid env numbers or zero, never read as data
+        const int n_wgs = a.vs->n_wgs;
+        const VerTile vt = a.vtiles[(int)blockIdx.x < a.vt_max ? blockIdx.x : 0];
+        if ((int)blockIdx.x >= n_wgs) return;   // the launch covers the worst case; block-uniform
+        vrow = a.perm[vt.base + l31];
         const long long off = (long long)vt.slot * a.vstride;
         a.W1 += off; a.W2p += off; a.b2 += off; a.wmu += off; a.wls += off;
-        m0 = 32 * rt; vcount = vt.count;
+        m0 = vt.base; vcount = vt.count; nt0 = vt.cols & 255; ntiles = vt.cols >> 8;
         vrow = __shfl(vrow, (lane & 32) + (l31 < vcount ? l31 : vcount - 1));   // rows beyond the count repeat the tile's last env
     }
     const int K = a.K, Np = a.Np, d0 = a.d0;

@@ -49,7 +49,9 @@ class ReplayBuffer:
 
     # -- np.random.seed(s) of the reference's buffer process ---------------------------------
     def seed(self, s):
+        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_seed(self._h, int(s) & 0xFFFFFFFF, _lib.stream_ptr()))
+        self._pf_order_store(False)
 
     # -- reference surface ---------------------------------------------------------------------
     def store(self, obs, act, rew, next_obs, done, worker_index=None):
@@ -95,8 +97,10 @@ class ReplayBuffer:
         keep them longer).  prefetch(0) turns it off.
         own_stream=True: the draws run on a stream of the buffer's own, beside the caller's stream (a learner's update on the same
         thread then no longer queues behind the gather and its copy down); this object's store / store_batch calls are ordered
-        against the draws by events.  Writers that go to the ring BEHIND this object's back on another stream (a RolloutDevice's fused
-        env-step launch stores through the C handle) are not: keep the default there."""
+        against the draws by events, and so are its other calls that move the sampler or the rows (seed, draws of another size,
+        sample_batch_device / sample_many, set_rows); the counters get_counts() reads include the draws in flight.  Writers that go
+        to the ring BEHIND this object's back on another stream (a RolloutDevice's fused env-step launch stores through the C
+        handle; a feed plan attached with set_feed) are not: keep the default there."""
         pf = getattr(self, "_pf", None)
         if pf is not None:
             if pf["stream"] is not None:
@@ -180,7 +184,9 @@ class ReplayBuffer:
             offs.append((offs[-1] + n + 3) & ~3)               # every piece 16-byte aligned
         flat = torch.empty(offs[5], dtype=torch.float32, device=self.device)
         p = [flat.data_ptr() + 4 * offs[j] for j in range(5)]
+        self._pf_order_store(True)       # (a draw of another size while a prefetch is on: behind the draws in flight, in front of the next)
         _lib.check(self._lib.ddrl_replay_sample(self._h, B, p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
+        self._pf_order_store(False)
         h = flat.cpu().numpy()
         return dict(obs1=h[offs[0]:offs[0] + B * o].reshape(B, o), obs2=h[offs[1]:offs[1] + B * o].reshape(B, o),
                     acts=h[offs[2]:offs[2] + B * a] if self._acts_1d else h[offs[2]:offs[2] + B * a].reshape(B, a),
@@ -192,9 +198,11 @@ class ReplayBuffer:
         idx = None
         if with_indices:
             idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_sample(self._h, B, _lib.dptr(out["obs1"]), _lib.dptr(out["obs2"]),
                                                 _lib.dptr(out["acts"]), _lib.dptr(out["rews"]),
                                                 _lib.dptr(out["done"]), _lib.dptr(idx), _lib.stream_ptr()))
+        self._pf_order_store(False)
         if with_indices:
             out = dict(out, idxs=idx)
         return out
@@ -219,7 +227,9 @@ class ReplayBuffer:
             ptrs[j] = flat.data_ptr() + 4 * off
             off += K * B * w
         assert flat.numel() >= off and flat.dtype == torch.float32 and flat.is_cuda and flat.is_contiguous()
+        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_sample_many(self._h, B, K, ptrs, _lib.stream_ptr()))
+        self._pf_order_store(False)
         return flat[:off]
 
     def set_feed(self, plan, batch_size, regions):
@@ -303,7 +313,9 @@ class ReplayBuffer:
         values = self._f32(values)
         w = int(np.prod(self._ring_shapes()[array][1:])) if len(self._ring_shapes()[array]) > 1 else 1
         nrows = values.numel() // w
+        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_rows_import(self._h, int(array), int(row0), int(nrows), _lib.dptr(values), _lib.stream_ptr()))
+        self._pf_order_store(False)
 
     def check(self):
         """Surface the ring's sticky device-side error now (an empty-ring draw inside a graph, a value a compact array cannot hold)."""
@@ -417,7 +429,9 @@ class ReplayBufferNStep:
             self._lib.ddrl_replay_destroy(h)
 
     def seed(self, s):
+        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_seed(self._h, int(s) & 0xFFFFFFFF, _lib.stream_ptr()))
+        self._pf_order_store(False)
 
     def store(self, o_queue, a_r_d_queue, worker_index=None):
         """One window (sac_ray.py:53-70): o_queue = Ln+1 tuples (o,), a_r_d_queue = Ln tuples (a, r, d)."""

@@ -579,16 +579,24 @@ def test_vectorised_rollout_equals_n_reference_workers_in_the_weights_each_env_a
     assert roll.env.stats()[0] >= n * (steps // limit - 1)
 
 
-@pytest.mark.parametrize("n,limit,steps", [(96, 9, 30), (1024, 37, 64)])
-def test_versioned_rollout_actions_match_each_versions_own_policy(n, limit, steps):
+@pytest.mark.parametrize("n,limit,steps,slots,hidden", [(96, 9, 30, None, None), (1024, 37, 64, None, None), (1024, 37, 24, 24, None),
+                                                        (1024, 37, 24, 100, None), (512, 21, 24, 16, (64, 512)), (256, 11, 16, 40, (128, 96))])
+def test_versioned_rollout_actions_match_each_versions_own_policy(n, limit, steps, slots, hidden, monkeypatch):
     """The same with real (random) policies: every env's stored action equals Actor.get_action of THAT env's version on the
     observation it acted on, with the fused step's own noise element — within float32 of the row-major policy kernels.  (The second
-    case: 32 row tiles' worth of envs spread over up to 33 live versions — mostly partial row tiles.)"""
+    case: 32 row tiles' worth of envs spread over up to 33 live versions — mostly partial row tiles.  `slots`: the forward's planner
+    told the chip holds that many workgroups (DDRL_VER_WG_SLOTS), so that these env counts walk what 8192+ envs do on the real
+    one — full rounds of coarse workgroups, then the surplus row tiles cut into short ones; `hidden`: other column-tile counts, 16
+    of them included — four workgroups per row tile at the least.)"""
     import distributed_drl_amd as ddrl
     from distributed_drl_amd import _lib
     from distributed_drl_amd.agent import Actor, HyperParameters, Learner
     from distributed_drl_amd.workers import RolloutDevice
+    if slots is not None:
+        monkeypatch.setenv("DDRL_VER_WG_SLOTS", str(slots))
     opt = HyperParameters()
+    if hidden is not None:
+        opt.hidden_sizes = hidden
     opt.num_envs, opt.start_steps, opt.max_ep_len, opt.seed = n, -1, limit, 11
     keys, vals = Learner(opt).get_weights()
     rs = np.random.RandomState(2)

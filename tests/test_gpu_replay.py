@@ -797,3 +797,44 @@ def test_prefetch_on_its_own_stream_orders_against_stores():
         x = [torch.from_numpy(v).cuda() for v in more[it]]
         a.store_batch(*x); b.store_batch(*x)          # the ring wraps (700 rows): rows the next draws may pick are being replaced
     a.prefetch(0)
+
+
+@pytest.mark.gpu
+def test_prefetch_on_its_own_stream_orders_every_sampler_call_of_the_object():
+    """The calls of the same object that move the sampler or the rows while an own-stream prefetch is on — a draw of another size,
+    sample_batch_device, sample_many, seed, set_rows, stores — are ordered against the draws in flight: a mixed call sequence hands
+    out exactly what the same sequence does with the prefetch on the caller's stream (one stream: program order)."""
+    import distributed_drl_amd as d
+    rs = np.random.RandomState(4)
+    mk = lambda m: (rs.randn(m, 8).astype(np.float32), rs.uniform(-1, 1, (m, 2)).astype(np.float32), rs.randn(m).astype(np.float32),
+                    rs.randn(m, 8).astype(np.float32), np.zeros(m, np.float32))
+    first, more, rows = mk(900), [mk(40) for _ in range(8)], rs.randn(16, 8).astype(np.float32)
+
+    def run(own):
+        rb = d.ReplayBufferSAC1(8, 2, 1000, seed=11)
+        rb.store_batch(*(torch.from_numpy(x).cuda() for x in first))
+        rb.prefetch(32, depth=6, hold=2, own_stream=own)
+        out = []
+        flat = torch.empty(3 * 48 * 20, dtype=torch.float32, device="cuda")
+        for it in range(8):
+            out.append(np.concatenate([v.reshape(-1) for v in rb.sample_batch(32).values()]).copy())
+            if it % 2 == 0:
+                out.append(np.concatenate([v.reshape(-1) for v in rb.sample_batch(48).values()]).copy())
+            if it % 3 == 1:
+                dv = rb.sample_batch_device(16, fresh=True, with_indices=True)
+                out.append(dv["idxs"].cpu().numpy().astype(np.float32))
+            if it == 3:
+                out.append(rb.sample_many(48, 3, flat).cpu().numpy().copy())
+            if it == 4:
+                rb.seed(77)
+            if it == 5:
+                rb.set_rows(0, 100, torch.from_numpy(rows).cuda())
+            rb.store_batch(*(torch.from_numpy(x).cuda() for x in more[it]))
+        rb.prefetch(0)
+        return out
+
+    for _ in range(3):                               # (a race would show as a difference in some repeat)
+        one, two = run(False), run(True)
+        assert len(one) == len(two)
+        for i, (x, y) in enumerate(zip(one, two)):
+            np.testing.assert_array_equal(x, y, err_msg="call %d" % i)
