@@ -429,9 +429,7 @@ class ReplayBufferNStep:
             self._lib.ddrl_replay_destroy(h)
 
     def seed(self, s):
-        self._pf_order_store(True)
         _lib.check(self._lib.ddrl_replay_seed(self._h, int(s) & 0xFFFFFFFF, _lib.stream_ptr()))
-        self._pf_order_store(False)
 
     def store(self, o_queue, a_r_d_queue, worker_index=None):
         """One window (sac_ray.py:53-70): o_queue = Ln+1 tuples (o,), a_r_d_queue = Ln tuples (a, r, d)."""

@@ -1,0 +1,3 @@
+set -u
+cd "${GRAFT_REPO_ROOT:?}"
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -4
