@@ -385,6 +385,15 @@ struct RolloutArgs {
     int *slot;
     const int *newest;
     long long vstride;
+    // ... and the NEXT forward's plan, written by this launch (nullable: vcnt): every env counts itself into its slot's group and files
+    // itself in that group's row list; the last workgroup to finish turns the counts into the forward's workgroup table (what
+    // k_version_plan does as a launch of its own, 7-11 us between this launch and the forward that waits for it)
+    int *vcnt;             // [VER_MAX_SLOTS], zero on entry, zero again on exit
+    int *perm;             // row lists: group s at perm[perm2d_off + s * n ..)
+    long long perm2d_off;
+    VerTile *vtiles;
+    VerState *vs;
+    int n_slots, col_tiles, wg_slots, vt_cap;
     // replay ring
     ddrl_replay_dev::RingState *rs;
     ddrl_replay_dev::RingPtrs ring;
@@ -394,11 +403,13 @@ struct RolloutArgs {
 template <int NH>  // head partial rows fetched per env: 4 (act_dim <= 2) or 8
 __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
     __shared__ long long s_ptr;
+    __shared__ int s_last;
     if (threadIdx.x == 0) s_ptr = a.rs->ptr;
     __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = a.n;
     long long n_end = 0, len_end = 0;
     double ret_end = 0.0;
+    int my_slot = 0;       // the version this env acts on at the NEXT step
     if (i < n) {
         // ---- loads first: head partials (mu heads 0..act-1, log_std heads act..2act-1), the acted-on observation, the env state
         const int nq = (a.nt2 + 3) >> 2;  // float4 groups of a partial row that hold tiles
@@ -472,6 +483,7 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
             e.reset(o);                                 // :127
             if (a.slot) a.slot[i] = *a.newest;          // :129-130  weights = ps.pull(keys); agent.set_weights(keys, weights)
         }
+        if (a.vcnt) my_slot = ended ? *a.newest : a.slot[i];
         {
             float4 *p = reinterpret_cast<float4 *>(a.obs + i * 8);
             p[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -493,10 +505,34 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
         atomicAdd((unsigned long long *)&a.stats->len_sum, (unsigned long long)len_end);
         atomicAdd(&a.stats->ret_sum, ret_end);
     }
+    if (a.vcnt) {
+        // this env's place in its group: the lanes of a wave that share a slot go as ONE atomic of their leader (a few thousand envs sit
+        // on a handful of versions; all leaders' atomics leave in one instruction: one round trip whatever the number of groups)
+        const int lane = threadIdx.x & 63;
+        const bool valid = i < n;
+        unsigned long long todo = __ballot(valid);
+        int gsize = 0, rank = 0, leader = lane;
+        while (todo) {
+            const int ld = __ffsll((long long)todo) - 1;
+            const int s0 = __builtin_amdgcn_readlane(my_slot, ld);   // (ld is wave-uniform: no trip through the LDS crossbar per group)
+            const bool mine = valid && my_slot == s0;
+            const unsigned long long m = __ballot(mine);
+            if (mine) { gsize = __popcll(m); rank = __popcll(m & ((1ull << lane) - 1ull)); leader = ld; }
+            todo &= ~m;
+        }
+        int base = 0;
+        if (valid && lane == leader) base = atomicAdd(&a.vcnt[my_slot], gsize);
+        base = __shfl(base, leader);
+        if (valid) a.perm[a.perm2d_off + (long long)my_slot * n + base + rank] = (int)i;
+        // (no fence: the counts are device-scope atomics whose results this wave has waited for — performed before its ticket below —
+        // and nothing else crosses workgroups inside this launch: row lists, records and slots are read by the NEXT launch.  A
+        // __threadfence() here writes back the L2's dirty lines — this launch's ring rows — in every workgroup: +8 us measured.)
+    }
     // the last block to finish advances the ring cursor (every block has read rs->ptr before its ticket)
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned ticket = atomicAdd(&a.rs->done_counter, 1u);
+        s_last = ticket == gridDim.x - 1 ? 1 : 0;
         if (ticket == gridDim.x - 1) {
             const long long cap = a.ring.capacity;
             a.rs->ptr = (s_ptr + n) % cap;
@@ -505,6 +541,78 @@ __global__ void __launch_bounds__(64) k_env_step_pi(RolloutArgs a) {
             a.rs->steps += n * a.ring.steps_inc;
             a.rs->done_counter = 0;
         }
+    }
+    if (!a.vcnt) return;
+    __syncthreads();
+    if (!s_last) return;   // block-uniform
+    // ---- the last workgroup (one wave): the counts -> the next forward's workgroup table (the tables of k_version_plan, sac1.hip; the
+    // row lists are this launch's own: group s at perm2d_off + s * n, so a record's row-list base is known without a scatter pass)
+    __shared__ int t_cnt[VER_MAX_SLOTS], t_start[VER_MAX_SLOTS];
+    __shared__ unsigned short t_slot[VER_MAX_SLOTS + 1024];   // slot of row tile ti (n / 32 + live groups <= 1024 + 2048 tiles)
+    const int lane = threadIdx.x;   // (the counts are read with device-scope atomic loads, behind this workgroup's own ticket)
+    constexpr int PER = VER_MAX_SLOTS / 64;
+    const int per = (a.n_slots + 63) >> 6;   // slots per lane (<= PER): lane l holds slots [per l, per l + per)
+    int c[PER], run = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int j = per * lane + q;
+        c[q] = (q < per && j < a.n_slots) ? __hip_atomic_load(&a.vcnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        run += (c[q] + 31) >> 5;
+    }
+    int incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    const int total = __shfl(incl, 63);
+    // slot of every row tile: each group's first tile gets its slot number, a running maximum over the tiles fills the rest (groups lie
+    // in slot order) — `chunk` tiles per lane, so the one big group of the newest version is not one lane's loop
+    const int chunk = (total + 63) >> 6;
+    for (int k = 0; k < chunk; ++k) t_slot[lane * chunk + k] = 0;
+    __syncthreads();
+    int ts = incl - run;   // first row tile of this lane's first slot
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (q < per) {   // wave-uniform
+            const int j = per * lane + q, nt = (c[q] + 31) >> 5;
+            if (j < VER_MAX_SLOTS) { t_cnt[j] = c[q]; t_start[j] = ts; }
+            if (nt > 0) { t_slot[ts] = (unsigned short)j; a.vcnt[j] = 0; }   // (... and zero again for the next launch)
+            ts += nt;
+        }
+    }
+    const VerSplit sp = ver_split(total, a.col_tiles, a.wg_slots, a.vt_cap);
+    if (lane == 0) { a.vs->n_tiles = total; a.vs->n_wgs = sp.n_wgs; }
+    __syncthreads();
+    {
+        int mx = 0;
+        for (int k = 0; k < chunk; ++k) mx = max(mx, (int)t_slot[lane * chunk + k]);
+        int inc = mx;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc = max(inc, u);
+        }
+        int runmx = __shfl_up(inc, 1);
+        if (lane == 0) runmx = 0;
+        for (int k = 0; k < chunk; ++k) {
+            runmx = max(runmx, (int)t_slot[lane * chunk + k]);
+            t_slot[lane * chunk + k] = (unsigned short)runmx;
+        }
+    }
+    __syncthreads();
+    // (one wave: every instruction counts — the divisions by the two group counts are done once, the per-record ones by reciprocal)
+    const int n_long_wgs = sp.n_long * sp.g_long;
+    const int gb_l = a.col_tiles / sp.g_long, ge_l = a.col_tiles % sp.g_long, gb_s = a.col_tiles / sp.g_short, ge_s = a.col_tiles % sp.g_short;
+    const float inv_l = 1.0f / (float)sp.g_long, inv_s = 1.0f / (float)sp.g_short;
+    const int base0 = (int)a.perm2d_off, ni = (int)n;
+    for (int b = lane; b < sp.n_wgs; b += 64) {
+        const bool lg = b < n_long_wgs;
+        const int g = lg ? sp.g_long : sp.g_short, bb = lg ? b : b - n_long_wgs;
+        const int q = (int)(((float)bb + 0.5f) * (lg ? inv_l : inv_s));   // bb / g: exact (bb < 2^20, g <= 16: the product is >= 0.03 off a whole number)
+        const int ti = (lg ? 0 : sp.n_long) + q, grp = bb - q * g;
+        const int j = t_slot[ti], k = ti - t_start[j], cj = t_cnt[j];
+        const int gbase = lg ? gb_l : gb_s, gextra = lg ? ge_l : ge_s;
+        const int ntl = gbase + (grp < gextra ? 1 : 0), nt0 = grp * gbase + (grp < gextra ? grp : gextra);
+        a.vtiles[b] = VerTile{j, base0 + j * ni + 32 * k, cj - 32 * k < 32 ? cj - 32 * k : 32, nt0 | (ntl << 8)};
     }
 }
 
@@ -634,6 +742,10 @@ int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay,
         a.newest = versioned ? reinterpret_cast<const int *>(v.vs) : nullptr;   // VerState::newest is its first word
         a.vstride = v.vstride;
         a.bmu = versioned ? v.vbmu : v.bmu; a.bls = versioned ? v.vbls : v.bls;
+        // the next forward's plan rides in this launch (base offsets of the row lists must fit the records' int)
+        const bool fused_plan = versioned && v.vcnt != nullptr && v.perm2d_off + (long long)v.n_slots * h->n < (1ll << 31) && h->n / 32 <= 1024;
+        a.vcnt = fused_plan ? v.vcnt : nullptr; a.perm = v.perm; a.perm2d_off = v.perm2d_off; a.vtiles = v.vtiles;
+        a.vs = reinterpret_cast<VerState *>(const_cast<void *>(v.vs)); a.n_slots = v.n_slots; a.col_tiles = v.nt2; a.wg_slots = v.wg_slots; a.vt_cap = v.vt_cap;
         if (store) *v.steps_since_install += 1;
         const int rc = ddrl_actor_internal_forward(actor, h->n, stream, versioned ? 1 : 0);
         if (rc != DDRL_OK) return rc;
@@ -642,7 +754,7 @@ int ddrl_rollout_step(ddrl_env_t *h, ddrl_actor_t *actor, ddrl_replay_t *replay,
         if (v.act <= 2) k_env_step_pi<4><<<(unsigned)((h->n + 63) / 64), 64, 0, ddrl::as_stream(stream)>>>(a);
         else k_env_step_pi<8><<<(unsigned)((h->n + 63) / 64), 64, 0, ddrl::as_stream(stream)>>>(a);
         DDRL_LAUNCH_CHECK();
-        if (versioned) *v.plan_fresh = false;   // episode ends of this step moved envs to the newest version
+        if (versioned) *v.plan_fresh = fused_plan;   // episode ends of this step moved envs to the newest version: the launch's own tail has planned for that, or the next forward plans
         ddrl_replay_note_store(replay, h->n);
     }
     return DDRL_OK;

@@ -2065,6 +2065,8 @@ struct ddrl_actor {
     VerTile *vtiles_d;
     VerState *vs_d;
     int vt_cap;                    // records of the forward's workgroup table (= the versioned forward's grid)
+    int *vcnt_d;                   // envs per slot while an env-step launch counts them; all zero between launches
+    long long perm2d_off;          // perm_d: where the env-step launch's [n_slots][max_rows] row lists start
     int wg_slots;                  // resident workgroups of the two-per-CU forward: 2 x CUs (the planning launch sizes the column split for it)
     long long steps_since_install;   // host-side: >= the envs' max_ep_len <=> every env has adopted the newest version
 };
@@ -2073,7 +2075,6 @@ struct ddrl_actor {
 // One workgroup.  Picks the slot the incoming weights go to: the newest slot itself when no env has adopted it yet (nobody
 // can ever act on it again once a newer version exists: a worker pulls whatever the server holds at ITS episode end), else
 // the lowest slot no env acts on.  n_slots >= min(n_envs, max_ep_len) + 2 always leaves one.
-constexpr int VER_MAX_SLOTS = 2048;
 __global__ void __launch_bounds__(256) k_version_copy(const float *__restrict__ src, float *__restrict__ vslab, long long vstride,
                                                       const VerState *__restrict__ vs, long long n4) {
     float4 *dst = reinterpret_cast<float4 *>(vslab + (long long)vs->target * vstride);
@@ -2290,7 +2291,7 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
         c2.batch = 32;
         h->direct = direct_ok(c2) && max_rows % 32 == 0 && max_rows <= 32 * 4095 && cfg->obs_dim + 1 <= 13;
         h->dslab = nullptr; h->segs_dd = nullptr;
-        h->n_slots = 0; h->vslab = nullptr; h->slot_d = h->perm_d = nullptr; h->vtiles_d = nullptr; h->vs_d = nullptr;
+        h->n_slots = 0; h->vslab = nullptr; h->slot_d = h->perm_d = nullptr; h->vtiles_d = nullptr; h->vs_d = nullptr; h->vcnt_d = nullptr;
         h->plan_fresh = false; h->pi_p_stale = false; h->flat_tmp = nullptr;
         h->steps_since_install = 1ll << 40;
     }
@@ -2317,7 +2318,7 @@ int ddrl_actor_destroy(ddrl_actor_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
     (void)hipFree(h->dslab); (void)hipFree(h->segs_dd); (void)hipFree(h->flat_tmp);
-    (void)hipFree(h->vslab); (void)hipFree(h->slot_d); (void)hipFree(h->perm_d); (void)hipFree(h->vtiles_d); (void)hipFree(h->vs_d);
+    (void)hipFree(h->vslab); (void)hipFree(h->slot_d); (void)hipFree(h->perm_d); (void)hipFree(h->vtiles_d); (void)hipFree(h->vs_d); (void)hipFree(h->vcnt_d);
     (void)hipFree(h->pi_p); (void)hipFree(h->H1); (void)hipFree(h->H2); (void)hipFree(h->segs_d);
     delete h;
     return DDRL_OK;
@@ -2363,7 +2364,10 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
     const long long np = ((long long)h->Ld.total_int + 2048 + 63) & ~63ll;   // as the policy part of dslab (incl. the guard)
     hipError_t e = dev_alloc(&h->vslab, (size_t)np * n_slots + 2048);
     if (e == hipSuccess) e = dev_alloc(&h->slot_d, (size_t)h->max_rows + 64);
-    if (e == hipSuccess) e = dev_alloc(&h->perm_d, (size_t)32 * (h->max_rows / 32 + n_slots) + (size_t)h->max_rows + 64);
+    // row lists: the planning launch's dense [tiles][32] (+ its parking space), then the env-step launch's own [n_slots][max_rows]
+    const long long perm_dense = 32ll * (h->max_rows / 32 + n_slots) + h->max_rows + 64;
+    if (e == hipSuccess) e = dev_alloc(&h->perm_d, (size_t)perm_dense + (size_t)n_slots * (size_t)h->max_rows);
+    if (e == hipSuccess) e = dev_alloc(&h->vcnt_d, (size_t)VER_MAX_SLOTS);
     int ncu = 256;
     {
         hipDeviceProp_t prop;
@@ -2390,6 +2394,7 @@ int ddrl_actor_versions_enable(ddrl_actor_t *h, int32_t n_slots, void *stream) {
         if (v >= 1 && v <= 2 * ncu) h->wg_slots = v;
     }
     h->vt_cap = (int)vt_cap;
+    h->perm2d_off = perm_dense;
     k_version_copy<<<256, 256, 0, s>>>(h->pi_d, h->vslab, h->vstride, h->vs_d, h->vstride / 4);
     h->steps_since_install = 1ll << 40;
     h->plan_fresh = false;
@@ -2549,6 +2554,7 @@ ddrl_actor_rollout_view ddrl_actor_internal_view(ddrl_actor *h) {
     v.vbmu = h->n_slots ? h->vslab + h->Ld.pi_bmu : nullptr; v.vbls = h->n_slots ? h->vslab + h->Ld.pi_bls : nullptr;
     v.steps_since_install = &h->steps_since_install;
     v.plan_fresh = &h->plan_fresh;
+    v.vcnt = h->vcnt_d; v.perm = h->perm_d; v.perm2d_off = h->perm2d_off; v.vtiles = h->vtiles_d; v.vt_cap = h->vt_cap; v.wg_slots = h->wg_slots;
     v.obs_dim = h->cfg.obs_dim; v.act = h->cfg.act_dim; v.nt2 = (h->cfg.hidden2 + 31) / 32; v.max_rows = h->max_rows;
     v.scale = (float)h->cfg.act_scale; v.device = h->device;
     return v;
