@@ -46,48 +46,55 @@ def _grads_close(g, g64, g32):
     assert (err > 2e-4 * gmax).mean() <= 1e-2 and err.max() <= 5e-3 * gmax, (err.max() / gmax, err32 / gmax, (err > 2e-4 * gmax).mean())
 
 
-def _ddqn_flip_variants(params, b, cfg, lr, max_cands=4):
-    """A relu pre-activation of the differentiated network that is ZERO within float32 rounding has no defined sign in float32: an
+def _flip_variants(params, b, cfg, lr, nets, backup, max_cands=4, with_unflipped=False):
+    """A relu pre-activation of a differentiated network that is ZERO within float32 rounding has no defined sign in float32: an
     implementation that sums its terms in another order than torch may mask that unit for that batch row where the float64 oracle does
     not (or the other way round).  The forward value moves by ~0, but the gradient moves by that row's whole contribution — a rank-one
-    change of every weight gradient below it, which at wide observations is a sizeable fraction of ALL elements (what the plain bars
-    of _grads_close / _params_close do not allow for).  This returns, for every non-empty subset of the (at most max_cands) entries
-    whose |z| <= 2^-19 sum|terms|, the float64 gradient and first-step parameters / targets of the Double-DQN update
-    (algos/dqn/actor_learner.py:40-74) with those masks inverted: a float32 result is right if it matches ONE of them."""
+    change of every weight gradient below it, which at wide observations is a sizeable fraction of ALL elements and at small batches a
+    sizeable fraction of the largest element (what the plain bars of _grads_close / _params_close do not allow for).  This returns, for
+    every non-empty subset of the (at most max_cands) entries whose |z| <= 2^-19 sum|terms|, the float64 gradient and first-step
+    parameters / targets of the update with those masks inverted — Double-DQN (algos/dqn/actor_learner.py:40-74: nets = ["main/q1"])
+    or soft-Q (algos/sqn/actor_learner.py:19-78: the twin networks ["main/q1", "main/q2"], each regressed on the same detached
+    `backup`): a float32 result is right if it matches ONE of them."""
     import itertools
-    f = lambda k: np.asarray(params["main/q1/" + k], np.float64)
-    W1, b1, W2, b2, W3, b3 = f("dense/kernel"), f("dense/bias"), f("dense_1/kernel"), f("dense_1/bias"), f("dense_2/kernel"), f("dense_2/bias")
-    x, x2 = b["obs1"].astype(np.float64), b["obs2"].astype(np.float64)
-    a, r, d = b["acts"].astype(np.int64), b["rews"].astype(np.float64), b["done"].astype(np.float64)
+    x = b["obs1"].astype(np.float64)
+    a = b["acts"].astype(np.int64)
     B = x.shape[0]
-
-    def net(xx):
-        z1 = xx @ W1 + b1
+    backup = np.asarray(backup, np.float64)
+    per_net, cands = [], []
+    for ni, pre in enumerate(nets):
+        f = lambda k: np.asarray(params[pre + "/" + k], np.float64)
+        W1, b1, W2, b2, W3, b3 = f("dense/kernel"), f("dense/bias"), f("dense_1/kernel"), f("dense_1/bias"), f("dense_2/kernel"), f("dense_2/bias")
+        z1 = x @ W1 + b1
         h1 = np.maximum(z1, 0)
         z2 = h1 @ W2 + b2
-        return z1, h1, z2, np.maximum(z2, 0) @ W3 + b3
-    z1, h1, z2, q = net(x)
-    qx2 = net(x2)[3]                                     # target == main right after set_weights (target_init)
-    backup = r + cfg.gamma * (1.0 - d) * qx2[np.arange(B), qx2.argmax(1)]
-    dq = np.zeros_like(q)
-    dq[np.arange(B), a] = (q[np.arange(B), a] - backup) / B
-    s1 = np.abs(x) @ np.abs(W1) + np.abs(b1)
-    s2 = np.abs(h1) @ np.abs(W2) + np.abs(b2)
-    cands = [(1, i, j) for i, j in zip(*np.where(np.abs(z1) <= 2.0 ** -19 * s1))] + [(2, i, j) for i, j in zip(*np.where(np.abs(z2) <= 2.0 ** -19 * s2))]
-    if not cands or len(cands) > max_cands:
+        q = np.maximum(z2, 0) @ W3 + b3
+        dq = np.zeros_like(q)
+        dq[np.arange(B), a] = (q[np.arange(B), a] - backup) / B
+        s1 = np.abs(x) @ np.abs(W1) + np.abs(b1)
+        s2 = np.abs(h1) @ np.abs(W2) + np.abs(b2)
+        cands += [(ni, 1, i, j) for i, j in zip(*np.where(np.abs(z1) <= 2.0 ** -19 * s1))] + [(ni, 2, i, j) for i, j in zip(*np.where(np.abs(z2) <= 2.0 ** -19 * s2))]
+        per_net.append((W1, b1, W2, b2, W3, b3, z1, z2, dq))
+    if with_unflipped:     # (tests/test_oracle_math_fixtures.py: the helper's own math against the oracles, no inversion)
+        cands = cands[:max_cands]
+    elif not cands or len(cands) > max_cands:
         return []
     out = []
-    for k in range(1, len(cands) + 1):
+    for k in range(0 if with_unflipped else 1, len(cands) + 1):
         for sub in itertools.combinations(cands, k):
-            m1, m2 = z1 > 0, z2 > 0
-            for layer, i, j in sub:
-                (m1 if layer == 1 else m2)[i, j] ^= True
-            hh1 = z1 * m1
-            hh2 = (hh1 @ W2 + b2) * m2
-            dz2 = (dq @ W3.T) * m2
-            dz1 = (dz2 @ W2.T) * m1
-            g = np.concatenate([(x.T @ dz1).ravel(), dz1.sum(0), (hh1.T @ dz2).ravel(), dz2.sum(0), (hh2.T @ dq).ravel(), dq.sum(0)])
-            p0 = np.concatenate([v.ravel() for v in (W1, b1, W2, b2, W3, b3)])
+            gs, ps = [], []
+            for ni, (W1, b1, W2, b2, W3, b3, z1, z2, dq) in enumerate(per_net):
+                m1, m2 = z1 > 0, z2 > 0
+                for nj, layer, i, j in sub:
+                    if nj == ni:
+                        (m1 if layer == 1 else m2)[i, j] ^= True
+                hh1 = z1 * m1
+                hh2 = (hh1 @ W2 + b2) * m2
+                dz2 = (dq @ W3.T) * m2
+                dz1 = (dz2 @ W2.T) * m1
+                gs += [(x.T @ dz1).ravel(), dz1.sum(0), (hh1.T @ dz2).ravel(), dz2.sum(0), (hh2.T @ dq).ravel(), dq.sum(0)]
+                ps += [v.ravel() for v in (W1, b1, W2, b2, W3, b3)]
+            g, p0 = np.concatenate(gs), np.concatenate(ps)
             main = p0 - lr * g / (np.abs(g) + cfg.adam_eps / np.sqrt(1.0 - cfg.beta2))
             out.append((sub, g, main, cfg.polyak * p0 + (1.0 - cfg.polyak) * main))
     return out
@@ -194,10 +201,9 @@ def test_dqn_random_shape_first_update(ddrl, obs, acts, hid, batch, variant):
         # a relu pre-activation at zero within float32 rounding?  Then the gradient must equal the float64 one under SOME sign
         # assignment of those entries (found by seeds 21 / 23: obs 2560 hidden (68, 340) batch 195 and obs 2398 hidden (280, 240)
         # batch 192 — round 5's library gives the same gradients there)
-        if sqn:
-            raise
+        # (seed 31: soft-Q, obs 44 hidden (73, 176): one layer-1 unit of one batch row — 44 + 1 elements, 2 % of the largest one)
         main, targ = learner.export(_lib.SAC1_MAIN).cpu().numpy(), learner.export(_lib.SAC1_TARGET).cpu().numpy()
-        for sub, g_alt, main_alt, targ_alt in _ddqn_flip_variants(params, b, cfg, cfg.lr):
+        for sub, g_alt, main_alt, targ_alt in _flip_variants(params, b, cfg, cfg.lr, ["main/q1", "main/q2"] if sqn else ["main/q1"], w["q_backup"].numpy()):
             okg = np.abs(g - g_alt) <= 1e-3 * np.abs(g_alt)
             if np.abs(g - g_alt).max() <= 2e-4 * np.abs(g_alt).max() and okg.mean() >= 0.97 and \
                     np.abs(main - main_alt)[okg].max() <= 2e-2 * cfg.lr and np.abs(targ - targ_alt)[okg].max() <= 2e-2 * cfg.lr:

@@ -165,3 +165,30 @@ def test_fixtures_regenerate_identically_from_the_reference(tmp_path):
             assert np.array_equal(a[k], b[k]), (fam, k)
         with open(os.path.join(GOLD, fam + "_math.json")) as f, open(os.path.join(str(tmp_path), fam + "_math.json")) as g2:
             assert json.load(f) == json.load(g2)
+
+
+@pytest.mark.parametrize("sqn", [False, True])
+def test_relu_sign_variants_of_the_fuzz_test_are_the_oracles_own_math(sqn):
+    """tests/test_gpu_fuzz_shapes.py accepts a HIP gradient that equals the float64 one under ANOTHER sign assignment of the relu
+    pre-activations that are zero within float32 rounding (_flip_variants: its own NumPy restatement of the Double-DQN / soft-Q
+    gradient and first Adam step).  That restatement with NO sign inverted must be the float64 oracle's result, and inverting one mask
+    entry must change exactly the gradient elements below that unit."""
+    from test_gpu_fuzz_shapes import _flip_variants
+    cfg = dq.Config(obs_dim=44, n_actions=2, hidden1=73, hidden2=176, batch=37)
+    params = (dq.sqn_init_params if sqn else dq.init_params)(cfg, 2)
+    rs = np.random.RandomState(3)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = rs.uniform(-0.1, 0.1, params[k].shape).astype(np.float32)
+    o64 = dq.SqnOracle(cfg, params, 0.1, torch.float64) if sqn else dq.DqnOracle(cfg, params, torch.float64)
+    b = dq.synthetic_batch(cfg, 10)
+    w = o64.step(b)
+    nets = ["main/q1", "main/q2"] if sqn else ["main/q1"]
+    # (a threshold of 2^-19 finds no candidate on this draw: hand the helper the entry closest to zero by scaling nothing — the
+    # unflipped form is returned first whatever the candidates are)
+    out = _flip_variants(params, b, cfg, cfg.lr, nets, w["q_backup"].numpy(), max_cands=0, with_unflipped=True)
+    assert len(out) == 1 and out[0][0] == ()
+    _, g, main, targ = out[0]
+    np.testing.assert_allclose(g, o64.flat("grads"), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(main, o64.flat("main"), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(targ, o64.flat("target"), rtol=0, atol=1e-12)
