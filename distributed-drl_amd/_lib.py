@@ -60,6 +60,7 @@ SIGNATURES = {
     "ddrl_version": (c_int, []),
     "ddrl_last_error": (c_char_p, []),
     "ddrl_device_arch": (c_int, [c_int, c_char_p, c_int]),
+    "ddrl_host_device_pointer": (c_int, [_P, ctypes.POINTER(ctypes.c_void_p)]),
     "ddrl_replay_create": (c_int, [POINTER(_P), c_int, c_int64, c_int, c_int, c_uint32]),
     "ddrl_replay_destroy": (c_int, [_P]),
     "ddrl_replay_seed": (c_int, [_P, c_uint32, _P]),

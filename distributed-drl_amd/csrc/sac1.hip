@@ -782,6 +782,8 @@ struct ddrl_sac1 {
 
 static void refresh_shadows(ddrl_sac1 *h, hipStream_t s);
 int ddrl_internal_normal_fill_ctr(float *out_d, int64_t n, uint32_t seed, const uint32_t *ctr_d, uint64_t base, void *stream);   // common.hip
+int ddrl_internal_host_block_up(const float *src, float *dst_d, int64_t n, float *e0, float *e1, float *e2, int64_t m, uint32_t seed,
+                                const uint32_t *ctr, void *stream);                                                              // common.hip
 
 static int sac1_free(ddrl_sac1 *h) {
     for (auto &g : h->host_graphs) (void)hipGraphExecDestroy(g.exec);
@@ -1891,7 +1893,25 @@ int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32
     tail[0] = (uint32_t)noise_ctr; tail[1] = (uint32_t)(noise_ctr >> 32);
     if (!h->host_ctr_d) DDRL_HIP_CHECK(hipMalloc((void **)&h->host_ctr_d, 2 * sizeof(uint32_t)));
     const bool eps_contig = in0[6] - in0[5] == m && in0[7] - in0[6] == m;
+    // a page-locked block is read by the device itself (one launch: batch up + noise); pageable memory goes through copies
+    const float *block_dev = nullptr;
+    bool resolved = false;
+    auto resolve = [&]() {   // (not on the replay path: a recorded graph holds the address)
+        if (resolved) return;
+        resolved = true;
+        hipPointerAttribute_t pa{};
+        if (hipPointerGetAttributes(&pa, block_h) == hipSuccess && pa.type == hipMemoryTypeHost && pa.devicePointer != nullptr)
+            block_dev = static_cast<const float *>(pa.devicePointer);
+        else (void)hipGetLastError();
+    };
     auto issue = [&]() -> int {
+        resolve();
+        if (block_dev) {
+            const int rc = ddrl_internal_host_block_up(block_dev, in0[0], n_floats, in0[5], in0[6], in0[7], m, noise_seed,
+                                                       reinterpret_cast<const uint32_t *>(block_dev + n_floats), stream);
+            if (rc != DDRL_OK) return rc;
+            return ddrl_sac1_step(h, in0[0], in0[1], in0[2], in0[3], in0[4], in0[5], in0[6], in0[7], losses_d, nullptr, nullptr, nullptr, stream);
+        }
         DDRL_HIP_CHECK(hipMemcpyAsync(in0[0], block_h, (size_t)n_floats * sizeof(float), hipMemcpyHostToDevice, s));
         DDRL_HIP_CHECK(hipMemcpyAsync(h->host_ctr_d, tail, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         int rc = DDRL_OK;
@@ -1913,11 +1933,8 @@ int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32
             return DDRL_OK;
         }
     if (h->host_graphs.size() >= 16) return issue();   // (a caller that keeps changing blocks: eager)
-    hipPointerAttribute_t pa{};
-    if (hipPointerGetAttributes(&pa, block_h) != hipSuccess || pa.type != hipMemoryTypeHost) {
-        (void)hipGetLastError();
-        return issue();                                // pageable memory: the copies are not capturable
-    }
+    resolve();
+    if (!block_dev) return issue();                    // pageable memory: the copies are not capturable
     ddrl_sac1::HostGraph hg{block_h, losses_d, noise_seed, h->opt_cur, h->sh_cur, nullptr};
     hipGraph_t graph = nullptr;
     // the recorded launches advance the host-side launch state without running: kept if the graph then runs once, put back if not

@@ -180,13 +180,21 @@ class Learner:
         st = getattr(self, "_stage_q", None)
         if st is None:
             hi, ho = torch.empty(1, self.cfg.obs_dim, dtype=torch.float32).pin_memory(), torch.empty(1, self.cfg.n_actions, dtype=torch.float32).pin_memory()
-            st = self._stage_q = (hi, hi.numpy(), torch.empty(1, self.cfg.obs_dim, dtype=torch.float32, device=self.device),
-                                  ho, ho.numpy(), torch.empty(1, self.cfg.n_actions, dtype=torch.float32, device=self.device))
-        hi, hiv, di, ho, hov, do = st
+            # the q row is written straight into its page-locked row (device-side address), and a narrow observation is read straight
+            # out of its own; pixel observations (the LDS-DMA layer-1 tiles) go up with a copy first
+            po, pi = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(self._lib.ddrl_host_device_pointer(ctypes.c_void_p(ho.data_ptr()), ctypes.byref(po)))
+            di = None
+            if self.cfg.obs_dim < 1024:
+                _lib.check(self._lib.ddrl_host_device_pointer(ctypes.c_void_p(hi.data_ptr()), ctypes.byref(pi)))
+            else:
+                di = torch.empty(1, self.cfg.obs_dim, dtype=torch.float32, device=self.device)
+            st = self._stage_q = (hi, hi.numpy(), di, pi, ho.numpy(), po, ho)
+        hi, hiv, di, pi, hov, po, _ = st
         hiv[0, :] = np.asarray(o, np.float32).reshape(-1)
-        di.copy_(hi, non_blocking=True)
-        _lib.check(self._lib.ddrl_dqn_q(self._h, _lib.dptr(di), 1, _lib.dptr(do), _lib.stream_ptr()))
-        ho.copy_(do, non_blocking=True)
+        if di is not None:
+            di.copy_(hi, non_blocking=True)
+        _lib.check(self._lib.ddrl_dqn_q(self._h, pi if di is None else _lib.dptr(di), 1, po, _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()
         return hov[0]
 

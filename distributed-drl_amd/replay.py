@@ -57,23 +57,37 @@ class ReplayBuffer:
     def store(self, obs, act, rew, next_obs, done, worker_index=None):
         """One transition (example/dsac.py:29-37).  Values are cast to float32 exactly as the
         NumPy row assignment does (float64 -> f32 round-to-nearest, bool -> 0.0/1.0)."""
-        # the five values cross PCIe as ONE block out of a page-locked staging row (five pageable copies were 5 x ~18 us of the
-        # call); the copy is synchronous, so the row is free again when store() returns
+        # the store launch reads the five values straight out of a page-locked staging row (its device-side address: no copy up, no
+        # wait) — one of a ring of rows, each free again once the launch that read it is done (an event per row, looked at when the
+        # ring comes round)
         st = getattr(self, "_stage1", None)
-        if st is None:
-            w = 2 * self.obs_dim + self.act_dim + 2
-            host = torch.empty(w, dtype=torch.float32).pin_memory()
-            st = self._stage1 = (host, host.numpy(), torch.empty(w, dtype=torch.float32, device=self.device))
-        host, hv, dev = st
         o, a = self.obs_dim, self.act_dim
+        if st is None:
+            w, R = (2 * o + a + 2 + 15) // 16 * 16, 64
+            host = torch.empty(R * w, dtype=torch.float32).pin_memory()
+            dp = ctypes.c_void_p()
+            _lib.check(self._lib.ddrl_host_device_pointer(ctypes.c_void_p(host.data_ptr()), ctypes.byref(dp)))
+            rows = []
+            for r in range(R):
+                base = dp.value + 4 * r * w
+                rows.append((host.numpy()[r * w:(r + 1) * w], [ctypes.c_void_p(base + 4 * k) for k in (0, o, o + a, o + a + 1, 2 * o + a + 1)]))
+            st = self._stage1 = {"host": host, "rows": rows, "ev": [None] * R, "turn": 0}
+        t = st["turn"]
+        st["turn"] = (t + 1) % len(st["rows"])
+        if st["ev"][t] is not None:
+            st["ev"][t].synchronize()
+        else:
+            st["ev"][t] = torch.cuda.Event()
+        hv, p = st["rows"][t]
         hv[0:o] = np.asarray(obs, dtype=np.float32).reshape(o)
         hv[o:o + a] = np.asarray(act, dtype=np.float32).reshape(a)
         hv[o + a] = np.asarray(rew, dtype=np.float32).reshape(())
         hv[o + a + 1:2 * o + a + 1] = np.asarray(next_obs, dtype=np.float32).reshape(o)
         hv[2 * o + a + 1] = np.asarray(done, dtype=np.float32).reshape(())
-        dev.copy_(host)
-        self.store_batch(dev[0:o].view(1, o), dev[o:o + a].view(1, a), dev[o + a:o + a + 1], dev[o + a + 1:2 * o + a + 1].view(1, o),
-                         dev[2 * o + a + 1:2 * o + a + 2])
+        self._pf_order_store(True)
+        _lib.check(self._lib.ddrl_replay_store(self._h, p[0], p[1], p[2], p[3], p[4], 1, _lib.stream_ptr()))   # (obs, act, rew, next_obs, done)
+        self._pf_order_store(False)
+        st["ev"][t].record()
 
     def store_batch(self, obs, act, rew, next_obs, done):
         """n sequential store() calls in row order (device tensors, float32)."""
@@ -115,7 +129,6 @@ class ReplayBuffer:
         offs = [0]
         for n in (B * o, B * o, B * a, B, B):
             offs.append((offs[-1] + n + 3) & ~3)
-        dev = [torch.empty(offs[5], dtype=torch.float32, device=self.device) for _ in range(depth)]
         host = [torch.empty(offs[5], dtype=torch.float32).pin_memory() for _ in range(depth)]
         views = []
         for h in host:
@@ -123,32 +136,50 @@ class ReplayBuffer:
             views.append(dict(obs1=v[offs[0]:offs[0] + B * o].reshape(B, o), obs2=v[offs[1]:offs[1] + B * o].reshape(B, o),
                               acts=v[offs[2]:offs[2] + B * a] if self._acts_1d else v[offs[2]:offs[2] + B * a].reshape(B, a),
                               rews=v[offs[3]:offs[3] + B], done=v[offs[4]:offs[4] + B]))
-        ptrs = [[d.data_ptr() + 4 * offs[j] for j in range(5)] for d in dev]
+        # the gather writes straight into the page-locked blocks (their device-side addresses: posted PCIe writes, no copy launch
+        # behind the gather, no device staging buffers) — rows of megabytes (config 5) keep a device block and a copy down
+        direct = B * o < (1 << 18)
+        dev = None if direct else [torch.empty(offs[5], dtype=torch.float32, device=self.device) for _ in range(depth)]
+        ptrs = []
+        for i in range(depth):
+            if direct:
+                dp = ctypes.c_void_p()
+                _lib.check(self._lib.ddrl_host_device_pointer(ctypes.c_void_p(host[i].data_ptr()), ctypes.byref(dp)))
+                base = dp.value
+            else:
+                base = dev[i].data_ptr()
+            ptrs.append([ctypes.c_void_p(base + 4 * offs[j]) for j in range(5)])
         side = torch.cuda.Stream() if own_stream else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())    # what the caller has stored so far is in the ring
         self._pf = dict(B=B, depth=depth, hold=hold, dev=dev, host=host, views=views, ptrs=ptrs, ev=[torch.cuda.Event() for _ in range(depth)], head=0,
-                        stream=side, store_ev=None, draw_ev=None)
+                        stream=side, sptr=None if side is None else ctypes.c_void_p(side.cuda_stream), store_ev=None, draw_ev=None)
         for i in range(depth - hold):
             self._pf_enqueue(i)
 
     def _pf_enqueue(self, i):
         pf = self._pf
         p = pf["ptrs"][i]
-        if pf["stream"] is None:
+        side = pf["stream"]
+        if side is None:
             _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
-            pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
+            if pf["dev"] is not None:
+                pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
             pf["ev"][i].record()
             return
-        with torch.cuda.stream(pf["stream"]):
-            if pf["store_ev"] is not None:
-                pf["stream"].wait_event(pf["store_ev"])      # the caller's last store has landed
-                pf["store_ev"] = None
-            _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
-            pf["draw_ev"] = torch.cuda.Event()
-            pf["draw_ev"].record()                           # (a store behind this draw must not overwrite rows it is still gathering)
+        if pf["store_ev"] is not None:
+            side.wait_event(pf["store_ev"])                  # the caller's last store has landed
+            pf["store_ev"] = None
+        _lib.check(self._lib.ddrl_replay_sample(self._h, pf["B"], p[0], p[1], p[2], p[3], p[4], None, pf["sptr"]))
+        if pf["dev"] is None:
+            pf["ev"][i].record(side)
+            pf["draw_ev"] = pf["ev"][i]                      # (a store behind this draw must not overwrite rows it is still gathering)
+            return
+        pf["draw_ev"] = torch.cuda.Event()
+        pf["draw_ev"].record(side)
+        with torch.cuda.stream(side):
             pf["host"][i].copy_(pf["dev"][i], non_blocking=True)
-            pf["ev"][i].record()
+        pf["ev"][i].record(side)
 
     def _pf_order_store(self, before):
         """own-stream prefetch: a store waits for the draws in flight (before=True), and leaves an event the next draw waits for."""
@@ -164,7 +195,8 @@ class ReplayBuffer:
 
     def sample_batch(self, batch_size=None):
         """dict(obs1, obs2, acts, rews, done) of fresh float32 NumPy arrays (example/dsac.py:39-45).
-        Raises ValueError("high <= 0") on an empty buffer like the reference."""
+        Raises ValueError("high <= 0") on an empty buffer like the reference.  One call at a time per buffer object (a Ray actor's calls
+        are serial, and so are those of remote.py's actor threads): the batch passes through a page-locked block the object owns."""
         pf = getattr(self, "_pf", None)
         if pf is not None and pf["B"] == int(self._default_batch if batch_size is None else batch_size):
             i, D = pf["head"], pf["depth"]
@@ -182,12 +214,20 @@ class ReplayBuffer:
         offs = [0]
         for n in (B * o, B * o, B * a, B, B):
             offs.append((offs[-1] + n + 3) & ~3)               # every piece 16-byte aligned
-        flat = torch.empty(offs[5], dtype=torch.float32, device=self.device)
-        p = [flat.data_ptr() + 4 * offs[j] for j in range(5)]
+        # ... gathered straight into a page-locked block of this buffer (its device-side address: no device staging block, no copy
+        # launch), of which the caller gets a fresh copy: 38 -> ~20 us per call
+        st = self.__dict__.setdefault("_plain_host", {}).get(B)
+        if st is None:
+            host = torch.empty(offs[5], dtype=torch.float32).pin_memory()
+            dp = ctypes.c_void_p()
+            _lib.check(self._lib.ddrl_host_device_pointer(ctypes.c_void_p(host.data_ptr()), ctypes.byref(dp)))
+            st = self._plain_host[B] = (host, host.numpy(), [ctypes.c_void_p(dp.value + 4 * offs[j]) for j in range(5)])
+        p = st[2]
         self._pf_order_store(True)       # (a draw of another size while a prefetch is on: behind the draws in flight, in front of the next)
         _lib.check(self._lib.ddrl_replay_sample(self._h, B, p[0], p[1], p[2], p[3], p[4], None, _lib.stream_ptr()))
         self._pf_order_store(False)
-        h = flat.cpu().numpy()
+        torch.cuda.current_stream().synchronize()
+        h = st[1].copy()
         return dict(obs1=h[offs[0]:offs[0] + B * o].reshape(B, o), obs2=h[offs[1]:offs[1] + B * o].reshape(B, o),
                     acts=h[offs[2]:offs[2] + B * a] if self._acts_1d else h[offs[2]:offs[2] + B * a].reshape(B, a),
                     rews=h[offs[3]:offs[3] + B], done=h[offs[4]:offs[4] + B])

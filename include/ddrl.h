@@ -48,6 +48,11 @@ int ddrl_version(void);
 const char *ddrl_last_error(void);
 /* Name of the device the library sees as `device` ("gfx950…"), for fail-loud checks. host buf. */
 int ddrl_device_arch(int device, char *buf_h, int buflen);
+/* The address under which the DEVICE sees a page-locked host buffer (hipHostMalloc / hipHostRegister memory: what torch's pin_memory()
+ * hands out) — usable wherever this header takes a device pointer for small, latency-bound transfers: ddrl_replay_sample then gathers a
+ * batch straight into the caller's host block (posted PCIe writes, no copy behind the launch), as ReplayBuffer.prefetch does for the
+ * reference's host-array surface (example/dsac.py:39-45).  DDRL_ERR_BAD_ARG for pageable memory. */
+int ddrl_host_device_pointer(const void *host_ptr, void **dev_ptr_out);
 
 /* ===================================================================================== */
 /* Replay ring buffer — replaces class ReplayBuffer                                       */
@@ -290,11 +295,13 @@ int ddrl_sac1_compute_grads_and_sample(ddrl_sac1_t *h, int set_in, ddrl_replay_t
  * algos/sac1/sac1.py:146-148 — as one call: block_h (page-locked host memory; n_floats floats) holds obs1, obs2, acts, rews, done at
  * the offsets the five buffers of ddrl_sac1_input_buffers(h, 0, .) have from the first one (DDRL_ERR_BAD_ARG if those do not form one
  * span; where an item is allocated with more rows than the batch — the direct path pads to whole 32-row tiles — the block must hold
- * zeros there); it goes up with one asynchronous copy, eps_x / eps_x2 / eps_t are generated in place exactly as three ddrl_normal_fill calls
- * at noise_ctr, noise_ctr + B*act, noise_ctr + 2*B*act would, then one ddrl_sac1_step on that set.  The block must have room for TWO
- * more floats behind the n_floats: the call writes the noise counter there and the device reads it from there — which is what lets
- * the whole sequence (two copies, noise, the update's launches) replay as ONE captured graph per (block, state-copy parity) from the
- * second use of a block on: on this surface the host's launch calls, not the device, set the rate (DDRL_HOST_GRAPH=0: always eager).
+ * zeros there); the first launch of the call reads it straight over PCIe into the input set (page-locked memory is device-addressable:
+ * no copy node; pageable memory goes through copies and is never captured), eps_x / eps_x2 / eps_t are generated by the same launch
+ * exactly as three ddrl_normal_fill calls at noise_ctr, noise_ctr + B*act, noise_ctr + 2*B*act would, then one ddrl_sac1_step on that
+ * set.  The block must have room for TWO more floats behind the n_floats: the call writes the noise counter there and the device reads
+ * it from there — which is what lets the whole sequence (batch up + noise, the update's launches) replay as ONE captured graph of
+ * kernel launches per (block, state-copy parity) from the second use of a block on: on this surface the host's launch calls, not the
+ * device, set the rate (DDRL_HOST_GRAPH=0: always eager).  The block must stay untouched until the work issued by the call has run.
  * The block may be rewritten once work queued on `stream` behind this call has started (record an event after the call and wait for
  * it). */
 int ddrl_sac1_step_host(ddrl_sac1_t *h, float *block_h, int64_t n_floats, uint32_t noise_seed, uint64_t noise_ctr, float *losses_d,
