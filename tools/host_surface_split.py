@@ -1,3 +1,5 @@
+"""Where the host-buffer loop train(sample_batch()) spends its time: the train side alone (a fixed host batch), the sample side alone (prefetch on the
+buffer's own stream), both, and a cProfile of the loop.  python tools/host_surface_split.py   (profiles/r06_host_surface.txt)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,7 +21,6 @@ b = {k: v.copy() for k, v in rb.sample_batch(256).items()}
 print("train(fixed host batch) only: %.1f us" % timed(lambda: L.train(b)))
 print("sample_batch (prefetch own stream) only: %.1f us" % timed(lambda: rb.sample_batch(256)))
 print("both: %.1f us" % timed(lambda: L.train(rb.sample_batch(256))))
-os.environ["X"] = "1"
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(2000): L.train(rb.sample_batch(256))

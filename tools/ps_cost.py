@@ -1,3 +1,4 @@
+"""Host cost of the parameter-server calls with NumPy values (example/dsac.py:59-65): get_weights, push, pull, set_weights.  python tools/ps_cost.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
