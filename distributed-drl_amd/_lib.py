@@ -125,6 +125,7 @@ SIGNATURES = {
     "ddrl_actor_set_weights": (c_int, [_P, _P, _P]),
     "ddrl_actor_get_weights": (c_int, [_P, _P, _P]),
     "ddrl_actor_act": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P]),
+    "ddrl_actor_act_one": (c_int, [_P, _P, c_uint32, c_uint64, c_int, _P, _P]),
     "ddrl_env_create": (c_int, [POINTER(_P), c_int, c_int64, c_uint32, c_int32]),
     "ddrl_env_destroy": (c_int, [_P]),
     "ddrl_env_reset": (c_int, [_P, _P, _P, _P]),

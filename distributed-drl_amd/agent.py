@@ -598,6 +598,18 @@ class Actor(_Net):
         hi, hiv, pi, ho, hov, po = st
         hiv[0, :] = np.asarray(o, np.float32).reshape(-1)
         a = self.cfg.act_dim
+        if getattr(self, "_act_one", True):
+            # ONE launch for the one row (ddrl_actor_act_one: both layers, the head, the squash, the noise elements from the counter — the
+            # same stream positions _normal(a) would consume); the batched kernels behind a noise launch are a chain of four
+            rc = self._lib.ddrl_actor_act_one(self._h, pi, self._noise_seed, self._noise_ctr, 1 if deterministic else 0, po, _lib.stream_ptr())
+            if rc == _lib.DDRL_ERR_UNSUPPORTED:
+                self._act_one = False
+            else:
+                _lib.check(rc)
+                if not deterministic:
+                    self._noise_ctr += a
+                torch.cuda.current_stream().synchronize()
+                return hov[0].copy()
         e = None if deterministic else self._normal(a)
         _lib.check(self._lib.ddrl_actor_act(self._h, pi, _lib.dptr(e), 1, 1 if deterministic else 0, po, _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()

@@ -605,6 +605,100 @@ __global__ void __launch_bounds__(256) k_rows_act(ActArgs a) {
     if (lane < a.act) a.act_out[r * a.act + lane] = o.act;
 }
 
+// get_action of ONE observation as one launch: every workgroup computes layer 1 (a few thousand products) and ITS 16 columns of layer 2
+// — 256 threads = 16 columns x 16 slices of the contraction, combined in slice order — and leaves the head's partial sums of those
+// columns; the last workgroup to finish (ticket) adds the partials in workgroup order, takes the noise elements from the counter
+// (== ddrl_normal_fill) and squashes (ddrl_pol::policy_row).  One workgroup alone pulls layer 2's 480 KB through one CU (~25 us);
+// the batched path is three launches behind a noise launch — a chain of four for one row, which is what a reference-style
+// rollout worker pays per env step (actor_learner.py:195-197; example/dsac.py:96).
+constexpr int A1_COLS = 16;
+struct ActOneArgs {
+    const float *obs;
+    NetPi pi;
+    float *act_out;
+    float *part;             // [workgroups][16]: head partial sums (mu 0..act-1, log_std act..2act-1)
+    unsigned int *ticket;
+    int d0, h1, h2, act, deterministic;
+    float scale;
+    uint32_t seed;
+    unsigned long long ctr;
+};
+__global__ void __launch_bounds__(256) k_act_one(ActOneArgs a) {
+    __shared__ float xs[64];
+    __shared__ float h1s[512];
+    __shared__ float ps[16][A1_COLS + 1];
+    __shared__ float v2[A1_COLS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    if (tid < a.d0) xs[tid] = a.obs[tid];
+    __syncthreads();
+    for (int j = tid; j < a.h1; j += 256) {
+        float acc = a.pi.b1[j];
+        for (int d = 0; d < a.d0; ++d) acc += xs[d] * a.pi.W1[(long long)d * a.h1 + j];
+        h1s[j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    const int col = tid & (A1_COLS - 1), slice = tid >> 4, c = blockIdx.x * A1_COLS + col;
+    const int per = (a.h1 + 15) >> 4, k0 = slice * per, k1 = k0 + per < a.h1 ? k0 + per : a.h1;
+    float acc = 0.f;
+    if (c < a.h2) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {   // eight loads in flight, one chain of additions (k order)
+            float w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = a.pi.W2[(long long)(k + q) * a.h2 + c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += h1s[k + q] * w[q];
+        }
+        for (; k < k1; ++k) acc += h1s[k] * a.pi.W2[(long long)k * a.h2 + c];
+    }
+    ps[slice][col] = acc;
+    __syncthreads();
+    if (tid < A1_COLS) {
+        const int cc = blockIdx.x * A1_COLS + tid;
+        float sum = 0.f;
+        if (cc < a.h2) {
+            sum = a.pi.b2[cc];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += ps[q][tid];
+            sum = fmaxf(sum, 0.f);
+        }
+        v2[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 2 * a.act) {   // head partials of this workgroup's columns: outputs 0..act-1 mu, act..2act-1 log_std
+        const float *W = tid < a.act ? a.pi.Wmu : a.pi.Wls;
+        const int o = tid < a.act ? tid : tid - a.act;
+        float sum = 0.f;
+        for (int q = 0; q < A1_COLS; ++q) {
+            const int cc = blockIdx.x * A1_COLS + q;
+            if (cc < a.h2) sum += v2[q] * W[(long long)cc * a.act + o];
+        }
+        a.part[blockIdx.x * 16 + tid] = sum;
+    }
+    __threadfence();   // the partials are out before the ticket (this launch has written nothing else)
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, ls[4] = {0.f, 0.f, 0.f, 0.f}, ev[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < a.act; ++o) {
+            float sm = 0.f, sl = 0.f;
+            for (unsigned b = 0; b < gridDim.x; ++b) {   // workgroup order
+                sm += __hip_atomic_load(&a.part[b * 16 + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sl += __hip_atomic_load(&a.part[b * 16 + a.act + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            mu[o] = sm + a.pi.bmu[o]; ls[o] = sl + a.pi.bls[o];
+            ev[o] = a.deterministic ? 0.f : ddrl_pol::normal_at(a.seed, a.ctr + (unsigned long long)o);
+        }
+        const ddrl_pol::PolRow pr = ddrl_pol::policy_row(mu, ls, ev, a.act, a.scale);
+        for (int o = 0; o < a.act; ++o) a.act_out[o] = pr.act[o];
+        *a.ticket = 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: layout
 // ------------------------------------------------------------------------------------------
@@ -2082,6 +2176,7 @@ struct ddrl_actor {
     VerTile *vtiles_d;
     VerState *vs_d;
     int vt_cap;                    // records of the forward's workgroup table (= the versioned forward's grid)
+    float *act1_part;              // ddrl_actor_act_one: head partials + ticket (allocated at the first call)
     int *vcnt_d;                   // envs per slot while an env-step launch counts them; all zero between launches
     long long perm2d_off;          // perm_d: where the env-step launch's [n_slots][max_rows] row lists start
     int wg_slots;                  // resident workgroups of the two-per-CU forward: 2 x CUs (the planning launch sizes the column split for it)
@@ -2308,7 +2403,7 @@ int ddrl_actor_create(ddrl_actor_t **out, int device, const ddrl_sac1_config_t *
         c2.batch = 32;
         h->direct = direct_ok(c2) && max_rows % 32 == 0 && max_rows <= 32 * 4095 && cfg->obs_dim + 1 <= 13;
         h->dslab = nullptr; h->segs_dd = nullptr;
-        h->n_slots = 0; h->vslab = nullptr; h->slot_d = h->perm_d = nullptr; h->vtiles_d = nullptr; h->vs_d = nullptr; h->vcnt_d = nullptr;
+        h->n_slots = 0; h->vslab = nullptr; h->slot_d = h->perm_d = nullptr; h->vtiles_d = nullptr; h->vs_d = nullptr; h->vcnt_d = nullptr; h->act1_part = nullptr;
         h->plan_fresh = false; h->pi_p_stale = false; h->flat_tmp = nullptr;
         h->steps_since_install = 1ll << 40;
     }
@@ -2335,7 +2430,7 @@ int ddrl_actor_destroy(ddrl_actor_t *h) {
     if (!h) return DDRL_OK;
     ddrl::DeviceGuard g(h->device);
     (void)hipFree(h->dslab); (void)hipFree(h->segs_dd); (void)hipFree(h->flat_tmp);
-    (void)hipFree(h->vslab); (void)hipFree(h->slot_d); (void)hipFree(h->perm_d); (void)hipFree(h->vtiles_d); (void)hipFree(h->vs_d); (void)hipFree(h->vcnt_d);
+    (void)hipFree(h->vslab); (void)hipFree(h->slot_d); (void)hipFree(h->perm_d); (void)hipFree(h->vtiles_d); (void)hipFree(h->vs_d); (void)hipFree(h->vcnt_d); (void)hipFree(h->act1_part);
     (void)hipFree(h->pi_p); (void)hipFree(h->H1); (void)hipFree(h->H2); (void)hipFree(h->segs_d);
     delete h;
     return DDRL_OK;
@@ -2500,6 +2595,28 @@ int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int6
     launch_gemm(gj, s);
     ActArgs aa{h->H2, net_pi(h->pi_p, L), eps_d, act_d, (int)n, c.hidden2, h->ldh2, c.act_dim, deterministic, (float)c.act_scale};
     k_rows_act<<<(unsigned)((n + 3) / 4), 256, 0, s>>>(aa);
+    DDRL_LAUNCH_CHECK();
+    return DDRL_OK;
+}
+
+int ddrl_actor_act_one(ddrl_actor_t *h, const float *obs_d, uint32_t noise_seed, uint64_t noise_ctr, int deterministic, float *act_d,
+                       void *stream) {
+    DDRL_REQUIRE(h != nullptr && obs_d != nullptr && act_d != nullptr, "NULL pointer");
+    const ddrl_sac1_config_t &c = h->cfg;
+    if (c.obs_dim > 64 || c.hidden1 > 512 || c.hidden2 > 512 || c.act_dim > 4) {
+        ddrl::set_error("ddrl_actor_act_one: shape outside (obs 64, hidden 512, act 4): use ddrl_actor_act");
+        return DDRL_ERR_UNSUPPORTED;
+    }
+    ddrl::DeviceGuard g(h->device);
+    hipStream_t s = ddrl::as_stream(stream);
+    if (!h->act1_part) {   // head partials of up to 32 workgroups + the ticket
+        hipError_t e = dev_alloc(&h->act1_part, (size_t)32 * 16 + 16);
+        if (e != hipSuccess) { ddrl::set_error("hipMalloc failed in ddrl_actor_act_one: %s", hipGetErrorString(e)); return DDRL_ERR_NOMEM; }
+    }
+    actor_refresh_row_major(h, s);
+    ActOneArgs a{obs_d, net_pi(h->pi_p, h->L), act_d, h->act1_part, reinterpret_cast<unsigned int *>(h->act1_part + 32 * 16),
+                 c.obs_dim, c.hidden1, c.hidden2, c.act_dim, deterministic, (float)c.act_scale, noise_seed, (unsigned long long)noise_ctr};
+    k_act_one<<<(unsigned)((c.hidden2 + A1_COLS - 1) / A1_COLS), 256, 0, s>>>(a);
     DDRL_LAUNCH_CHECK();
     return DDRL_OK;
 }

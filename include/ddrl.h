@@ -400,6 +400,13 @@ int ddrl_actor_get_weights(ddrl_actor_t *h, float *flat_pi_d, void *stream);
  * replaying — a captured call replays "no rebuild" and would act on the weights of the capture. */
 int ddrl_actor_act(ddrl_actor_t *h, const float *obs_d, const float *eps_d, int64_t n,
                    int deterministic, float *act_d, void *stream);
+/* Actor.get_action(o) for ONE observation as one launch (actor_learner.py:195-197, the call a reference-style rollout worker makes
+ * per env step, example/dsac.py:96): the same function as ddrl_actor_act with n = 1 and eps = the act_dim elements ddrl_normal_fill
+ * yields at (noise_seed, noise_ctr) — within float32 summation order of it.  obs_d[obs_dim], act_d[act_dim] (device pointers, or
+ * device-side addresses of page-locked host rows: ddrl_host_device_pointer).  DDRL_ERR_UNSUPPORTED for obs_dim > 64, a hidden
+ * width > 512 or act_dim > 4.  Same threading / capture rules as ddrl_actor_act. */
+int ddrl_actor_act_one(ddrl_actor_t *h, const float *obs_d, uint32_t noise_seed, uint64_t noise_ctr, int deterministic, float *act_d,
+                       void *stream);
 
 /* ===================================================================================== */
 /* Batched lander environment — stands where gym's LunarLanderContinuous-v2 env.step /     */

@@ -890,3 +890,30 @@ def test_reference_style_nstep_rollout_stores_the_deque_windows():
         got = rings[k][:len(want)].cpu().numpy()
         np.testing.assert_array_equal(got, np.stack([w[j] for w in want]).astype(np.float32).reshape(got.shape), err_msg=k)
     assert rb.get_counts() == (0, len(want) * opt.num_buffers, len(want))
+
+
+@pytest.mark.parametrize("hidden,obs,act", [((400, 300), 8, 2), ((64, 512), 11, 1), ((130, 70), 36, 4), ((512, 36), 3, 3), ((7, 9), 1, 1)])
+def test_get_action_as_one_launch_equals_the_batched_kernels(hidden, obs, act):
+    """Actor.get_action(o) (actor_learner.py:195-197) runs as ONE launch (ddrl_actor_act_one: both layers, head, squash, noise from the
+    counter): the same action as get_actions on the row with the noise elements ddrl_normal_fill yields at the same stream position —
+    within float32 summation order — stochastic and deterministic, across a set_weights, and the noise counter advances as before."""
+    from distributed_drl_amd import _lib
+    from distributed_drl_amd.agent import Actor, HyperParameters
+    opt = HyperParameters()
+    opt.hidden_sizes, opt.obs_dim, opt.act_dim, opt.seed = hidden, obs, act, 5
+    a = Actor(opt, max_rows=32)
+    lib = _lib.load()
+    rs = np.random.RandomState(1)
+    for rnd in range(3):
+        if rnd == 1:
+            a._flat_set(torch.from_numpy((0.3 * rs.standard_normal(a.get_weights_flat().numel())).astype(np.float32)).cuda())
+        for det in (False, True):
+            o = rs.randn(obs).astype(np.float32) * 2
+            ctr = a._noise_ctr
+            got = a.get_action(o, deterministic=det)
+            assert a._noise_ctr == ctr + (0 if det else act)
+            eps = torch.zeros(1, act, dtype=torch.float32, device="cuda")
+            _lib.check(lib.ddrl_normal_fill(_lib.dptr(eps), act, a._noise_seed, ctr, _lib.stream_ptr()))
+            want = a.get_actions(torch.from_numpy(o).cuda().reshape(1, -1), deterministic=det, eps=eps)[0].cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg="round %d det %s" % (rnd, det))
+    assert getattr(a, "_act_one", True) is True
