@@ -103,14 +103,14 @@ class ReplayBuffer:
     def prefetch(self, batch_size=None, depth=12, hold=2, own_stream=False):
         """The reference's `Cache` (algos/sac1/sac1.py:103-130: a helper that keeps ten sampled batches waiting so that the learner never
         waits for a sample) INSIDE the buffer: from now on `depth - hold` sample_batch(batch_size) draws are always in flight — index
-        draw, gather and the copy down into page-locked host blocks, queued on the buffer's stream — and sample_batch(batch_size)
+        draw and gather straight into page-locked host blocks, queued on the buffer's stream — and sample_batch(batch_size)
         hands out the oldest one, waiting only if it has not landed yet.  Batches, and their order, are exactly those of the calls
         without prefetch (one sampler, one queue); what changes is WHEN a batch was drawn: up to `depth - hold` calls earlier, so
         transitions stored in between are not in it — the reference's Cache has the same staleness.
         The arrays of a returned batch are views of a ring of host blocks: valid until `hold` further sample_batch calls (copy them to
         keep them longer).  prefetch(0) turns it off.
         own_stream=True: the draws run on a stream of the buffer's own, beside the caller's stream (a learner's update on the same
-        thread then no longer queues behind the gather and its copy down); this object's store / store_batch calls are ordered
+        thread then no longer queues behind the gather); this object's store / store_batch calls are ordered
         against the draws by events, and so are its other calls that move the sampler or the rows (seed, draws of another size,
         sample_batch_device / sample_many, set_rows); the counters get_counts() reads include the draws in flight.  Writers that go
         to the ring BEHIND this object's back on another stream (a RolloutDevice's fused env-step launch stores through the C
