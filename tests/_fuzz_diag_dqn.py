@@ -1,6 +1,6 @@
 """Per-tensor diagnosis of one Double-DQN shape of the fuzz (tests/test_gpu_fuzz_shapes.py): HIP gradient vs the float64 and float32
 oracles, tensor by tensor, with the rows / columns of the layer-1 gradient that are off — how the relu-sign-at-zero cases of round 6 were read
-(DESIGN section 2).  usage: python tools/fuzz_diag.py obs acts hidden1 hidden2 batch"""
+(DESIGN section 2).  usage: python tests/_fuzz_diag_dqn.py obs acts hidden1 hidden2 batch"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -4,7 +4,7 @@ stream, the float32 AND the float64 oracle (oracle/sac1_oracle.py: torch CPU, au
 The float32 oracle is an independent float32 implementation of the same update, so its own separation from the float64 trajectory is the
 yardstick: rounding differences feed back through Adam and the targets, two float32 trajectories drift apart like a random walk, and a
 systematic error (a beta^t product, a polyak image, a stale operand) would make the HIP learner leave the float64 oracle FASTER than the
-float32 oracle does.  Used by tests/test_gpu_sac1.py and tools/long_horizon.py."""
+float32 oracle does.  Used by tests/test_gpu_sac1.py and tests/_long_horizon_table.py."""
 import numpy as np
 import torch
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Dev tool: the long-horizon table of tests/_long_horizon.py (HIP learner beside the float32 and float64 oracles).
-usage: python tools/long_horizon.py [n_updates] [lr]"""
+"""Checker-side helper (imports the oracles, hence under tests/): the long-horizon table of tests/_long_horizon.py (HIP learner beside the float32 and float64 oracles).
+usage: python tests/_long_horizon_table.py [n_updates] [lr]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # _long_horizon lives beside this file
 import numpy as np
 import _long_horizon as lh
 from distributed_drl_amd.agent import HyperParameters, Learner
