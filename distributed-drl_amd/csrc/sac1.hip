@@ -632,25 +632,39 @@ __global__ void __launch_bounds__(256) k_act_one(ActOneArgs a) {
     const int tid = threadIdx.x;
     if (tid < a.d0) xs[tid] = a.obs[tid];
     __syncthreads();
-    for (int j = tid; j < a.h1; j += 256) {
-        float acc = a.pi.b1[j];
-        for (int d = 0; d < a.d0; ++d) acc += xs[d] * a.pi.W1[(long long)d * a.h1 + j];
-        h1s[j] = fmaxf(acc, 0.f);
+    const int col = tid & (A1_COLS - 1), slice = tid >> 4, c = blockIdx.x * A1_COLS + col;
+    const int per = (a.h1 + 15) >> 4, k0 = slice * per, k1 = k0 + per < a.h1 ? k0 + per : a.h1;   // per <= 32
+    // this thread's layer-2 operands are requested now (they do not depend on layer 1): one round trip under the layer-1 phase
+    float w2[32];
+    const int cc2 = c < a.h2 ? c : 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int k = k0 + q < k1 ? k0 + q : (k0 < a.h1 ? k0 : 0);
+        w2[q] = a.pi.W2[(long long)k * a.h2 + cc2];
+    }
+    {   // layer 1: units tid and tid + 256, eight input rows per round trip for both
+        const int j0 = tid < a.h1 ? tid : 0, j1 = tid + 256 < a.h1 ? tid + 256 : 0;
+        float acc0 = a.pi.b1[j0], acc1 = a.pi.b1[j1];
+        for (int d = 0; d < a.d0; d += 8) {
+            float u0[8], u1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int dd = d + q < a.d0 ? d + q : 0;
+                u0[q] = a.pi.W1[(long long)dd * a.h1 + j0]; u1[q] = a.pi.W1[(long long)dd * a.h1 + j1];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (d + q < a.d0) { acc0 += xs[d + q] * u0[q]; acc1 += xs[d + q] * u1[q]; }
+        }
+        if (tid < a.h1) h1s[tid] = fmaxf(acc0, 0.f);
+        if (tid + 256 < a.h1) h1s[tid + 256] = fmaxf(acc1, 0.f);
     }
     __syncthreads();
-    const int col = tid & (A1_COLS - 1), slice = tid >> 4, c = blockIdx.x * A1_COLS + col;
-    const int per = (a.h1 + 15) >> 4, k0 = slice * per, k1 = k0 + per < a.h1 ? k0 + per : a.h1;
     float acc = 0.f;
     if (c < a.h2) {
-        int k = k0;
-        for (; k + 8 <= k1; k += 8) {   // eight loads in flight, one chain of additions (k order)
-            float w[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) w[q] = a.pi.W2[(long long)(k + q) * a.h2 + c];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += h1s[k + q] * w[q];
-        }
-        for (; k < k1; ++k) acc += h1s[k] * a.pi.W2[(long long)k * a.h2 + c];
+        for (int q = 0; q < 32; ++q)
+            if (k0 + q < k1) acc += h1s[k0 + q] * w2[q];   // k order
     }
     ps[slice][col] = acc;
     __syncthreads();
@@ -682,13 +696,17 @@ __global__ void __launch_bounds__(256) k_act_one(ActOneArgs a) {
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    __shared__ float s_part[32 * 16];
+    for (int i = tid; i < (int)gridDim.x * 16; i += 256)   // every partial in ONE round trip (a serial chain of device-scope loads by one thread: +7 us)
+        s_part[i] = __hip_atomic_load(&a.part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (tid == 0) {
         float mu[4] = {0.f, 0.f, 0.f, 0.f}, ls[4] = {0.f, 0.f, 0.f, 0.f}, ev[4] = {0.f, 0.f, 0.f, 0.f};
         for (int o = 0; o < a.act; ++o) {
             float sm = 0.f, sl = 0.f;
             for (unsigned b = 0; b < gridDim.x; ++b) {   // workgroup order
-                sm += __hip_atomic_load(&a.part[b * 16 + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sl += __hip_atomic_load(&a.part[b * 16 + a.act + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sm += s_part[b * 16 + o];
+                sl += s_part[b * 16 + a.act + o];
             }
             mu[o] = sm + a.pi.bmu[o]; ls[o] = sl + a.pi.bls[o];
             ev[o] = a.deterministic ? 0.f : ddrl_pol::normal_at(a.seed, a.ctr + (unsigned long long)o);
